@@ -1,0 +1,122 @@
+"""ctypes wrapper over oracle/_build/libmapf_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+package (mapf_gpt_amd/) never imports this module.
+
+`OracleGenerator` mirrors the reference's pybind class ObservationGenerator
+(mapf_gpt/observation_generator.cpp:558-562): same three calls, list/array in, uint8 rows out.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libmapf_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """gcc-compile the C restatement (seconds)."""
+    src = os.path.join(_HERE, "mapf_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def build_ref():
+    """Compile the REAL reference tokenizer into oracle/_ref (only where /root/reference exists)."""
+    if not os.path.isdir("/root/reference/mapf_gpt"):
+        return None
+    subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.join(_HERE, "_ref")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, i32, u8p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+        L.orc_bfs.argtypes = [u8p, i32, i32, i32, i32, vp]
+        L.orc_bfs.restype = None
+        L.orc_gen_create.argtypes = [u8p, i32, i32]
+        L.orc_gen_create.restype = vp
+        L.orc_gen_destroy.argtypes = [vp]
+        L.orc_gen_create_agents.argtypes = [vp, i32, vp, vp]
+        L.orc_gen_update_agents.argtypes = [vp, vp, vp, vp]
+        L.orc_gen_generate_observations.argtypes = [vp, vp]
+        for f in ("orc_gen_dist", "orc_gen_next", "orc_gen_hist"):
+            getattr(L, f).argtypes = [vp]
+            getattr(L, f).restype = vp
+        L.orc_env_step.argtypes = [u8p, i32, i32, i32, vp, vp, vp]
+        L.orc_env_step.restype = i32
+        _lib = L
+    return _lib
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def bfs(grid, goal):
+    g = np.ascontiguousarray(np.asarray(grid) != 0, dtype=np.uint8)
+    H, W = g.shape
+    out = np.empty((H, W), dtype=np.uint16)
+    lib().orc_bfs(g.ctypes.data, H, W, int(goal[0]), int(goal[1]), out.ctypes.data)
+    return out
+
+
+class OracleGenerator:
+    """One env instance; mirrors ObservationGenerator(grid, cfg) with the default InputParameters
+    of inference.py:15-29 (the only ones the reference ever passes)."""
+
+    def __init__(self, grid):
+        self.grid = np.ascontiguousarray(np.asarray(grid) != 0, dtype=np.uint8)
+        self.H, self.W = self.grid.shape
+        self._h = lib().orc_gen_create(self.grid.ctypes.data, self.H, self.W)
+        self.n = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_gen_destroy(self._h)
+            self._h = None
+
+    def create_agents(self, positions, goals):
+        p, g = _i32(positions).reshape(-1, 2), _i32(goals).reshape(-1, 2)
+        self.n = p.shape[0]
+        lib().orc_gen_create_agents(self._h, self.n, p.ctypes.data, g.ctypes.data)
+
+    def update_agents(self, positions, goals, actions):
+        p, g, a = _i32(positions).reshape(-1, 2), _i32(goals).reshape(-1, 2), _i32(actions)
+        assert p.shape[0] == self.n and a.shape[0] == self.n
+        lib().orc_gen_update_agents(self._h, p.ctypes.data, g.ctypes.data, a.ctypes.data)
+
+    def generate_observations(self):
+        out = np.empty((self.n, 256), dtype=np.uint8)
+        lib().orc_gen_generate_observations(self._h, out.ctypes.data)
+        return out
+
+    def dist(self):
+        ptr = lib().orc_gen_dist(self._h)
+        buf = (ctypes.c_uint16 * (self.n * self.H * self.W)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint16).reshape(self.n, self.H, self.W).copy()
+
+    def next_tokens(self):
+        ptr = lib().orc_gen_next(self._h)
+        return np.frombuffer((ctypes.c_uint8 * self.n).from_address(ptr), dtype=np.uint8).copy()
+
+    def hist_tokens(self):
+        ptr = lib().orc_gen_hist(self._h)
+        return np.frombuffer((ctypes.c_uint8 * (self.n * 5)).from_address(ptr), dtype=np.uint8).reshape(self.n, 5).copy()
+
+
+def env_step(grid, pos, goal, actions):
+    """Our env spec (parity unpinned).  Returns (new_pos int32[n,2], n_on_goal)."""
+    g = np.ascontiguousarray(np.asarray(grid) != 0, dtype=np.uint8)
+    H, W = g.shape
+    p = _i32(pos).reshape(-1, 2).copy()
+    gl, a = _i32(goal).reshape(-1, 2), _i32(actions)
+    k = lib().orc_env_step(g.ctypes.data, H, W, p.shape[0], p.ctypes.data, gl.ctypes.data, a.ctypes.data)
+    return p, int(k)

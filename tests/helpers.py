@@ -1,0 +1,36 @@
+"""Shared test helpers (CPU side)."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def tok_cases():
+    return sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, "tok_*.npz"))
+                  if "known_answer" not in p)
+
+
+def load_tok(name):
+    return np.load(os.path.join(GOLDEN, f"tok_{name}.npz"))
+
+
+def replay_oracle(case):
+    """Run the C oracle over a golden trajectory -> uint8 [S, n, 256] (all agents)."""
+    grid, P, G, A = case["grid"], case["pos"], case["goal"], case["actions"]
+    gen = orc.OracleGenerator(grid)
+    out = []
+    for t in range(P.shape[0]):
+        if t == 0:
+            gen.create_agents(P[0], G[0])
+        gen.update_agents(P[t], G[t], A[t].astype(np.int32))
+        out.append(gen.generate_observations())
+    return np.array(out)
+
+
+def sha_rows(tokens):
+    return hashlib.sha256(np.ascontiguousarray(tokens, dtype=np.uint8).tobytes()).hexdigest()
