@@ -1,0 +1,187 @@
+/*
+ * mapf_gpt_amd.h -- C ABI of libmapf_gpt_amd.so, the MI355X (gfx950) implementation of
+ * MAPF-GPT's per-step hot path:  env step -> observation tokenizer -> GPT forward -> action.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference interface it replaces
+ * (file:line in CognitiveAISystems/MAPF-GPT).  Conventions:
+ *   - plain C types only; every `d_*` pointer is a DEVICE pointer (HBM) owned by the caller;
+ *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and returns without synchronising unless its comment says otherwise;
+ *   - returns MGPT_OK or an error code; no exception crosses the ABI; mgpt_last_error() gives a
+ *     thread-local message for the last failing call;
+ *   - contexts own their internal device state; the caller owns every buffer it passes in;
+ *   - a context may be used from one thread at a time; different contexts are independent
+ *     (no hidden globals besides the per-thread error string);
+ *   - the library never falls back to the CPU: with no HIP device every compute call fails.
+ *
+ * Coordinates are (row, col) int16 pairs in the PADDED map frame (5 obstacle cells on every
+ * side), exactly what the reference hands to its tokenizer (inference.py:130-131).
+ */
+#ifndef MAPF_GPT_AMD_H
+#define MAPF_GPT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGPT_OK 0
+#define MGPT_ERR_ARG 1          /* bad argument (NULL, size, unsupported shape)              */
+#define MGPT_ERR_HIP 2          /* a HIP runtime call failed (message has hipGetErrorString) */
+#define MGPT_ERR_STATE 3        /* call order violated (e.g. tokens before create_agents)    */
+#define MGPT_ERR_UNSUPPORTED 4  /* shape/precision outside what the kernels implement        */
+
+#define MGPT_CONTEXT 256        /* tokens per observation row (observation_generator.cpp:386) */
+#define MGPT_VOCAB 67           /* observation_generator.cpp:321-344                          */
+#define MGPT_NUM_ACTIONS 5      /* model.py:250-252                                           */
+
+/* thread-local text of the last error on this thread ("" if none) */
+const char *mgpt_last_error(void);
+/* ABI version (major*1000 + minor) */
+int mgpt_abi_version(void);
+/* number of visible HIP devices (0 and MGPT_OK when there is none) */
+int mgpt_device_count(int *count);
+
+/* ------------------------------------------------------------------------------------------
+ * Tokenizer: replaces the pybind module `observation_generator`
+ * (observation_generator.cpp:546-563), batched over many env instances.
+ * ------------------------------------------------------------------------------------------ */
+
+/* = struct InputParameters, observation_generator.h:22-40 / ctor args cpp:551.
+ * The kernels implement the configuration the reference always passes (inference.py:15-29):
+ * limit 20, 13 agents, 5 previous actions, context 256, radii 5; other values -> MGPT_ERR_UNSUPPORTED.
+ * grid_step and save_cost2go only steer the reference's CPU caching of distance fields
+ * (cpp:43-132) and do not change any token; they are accepted and ignored. */
+typedef struct mgpt_input_parameters {
+    int32_t cost2go_value_limit;
+    int32_t num_agents;
+    int32_t num_previous_actions;
+    int32_t context_size;
+    int32_t obs_radius;
+    int32_t agents_radius;
+    int32_t grid_step;
+    int32_t save_cost2go;
+} mgpt_input_parameters;
+
+typedef struct mgpt_tokenizer mgpt_tokenizer;
+
+/* = ObservationGenerator::ObservationGenerator(grid, cfg), observation_generator.h:112-119, for
+ * n_inst instances x n_agents agents sharing one padded frame H x W.  `n_grids` distinct obstacle
+ * maps are stored; instance i uses map i % n_grids (n_grids == 1: one shared map). */
+int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_parameters *cfg,
+                          int n_inst, int n_agents, int H, int W, int n_grids);
+int mgpt_tokenizer_destroy(mgpt_tokenizer *tok);
+
+/* the `grid` ctor argument (h:112): d_grids = uint8 [n_grids, H, W], non-zero = blocked */
+int mgpt_tokenizer_set_grids(mgpt_tokenizer *tok, const uint8_t *d_grids, void *stream);
+
+/* = create_agents(positions, goals), cpp:391-410: history <- "n"x5, one BFS distance-to-goal field
+ * per agent (cpp:200-286), greedy-direction bits (cpp:412-430).
+ * d_pos, d_goal: int16 [n_inst, n_agents, 2]. */
+int mgpt_tokenizer_create_agents(mgpt_tokenizer *tok, const int16_t *d_pos, const int16_t *d_goal,
+                                 void *stream);
+
+/* = update_agents(positions, goals, actions), cpp:432-485.  d_actions: int32 [n_inst, n_agents],
+ * the policy's previous INTENDED actions (inference.py:140-144,168); values outside 0..4 append "n".
+ * goals_may_change != 0 re-runs the BFS of every agent whose goal differs (cpp:464-468);
+ * 0 skips that comparison (on_target = "nothing": goals never change). */
+int mgpt_tokenizer_update_agents(mgpt_tokenizer *tok, const int16_t *d_pos, const int16_t *d_goal,
+                                 const int32_t *d_actions, int goals_may_change, void *stream);
+
+/* = generate_observations(), cpp:516-528.  d_tokens: uint8 [n_inst * n_agents, 256], row-major,
+ * row = inst * n_agents + agent.  Token ids are < 67 and fit a byte (the reference widens them to
+ * int64 only for torch.nn.Embedding, inference.py:91,97).  Positions of one instance must be
+ * pairwise distinct (always true for env states). */
+int mgpt_tokenizer_generate_observations(mgpt_tokenizer *tok, uint8_t *d_tokens, void *stream);
+
+/* test/debug read-backs (device pointers into the context's state, valid until destroy):
+ * distance fields uint16 [n_inst, n_agents, H, W]; agent records 16 B each
+ * {int16 pos_r,pos_c,goal_r,goal_c; uint8 hist[5]; uint8 next; uint8 pad[2]}. */
+int mgpt_tokenizer_state(mgpt_tokenizer *tok, const uint16_t **d_dist, const void **d_records);
+/* same state copied into caller-owned device buffers (either may be NULL) */
+int mgpt_tokenizer_copy_state(mgpt_tokenizer *tok, uint16_t *d_dist_out, void *d_records_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Environment step: the part of the loop the reference delegates to POGEMA
+ * (experiment_setup/create_env.py:36-46; call shape create_env.py:14-20).  POGEMA is not in the
+ * reference tree: this implements the spec in DESIGN.md ("Env step spec"), parity unpinned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mgpt_env mgpt_env;
+
+int mgpt_env_create(mgpt_env **out, int n_inst, int n_agents, int H, int W, int n_grids,
+                    int max_episode_steps);
+int mgpt_env_destroy(mgpt_env *env);
+int mgpt_env_set_grids(mgpt_env *env, const uint8_t *d_grids, void *stream);
+/* = env.reset(): copies starts/goals (int16 [n_inst,n_agents,2]) and clears episode counters. */
+int mgpt_env_reset(mgpt_env *env, const int16_t *d_pos, const int16_t *d_goal, void *stream);
+/* = env.step(actions): d_actions int32 [n_inst, n_agents] in {0 wait,1 up,2 down,3 left,4 right}.
+ * Instances that are already done ignore the actions. */
+int mgpt_env_step(mgpt_env *env, const int32_t *d_actions, void *stream);
+/* device views of the env state: pos/goal int16 [n_inst,n_agents,2]; done uint8 [n_inst]
+ * (1 terminated = all on goal, 2 truncated = max_episode_steps reached); */
+int mgpt_env_state(mgpt_env *env, const int16_t **d_pos, const int16_t **d_goal, const uint8_t **d_done);
+/* the same state copied (stream-ordered, device to device) into caller-owned buffers; any may be NULL */
+int mgpt_env_copy_state(mgpt_env *env, int16_t *d_pos_out, int16_t *d_goal_out, uint8_t *d_done_out, void *stream);
+/* per-instance episode metrics, float32 [n_inst, 5] = {CSR, ISR, SoC, makespan, ep_length}
+ * (the keys the reference's result tables use: eval_configs/05-puzzles/05-puzzles.yaml:49-58). */
+int mgpt_env_metrics(mgpt_env *env, float *d_metrics, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Policy forward: replaces GPT.forward / GPT.act (mapf_gpt/model.py:167-189, 244-260).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mgpt_gpt mgpt_gpt;
+
+#define MGPT_PREC_F32 0     /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-5 parity path        */
+#define MGPT_PREC_F16X3 1   /* split-fp16 (hi/lo, 3 MFMA passes, fp32 accumulate): ~fp32 accuracy     */
+#define MGPT_PREC_BF16 2    /* single-pass bf16 MFMA, fp32 accumulate: the reference's autocast mode  */
+
+/* = GPTConfig + GPT.__init__ (model.py:107-145): bias=False, dropout=0, vocab 67.
+ * max_rows = largest batch one forward call will see (activation workspace is sized for it). */
+int mgpt_gpt_create(mgpt_gpt **out, int n_layer, int n_head, int n_embd, int block_size, int max_rows);
+int mgpt_gpt_destroy(mgpt_gpt *gpt);
+
+/* = load_state_dict (inference.py:83).  `name` is the reference state_dict key
+ * ("transformer.h.3.attn.c_attn.weight", ...; lm_head.weight is tied to transformer.wte.weight,
+ * model.py:138, either name sets both).  data: float32, HOST or DEVICE pointer (is_device),
+ * n_elem must match the parameter's size.  Synchronous. */
+int mgpt_gpt_set_param(mgpt_gpt *gpt, const char *name, const float *data, int64_t n_elem, int is_device);
+/* call once after all parameters are set (builds the packed operand planes of the chosen precisions) */
+int mgpt_gpt_finalize(mgpt_gpt *gpt);
+
+/* = GPT.forward(idx)[0][:, -1, :] (model.py:167-189): d_tokens uint8 [rows, 256] ->
+ * d_logits float32 [rows, 67] (logits of the LAST position, the only ones the reference computes
+ * at inference, model.py:186). */
+int mgpt_gpt_forward(mgpt_gpt *gpt, const uint8_t *d_tokens, int rows, float *d_logits,
+                     int precision, void *stream);
+
+/* = GPT.act (model.py:244-260): softmax over logits[:5]; do_sample != 0 draws from it with the
+ * library's counter-based RNG keyed by (seed, step, row) -- torch.multinomial's stream is
+ * device-specific and not reproduced -- else arg-max.  d_actions int32 [rows].
+ * d_logits may be NULL, else float32 [rows, 67] is also written. */
+int mgpt_gpt_act(mgpt_gpt *gpt, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits,
+                 int do_sample, uint64_t seed, uint64_t step, int precision, void *stream);
+
+/* test/debug: copy an fp32-path workspace buffer (valid after mgpt_gpt_forward with MGPT_PREC_F32):
+ * which 0 = residual stream x [rows*256, C], 1 = last LayerNorm output, 2 = q|k|v planes
+ * [3][rows][n_head][256][hs], 3 = MLP hidden [rows*256, 4C]; n_elem floats from the start. */
+int mgpt_gpt_debug_copy(mgpt_gpt *gpt, int which, float *d_out, int64_t n_elem, void *stream);
+
+/* sampling alone (same RNG as mgpt_gpt_act), for callers that already hold logits */
+int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_actions, int do_sample,
+                        uint64_t seed, uint64_t step, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel timing hooks (bench.py's live roofline): when enabled, the library brackets every kernel
+ * class with hipEvents on the launch stream.  mgpt_prof_read synchronises the device.
+ * ------------------------------------------------------------------------------------------ */
+#define MGPT_PROF_MAX 32
+int mgpt_prof_enable(int on);
+int mgpt_prof_reset(void);
+/* names[i] (static strings), total_ms[i], launches[i] for i < *n (n in: capacity, out: used) */
+int mgpt_prof_read(const char **names, float *total_ms, int64_t *launches, int *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPF_GPT_AMD_H */

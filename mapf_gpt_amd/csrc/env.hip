@@ -1,0 +1,245 @@
+// env.hip -- batched grid MAPF environment step on MI355X (the part of the loop the reference
+// delegates to POGEMA: experiment_setup/create_env.py:36-46, example.py:41-50).
+//
+// PARITY UNPINNED: POGEMA is a pip dependency of the reference, absent from its tree.  This file
+// implements the spec written in DESIGN.md ("Env step spec") and restated in oracle/mapf_oracle.c
+// (orc_env_step); tests check it bit-for-bit against that restatement and through invariants.
+//
+//   actions: 0 wait, 1 up(-1,0), 2 down(+1,0), 3 left(0,-1), 4 right(0,+1)
+//   "soft" collisions, order-independent fixpoint:
+//     1. a move into a blocked / out-of-frame cell becomes wait;
+//     2. two agents swapping along an edge both wait;
+//     3. until stable: a moving agent whose target is claimed by >= 2 agents reverts to wait
+//        (a waiting agent claims its own cell).
+//   on_target = "nothing": agents stay on the grid; terminated when all stand on their goals,
+//   truncated after max_episode_steps.
+//
+// One workgroup per instance, one thread per agent; the per-agent current/target cell ids live in
+// LDS and every conflict test is an O(n_agents) LDS scan (n_agents <= 1024), so no per-cell scratch
+// grid is needed.  Traffic is ~13 B per agent-step: negligible next to the tokenizer and the policy.
+#include "common.h"
+
+using namespace mgpt;
+
+namespace {
+
+__global__ void env_reset_kernel(int16_t *__restrict__ pos, int16_t *__restrict__ goal, const int16_t *__restrict__ pos0,
+                                 const int16_t *__restrict__ goal0, int32_t *__restrict__ arrive,
+                                 int32_t *__restrict__ tcount, uint8_t *__restrict__ done, int n_inst, int n_agents)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = n_inst * n_agents;
+    if (i < total) {
+        const int16_t pr = pos0[2 * i], pc = pos0[2 * i + 1], gr = goal0[2 * i], gc = goal0[2 * i + 1];
+        pos[2 * i] = pr; pos[2 * i + 1] = pc;
+        goal[2 * i] = gr; goal[2 * i + 1] = gc;
+        arrive[i] = (pr == gr && pc == gc) ? 0 : -1;
+    }
+    if (i < n_inst) { tcount[i] = 0; done[i] = 0; }
+}
+
+__global__ __launch_bounds__(1024) void env_step_kernel(const uint8_t *__restrict__ grids, int n_grids, int n_agents,
+                                                        int H, int W, int max_steps, int16_t *__restrict__ pos,
+                                                        const int16_t *__restrict__ goal,
+                                                        const int32_t *__restrict__ actions, int32_t *__restrict__ arrive,
+                                                        int32_t *__restrict__ tcount, uint8_t *__restrict__ done)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *cur = reinterpret_cast<int *>(smem);
+    int *tgt = cur + n_agents;
+    const int inst = blockIdx.x;
+    if (done[inst] != 0) return;                      // workgroup-uniform
+    const uint8_t *grid = grids + (size_t)(inst % n_grids) * H * W;
+    const int a = threadIdx.x;
+    const bool valid = a < n_agents;
+    const size_t g = (size_t)inst * n_agents + a;
+
+    int my_cur = -1, my_tgt = -1, pr = 0, pc = 0;
+    if (valid) {
+        pr = pos[2 * g]; pc = pos[2 * g + 1];
+        int act = actions[g];
+        if (act < 0 || act > 4) act = 0;
+        const int dr = (act == 1) ? -1 : (act == 2 ? 1 : 0);
+        const int dc = (act == 3) ? -1 : (act == 4 ? 1 : 0);
+        const int nr = pr + dr, nc = pc + dc;
+        my_cur = pr * W + pc;
+        my_tgt = (nr < 0 || nr >= H || nc < 0 || nc >= W || grid[nr * W + nc] != 0) ? my_cur : nr * W + nc;   // rule 1
+        cur[a] = my_cur;
+        tgt[a] = my_tgt;
+    }
+    __syncthreads();
+    bool swap = false;                                // rule 2, decided on the rule-1 targets
+    if (valid && my_tgt != my_cur) {
+        for (int b = 0; b < n_agents; b++)
+            if (b != a && cur[b] == my_tgt && tgt[b] == my_cur) swap = true;
+    }
+    __syncthreads();
+    if (swap) { my_tgt = my_cur; tgt[a] = my_cur; }
+    __syncthreads();
+    for (;;) {                                        // rule 3 (Jacobi: all reads see the previous round)
+        int revert = 0;
+        if (valid && my_tgt != my_cur) {
+            int c = 0;
+            for (int b = 0; b < n_agents; b++) c += (tgt[b] == my_tgt) ? 1 : 0;
+            revert = c > 1;
+        }
+        const int any = __syncthreads_or(revert);
+        if (revert) { my_tgt = my_cur; tgt[a] = my_cur; }
+        __syncthreads();
+        if (!any) break;
+    }
+    const int t_new = tcount[inst] + 1;
+    int on = 0;
+    if (valid) {
+        const int nr = my_tgt / W, nc = my_tgt - nr * W;
+        pos[2 * g] = (int16_t)nr; pos[2 * g + 1] = (int16_t)nc;
+        const int gr = goal[2 * g], gc = goal[2 * g + 1];
+        on = (nr == gr && nc == gc) ? 1 : 0;
+        const bool was_on = (pr == gr && pc == gc);
+        if (on && !was_on) arrive[g] = t_new;         // time of the (latest) arrival
+        if (!on) arrive[g] = -1;
+    }
+    const int n_on = __syncthreads_count(on);
+    if (a == 0) {
+        tcount[inst] = t_new;
+        if (n_on == n_agents) done[inst] = 1;
+        else if (t_new >= max_steps) done[inst] = 2;
+    }
+}
+
+// {CSR, ISR, SoC, makespan, ep_length} per instance (keys of eval_configs/*/*.yaml results_views)
+__global__ void env_metrics_kernel(const int16_t *__restrict__ pos, const int16_t *__restrict__ goal,
+                                   const int32_t *__restrict__ arrive, const int32_t *__restrict__ tcount, int n_inst,
+                                   int n_agents, float *__restrict__ out)
+{
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= n_inst) return;
+    const int t = tcount[inst];
+    int on = 0, soc = 0, mk = 0;
+    for (int a = 0; a < n_agents; a++) {
+        const size_t g = (size_t)inst * n_agents + a;
+        const bool o = pos[2 * g] == goal[2 * g] && pos[2 * g + 1] == goal[2 * g + 1];
+        const int ta = o ? max(arrive[g], 0) : t;
+        on += o ? 1 : 0;
+        soc += ta;
+        mk = max(mk, ta);
+    }
+    float *m = out + (size_t)inst * 5;
+    m[0] = (on == n_agents) ? 1.f : 0.f;
+    m[1] = (float)on / (float)n_agents;
+    m[2] = (float)soc;
+    m[3] = (float)mk;
+    m[4] = (float)t;
+}
+
+}  // namespace
+
+struct mgpt_env {
+    int n_inst, n_agents, H, W, n_grids, max_steps;
+    uint8_t *grids = nullptr;
+    int16_t *pos = nullptr, *goal = nullptr;
+    int32_t *arrive = nullptr, *tcount = nullptr;
+    uint8_t *done = nullptr;
+    bool have_grids = false, have_reset = false;
+};
+
+extern "C" int mgpt_env_create(mgpt_env **out, int n_inst, int n_agents, int H, int W, int n_grids, int max_episode_steps)
+{
+    MGPT_REQUIRE(out, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(n_inst > 0 && n_agents > 0 && H > 0 && W > 0 && n_grids > 0 && n_grids <= n_inst && max_episode_steps > 0,
+                 MGPT_ERR_ARG, "bad sizes");
+    MGPT_REQUIRE(n_agents <= 1024, MGPT_ERR_UNSUPPORTED, "n_agents=%d > 1024 (one thread per agent)", n_agents);
+    mgpt_env *e = new mgpt_env();
+    e->n_inst = n_inst; e->n_agents = n_agents; e->H = H; e->W = W; e->n_grids = n_grids; e->max_steps = max_episode_steps;
+    const size_t total = (size_t)n_inst * n_agents;
+    hipError_t err = hipMalloc(&e->grids, (size_t)n_grids * H * W);
+    if (err == hipSuccess) err = hipMalloc(&e->pos, total * 2 * sizeof(int16_t));
+    if (err == hipSuccess) err = hipMalloc(&e->goal, total * 2 * sizeof(int16_t));
+    if (err == hipSuccess) err = hipMalloc(&e->arrive, total * sizeof(int32_t));
+    if (err == hipSuccess) err = hipMalloc(&e->tcount, (size_t)n_inst * sizeof(int32_t));
+    if (err == hipSuccess) err = hipMalloc(&e->done, (size_t)n_inst);
+    if (err != hipSuccess) {
+        set_error("hipMalloc failed in mgpt_env_create: %s", hipGetErrorString(err));
+        mgpt_env_destroy(e);
+        return MGPT_ERR_HIP;
+    }
+    *out = e;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_env_destroy(mgpt_env *e)
+{
+    if (!e) return MGPT_OK;
+    (void)hipFree(e->grids); (void)hipFree(e->pos); (void)hipFree(e->goal);
+    (void)hipFree(e->arrive); (void)hipFree(e->tcount); (void)hipFree(e->done);
+    delete e;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_env_set_grids(mgpt_env *e, const uint8_t *d_grids, void *stream)
+{
+    MGPT_REQUIRE(e && d_grids, MGPT_ERR_ARG, "NULL argument");
+    MGPT_HIP(hipMemcpyAsync(e->grids, d_grids, (size_t)e->n_grids * e->H * e->W, hipMemcpyDeviceToDevice,
+                            (hipStream_t)stream));
+    e->have_grids = true;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_env_reset(mgpt_env *e, const int16_t *d_pos, const int16_t *d_goal, void *stream)
+{
+    MGPT_REQUIRE(e && d_pos && d_goal, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(e->have_grids, MGPT_ERR_STATE, "mgpt_env_set_grids must precede reset");
+    hipStream_t s = (hipStream_t)stream;
+    const int total = e->n_inst * e->n_agents;
+    hipLaunchKernelGGL(env_reset_kernel, dim3(cdiv(total > e->n_inst ? total : e->n_inst, 256)), dim3(256), 0, s, e->pos,
+                       e->goal, d_pos, d_goal, e->arrive, e->tcount, e->done, e->n_inst, e->n_agents);
+    MGPT_LAUNCH_CHECK();
+    e->have_reset = true;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_env_step(mgpt_env *e, const int32_t *d_actions, void *stream)
+{
+    MGPT_REQUIRE(e && d_actions, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(e->have_reset, MGPT_ERR_STATE, "mgpt_env_reset must precede step");
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = cdiv(e->n_agents, 64) * 64;
+    ProfScope ps(P_ENV_STEP, s);
+    hipLaunchKernelGGL(env_step_kernel, dim3(e->n_inst), dim3(threads), (size_t)e->n_agents * 2 * sizeof(int), s, e->grids,
+                       e->n_grids, e->n_agents, e->H, e->W, e->max_steps, e->pos, e->goal, d_actions, e->arrive,
+                       e->tcount, e->done);
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_env_state(mgpt_env *e, const int16_t **d_pos, const int16_t **d_goal, const uint8_t **d_done)
+{
+    MGPT_REQUIRE(e, MGPT_ERR_ARG, "NULL argument");
+    if (d_pos) *d_pos = e->pos;
+    if (d_goal) *d_goal = e->goal;
+    if (d_done) *d_done = e->done;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_env_metrics(mgpt_env *e, float *d_metrics, void *stream)
+{
+    MGPT_REQUIRE(e && d_metrics, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(e->have_reset, MGPT_ERR_STATE, "mgpt_env_reset must precede metrics");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(P_ENV_METRICS, s);
+    hipLaunchKernelGGL(env_metrics_kernel, dim3(cdiv(e->n_inst, 64)), dim3(64), 0, s, e->pos, e->goal, e->arrive,
+                       e->tcount, e->n_inst, e->n_agents, d_metrics);
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_env_copy_state(mgpt_env *e, int16_t *d_pos_out, int16_t *d_goal_out, uint8_t *d_done_out, void *stream)
+{
+    MGPT_REQUIRE(e, MGPT_ERR_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nb = (size_t)e->n_inst * e->n_agents * 2 * sizeof(int16_t);
+    if (d_pos_out) MGPT_HIP(hipMemcpyAsync(d_pos_out, e->pos, nb, hipMemcpyDeviceToDevice, s));
+    if (d_goal_out) MGPT_HIP(hipMemcpyAsync(d_goal_out, e->goal, nb, hipMemcpyDeviceToDevice, s));
+    if (d_done_out) MGPT_HIP(hipMemcpyAsync(d_done_out, e->done, (size_t)e->n_inst, hipMemcpyDeviceToDevice, s));
+    return MGPT_OK;
+}

@@ -1,0 +1,324 @@
+// gpt.hip -- policy context, parameter store, forward drivers and the action sampler
+// (replaces mapf_gpt/model.py GPT.forward / GPT.act for inference).
+#include <string>
+
+#include "common.h"
+#include "gpt_ctx.h"
+#include "gpt_kernels_f32.h"
+
+using namespace mgpt;
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kV = MGPT_VOCAB;
+
+// ----- action sampling, model.py:250-259 -----
+// Counter-based RNG: splitmix64 finaliser over (seed, step, row) -> 24-bit uniform.  The same
+// arithmetic is restated in mapf_gpt_amd/sampling.py for host-side verification.
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t step, uint64_t row)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (step + 1ull);
+    z ^= row * 0xD1342543DE82EF95ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ logits, int rows, int32_t *__restrict__ actions,
+                                                     int do_sample, uint64_t seed, uint64_t step, uint64_t row0)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const float *l = logits + (size_t)row * kV;
+    float v[MGPT_NUM_ACTIONS];
+    float mx = -INFINITY;
+    int best = 0;
+#pragma unroll
+    for (int i = 0; i < MGPT_NUM_ACTIONS; i++) {
+        v[i] = l[i];
+        if (v[i] > mx) { mx = v[i]; best = i; }     // first maximum, as torch.topk(k=1) on ties
+    }
+    if (!do_sample) { actions[row] = best; return; }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MGPT_NUM_ACTIONS; i++) { v[i] = expf(v[i] - mx); sum += v[i]; }
+    const float u = uniform01(seed, step, row0 + (uint64_t)row) * sum;
+    float c = 0.f;
+    int a = MGPT_NUM_ACTIONS - 1;
+#pragma unroll
+    for (int i = 0; i < MGPT_NUM_ACTIONS; i++) {
+        c += v[i];
+        if (u < c) { a = i; break; }
+    }
+    actions[row] = a;
+}
+
+}  // namespace
+
+static size_t n_tensors(const mgpt_gpt *g) { return 3 + (size_t)g->L * 6; }
+
+extern "C" int mgpt_gpt_create(mgpt_gpt **out, int n_layer, int n_head, int n_embd, int block_size, int max_rows)
+{
+    MGPT_REQUIRE(out, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(n_layer > 0 && n_head > 0 && n_embd > 0 && max_rows > 0, MGPT_ERR_ARG, "bad sizes");
+    MGPT_REQUIRE(block_size == kT, MGPT_ERR_UNSUPPORTED, "block_size must be 256 (config-*.py:13), got %d", block_size);
+    MGPT_REQUIRE(n_embd % n_head == 0, MGPT_ERR_ARG, "n_embd %% n_head != 0 (model.py:27)");
+    const int hs = n_embd / n_head;
+    MGPT_REQUIRE(hs == 32 || hs == 64, MGPT_ERR_UNSUPPORTED, "head size %d: kernels exist for 32 and 64", hs);
+    MGPT_REQUIRE(n_embd % 32 == 0 && n_embd <= 1024, MGPT_ERR_UNSUPPORTED, "n_embd must be a multiple of 32, <= 1024");
+    mgpt_gpt *g = new mgpt_gpt();
+    g->L = n_layer; g->nh = n_head; g->C = n_embd; g->hs = hs; g->block = block_size; g->max_rows = max_rows;
+    const size_t C = n_embd;
+    size_t off = 0;
+    g->off_wte = off; off += (size_t)kV * C;
+    g->off_wpe = off; off += (size_t)kT * C;
+    g->off_lnf = off; off += C;
+    for (int l = 0; l < n_layer; l++) {
+        LayerOff lo;
+        lo.ln1 = off; off += C;
+        lo.attn_w = off; off += 3 * C * C;
+        lo.proj_w = off; off += C * C;
+        lo.ln2 = off; off += C;
+        lo.fc_w = off; off += 4 * C * C;
+        lo.proj2_w = off; off += 4 * C * C;
+        g->layers.push_back(lo);
+    }
+    g->n_params = off;
+    g->is_set.assign(n_tensors(g), 0);
+    const size_t M = (size_t)max_rows * kT;
+    hipError_t e = hipMalloc(&g->params, off * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&g->x, M * C * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&g->xn, M * C * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&g->qkv, 3 * M * C * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&g->hbuf, 4 * M * C * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&g->logits_tmp, (size_t)max_rows * kV * sizeof(float));
+    if (e != hipSuccess) {
+        set_error("hipMalloc failed in mgpt_gpt_create: %s", hipGetErrorString(e));
+        mgpt_gpt_destroy(g);
+        return MGPT_ERR_HIP;
+    }
+    *out = g;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_gpt_destroy(mgpt_gpt *g)
+{
+    if (!g) return MGPT_OK;
+    (void)hipFree(g->params); (void)hipFree(g->x); (void)hipFree(g->xn); (void)hipFree(g->qkv);
+    (void)hipFree(g->hbuf); (void)hipFree(g->logits_tmp);
+    delete g;
+    return MGPT_OK;
+}
+
+// reference state_dict key -> (tensor index, offset, element count)
+static bool locate_param(const mgpt_gpt *g, const char *name_in, size_t *idx, size_t *off, size_t *count)
+{
+    std::string name(name_in);
+    const std::string pre = "_orig_mod.";                       // inference.py:33-44
+    if (name.compare(0, pre.size(), pre) == 0) name = name.substr(pre.size());
+    const size_t C = g->C;
+    if (name == "transformer.wte.weight" || name == "lm_head.weight") { *idx = 0; *off = g->off_wte; *count = kV * C; return true; }
+    if (name == "transformer.wpe.weight") { *idx = 1; *off = g->off_wpe; *count = (size_t)kT * C; return true; }
+    if (name == "transformer.ln_f.weight") { *idx = 2; *off = g->off_lnf; *count = C; return true; }
+    const std::string hp = "transformer.h.";
+    if (name.compare(0, hp.size(), hp) != 0) return false;
+    size_t p = hp.size(), l = 0;
+    if (p >= name.size() || name[p] < '0' || name[p] > '9') return false;
+    while (p < name.size() && name[p] >= '0' && name[p] <= '9') { l = l * 10 + (size_t)(name[p] - '0'); p++; }
+    if (l >= (size_t)g->L || p >= name.size() || name[p] != '.') return false;
+    const std::string rest = name.substr(p + 1);
+    const LayerOff &lo = g->layers[l];
+    const size_t base = 3 + l * 6;
+    if (rest == "ln_1.weight") { *idx = base + 0; *off = lo.ln1; *count = C; return true; }
+    if (rest == "attn.c_attn.weight") { *idx = base + 1; *off = lo.attn_w; *count = 3 * C * C; return true; }
+    if (rest == "attn.c_proj.weight") { *idx = base + 2; *off = lo.proj_w; *count = C * C; return true; }
+    if (rest == "ln_2.weight") { *idx = base + 3; *off = lo.ln2; *count = C; return true; }
+    if (rest == "mlp.c_fc.weight") { *idx = base + 4; *off = lo.fc_w; *count = 4 * C * C; return true; }
+    if (rest == "mlp.c_proj.weight") { *idx = base + 5; *off = lo.proj2_w; *count = 4 * C * C; return true; }
+    return false;
+}
+
+extern "C" int mgpt_gpt_set_param(mgpt_gpt *g, const char *name, const float *data, int64_t n_elem, int is_device)
+{
+    MGPT_REQUIRE(g && name && data, MGPT_ERR_ARG, "NULL argument");
+    size_t idx, off, count;
+    MGPT_REQUIRE(locate_param(g, name, &idx, &off, &count), MGPT_ERR_ARG, "unknown parameter '%s'", name);
+    MGPT_REQUIRE((size_t)n_elem == count, MGPT_ERR_ARG, "parameter '%s': got %lld elements, expected %zu", name,
+                 (long long)n_elem, count);
+    MGPT_HIP(hipMemcpy(g->params + off, data, count * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    g->is_set[idx] = 1;
+    g->finalized = false;
+    return MGPT_OK;
+}
+
+int gpt_fast_finalize(mgpt_gpt *g);   // gpt_fast.hip (packed operand planes); weak no-op until that path exists
+__attribute__((weak)) int gpt_fast_finalize(mgpt_gpt *) { return MGPT_OK; }
+int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, hipStream_t s);
+__attribute__((weak)) int gpt_fast_forward(mgpt_gpt *, const uint8_t *, int, float *, int precision, hipStream_t)
+{
+    set_error("precision %d is not built into this library", precision);
+    return MGPT_ERR_UNSUPPORTED;
+}
+
+extern "C" int mgpt_gpt_finalize(mgpt_gpt *g)
+{
+    MGPT_REQUIRE(g, MGPT_ERR_ARG, "NULL argument");
+    for (size_t i = 0; i < g->is_set.size(); i++)
+        MGPT_REQUIRE(g->is_set[i], MGPT_ERR_STATE, "parameter tensor #%zu was never set (see mgpt_gpt_set_param)", i);
+    int rc = gpt_fast_finalize(g);
+    if (rc != MGPT_OK) return rc;
+    g->finalized = true;
+    return MGPT_OK;
+}
+
+// ----- fp32 forward -----
+template <int EPI>
+static int launch_gemm(const float *A, const float *W, float *out, int64_t M, int N, int K, f32k::EpiArgs ep, int C,
+                       hipStream_t s)
+{
+    MGPT_REQUIRE(M % 128 == 0 && K % 32 == 0, MGPT_ERR_UNSUPPORTED, "gemm shape M=%lld K=%d", (long long)M, K);
+    const int mt = (int)(M / 128);
+    if (C == 160 && N % 160 == 0) {
+        const int ntn = N / 160;
+        hipLaunchKernelGGL((f32k::gemm_f32_kernel<160, 4, 1, EPI>), dim3(mt * ntn), dim3(256), 0, s, A, W, out, (int)M, N, K, ntn, ep);
+    } else if (N % 128 == 0) {
+        const int ntn = N / 128;
+        hipLaunchKernelGGL((f32k::gemm_f32_kernel<128, 2, 2, EPI>), dim3(mt * ntn), dim3(256), 0, s, A, W, out, (int)M, N, K, ntn, ep);
+    } else if (N % 64 == 0) {
+        const int ntn = N / 64;
+        hipLaunchKernelGGL((f32k::gemm_f32_kernel<64, 4, 1, EPI>), dim3(mt * ntn), dim3(256), 0, s, A, W, out, (int)M, N, K, ntn, ep);
+    } else {
+        set_error("gemm N=%d is not a multiple of 64", N);
+        return MGPT_ERR_UNSUPPORTED;
+    }
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+static int launch_layernorm(const float *x, const float *w, float *y, int64_t n_tok, int C, hipStream_t s)
+{
+    ProfScope ps(P_LAYERNORM, s);
+    const dim3 grid((unsigned)cdiv64(n_tok, 4));
+    if (C <= 256) hipLaunchKernelGGL((f32k::layernorm_kernel<1>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C);
+    else if (C <= 512) hipLaunchKernelGGL((f32k::layernorm_kernel<2>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C);
+    else if (C <= 768) hipLaunchKernelGGL((f32k::layernorm_kernel<3>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C);
+    else hipLaunchKernelGGL((f32k::layernorm_kernel<4>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C);
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+static int forward_f32_chunk(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, hipStream_t s)
+{
+    const int C = g->C;
+    const int64_t M = (int64_t)rows * kT;
+    const float *P = g->params;
+    int rc;
+    {
+        ProfScope ps(P_EMBED, s);
+        const int64_t total = M * (C / 4);
+        const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 64);
+        hipLaunchKernelGGL(f32k::embed_kernel, dim3(blocks), dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, M, C);
+        MGPT_LAUNCH_CHECK();
+    }
+    f32k::EpiArgs ep;
+    ep.C = C; ep.n_head = g->nh; ep.hs = g->hs; ep.plane = M * C;
+    const float scale = 1.0f / sqrtf((float)g->hs);
+    float *q = g->qkv, *k = g->qkv + M * C, *v = g->qkv + 2 * M * C;
+    for (int l = 0; l < g->L; l++) {
+        const LayerOff &lo = g->layers[l];
+        if ((rc = launch_layernorm(g->x, P + lo.ln1, g->xn, M, C, s)) != MGPT_OK) return rc;
+        {
+            ProfScope ps(P_GEMM_QKV, s);
+            if ((rc = launch_gemm<f32k::EPI_QKV>(g->xn, P + lo.attn_w, g->qkv, M, 3 * C, C, ep, C, s)) != MGPT_OK) return rc;
+        }
+        {
+            ProfScope ps(P_ATTN, s);
+            if (g->hs == 32) hipLaunchKernelGGL((f32k::attn_f32_kernel<32>), dim3(rows * g->nh), dim3(256), 0, s, q, k, v, g->xn, g->nh, scale);
+            else hipLaunchKernelGGL((f32k::attn_f32_kernel<64>), dim3(rows * g->nh), dim3(256), 0, s, q, k, v, g->xn, g->nh, scale);
+            MGPT_LAUNCH_CHECK();
+        }
+        {
+            ProfScope ps(P_GEMM_PROJ, s);
+            if ((rc = launch_gemm<f32k::EPI_RESID>(g->xn, P + lo.proj_w, g->x, M, C, C, ep, C, s)) != MGPT_OK) return rc;
+        }
+        if ((rc = launch_layernorm(g->x, P + lo.ln2, g->xn, M, C, s)) != MGPT_OK) return rc;
+        {
+            ProfScope ps(P_GEMM_FC, s);
+            if ((rc = launch_gemm<f32k::EPI_GELU>(g->xn, P + lo.fc_w, g->hbuf, M, 4 * C, C, ep, C, s)) != MGPT_OK) return rc;
+        }
+        {
+            ProfScope ps(P_GEMM_PROJ2, s);
+            if ((rc = launch_gemm<f32k::EPI_RESID>(g->hbuf, P + lo.proj2_w, g->x, M, C, 4 * C, ep, C, s)) != MGPT_OK) return rc;
+        }
+    }
+    {
+        ProfScope ps(P_HEAD, s);
+        hipLaunchKernelGGL(f32k::head_kernel, dim3(rows), dim3(64), (size_t)C * sizeof(float), s, g->x, P + g->off_lnf,
+                           P + g->off_wte, d_logits, C, kV);
+        MGPT_LAUNCH_CHECK();
+    }
+    return MGPT_OK;
+}
+
+// debugging aid for the GPU parity tests: copy an fp32-path workspace buffer out after a forward
+// which: 0 = x (residual stream), 1 = xn (last LayerNorm output), 2 = qkv planes, 3 = MLP hidden
+extern "C" int mgpt_gpt_debug_copy(mgpt_gpt *g, int which, float *d_out, int64_t n_elem, void *stream)
+{
+    MGPT_REQUIRE(g && d_out && n_elem > 0, MGPT_ERR_ARG, "bad argument");
+    const int64_t M = (int64_t)g->max_rows * kT, C = g->C;
+    const float *src = which == 0 ? g->x : which == 1 ? g->xn : which == 2 ? g->qkv : which == 3 ? g->hbuf : nullptr;
+    const int64_t cap = which == 2 ? 3 * M * C : which == 3 ? 4 * M * C : M * C;
+    MGPT_REQUIRE(src && n_elem <= cap, MGPT_ERR_ARG, "which=%d n_elem=%lld", which, (long long)n_elem);
+    MGPT_HIP(hipMemcpyAsync(d_out, src, (size_t)n_elem * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_gpt_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, void *stream)
+{
+    MGPT_REQUIRE(g && d_tokens && d_logits, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(rows > 0, MGPT_ERR_ARG, "rows=%d", rows);
+    MGPT_REQUIRE(g->finalized, MGPT_ERR_STATE, "mgpt_gpt_finalize must precede forward");
+    hipStream_t s = (hipStream_t)stream;
+    for (int r0 = 0; r0 < rows; r0 += g->max_rows) {
+        const int n = std::min(g->max_rows, rows - r0);
+        int rc;
+        if (precision == MGPT_PREC_F32) rc = forward_f32_chunk(g, d_tokens + (size_t)r0 * kT, n, d_logits + (size_t)r0 * kV, s);
+        else rc = gpt_fast_forward(g, d_tokens + (size_t)r0 * kT, n, d_logits + (size_t)r0 * kV, precision, s);
+        if (rc != MGPT_OK) return rc;
+    }
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_actions, int do_sample, uint64_t seed,
+                                   uint64_t step, void *stream)
+{
+    MGPT_REQUIRE(d_logits && d_actions && rows > 0, MGPT_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(P_SAMPLE, s);
+    hipLaunchKernelGGL(sample_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, d_logits, rows, d_actions, do_sample, seed, step, (uint64_t)0);
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_gpt_act(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits,
+                            int do_sample, uint64_t seed, uint64_t step, int precision, void *stream)
+{
+    MGPT_REQUIRE(g && d_tokens && d_actions, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(rows > 0, MGPT_ERR_ARG, "rows=%d", rows);
+    MGPT_REQUIRE(g->finalized, MGPT_ERR_STATE, "mgpt_gpt_finalize must precede act");
+    hipStream_t s = (hipStream_t)stream;
+    // row index inside the RNG key is the GLOBAL row of this call, independent of workspace chunking
+    for (int r0 = 0; r0 < rows; r0 += g->max_rows) {
+        const int n = std::min(g->max_rows, rows - r0);
+        float *lg = d_logits ? d_logits + (size_t)r0 * kV : g->logits_tmp;
+        int rc = mgpt_gpt_forward(g, d_tokens + (size_t)r0 * kT, n, lg, precision, stream);
+        if (rc != MGPT_OK) return rc;
+        ProfScope ps(P_SAMPLE, s);
+        hipLaunchKernelGGL(sample_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, lg, n, d_actions + r0, do_sample,
+                           seed, step, (uint64_t)r0);
+        MGPT_LAUNCH_CHECK();
+    }
+    return MGPT_OK;
+}

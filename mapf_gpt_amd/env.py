@@ -1,0 +1,128 @@
+"""Environment surface (the role POGEMA plays for the reference: experiment_setup/create_env.py).
+
+  * `BatchedEnv`   -- device-resident: n_inst instances stepped by one HIP kernel launch.
+  * `GridEnv`      -- the list API the reference drives (create_env.py:14-25, example.py:60-65):
+                      reset() -> (obs_list, info); step(actions) -> (obs, rewards, terminated,
+                      truncated, infos); observations are dicts with the three keys the adapter reads
+                      (inference.py:130-135): global_xy, global_target_xy, global_obstacles.
+PARITY UNPINNED: POGEMA itself is not in the reference tree; semantics are the spec in DESIGN.md.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, maps
+
+METRIC_KEYS = ("CSR", "ISR", "SoC", "makespan", "ep_length")   # eval_configs/*/*.yaml results_views
+
+
+class BatchedEnv:
+    def __init__(self, grids, n_inst, n_agents, max_episode_steps=128, device="cuda"):
+        _lib.require_gpu()
+        self.device = torch.device(device)
+        grids = torch.as_tensor(np.ascontiguousarray(grids) if isinstance(grids, np.ndarray) else grids)
+        if grids.dim() == 2:
+            grids = grids[None]
+        self.grids = (grids != 0).to(torch.uint8).contiguous().to(self.device)
+        self.n_grids, self.H, self.W = self.grids.shape
+        self.n_inst, self.n_agents, self.max_episode_steps = int(n_inst), int(n_agents), int(max_episode_steps)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_env_create(ctypes.byref(self._h), self.n_inst, self.n_agents, self.H, self.W,
+                                                  self.n_grids, self.max_episode_steps))
+            _lib.check(_lib.lib().mgpt_env_set_grids(self._h, _lib.ptr(self.grids), _lib.stream_ptr()))
+        shp = (self.n_inst, self.n_agents, 2)
+        # caller-visible mirrors of the env state, refreshed by sync_state()
+        self.pos = torch.empty(shp, dtype=torch.int16, device=self.device)
+        self.goal = torch.empty(shp, dtype=torch.int16, device=self.device)
+        self.done = torch.zeros((self.n_inst,), dtype=torch.uint8, device=self.device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().mgpt_env_destroy(h)
+            self._h = None
+
+    def reset(self, pos, goal):
+        shp = (self.n_inst, self.n_agents, 2)
+        pos = pos.to(self.device, torch.int16).contiguous()
+        goal = goal.to(self.device, torch.int16).contiguous()
+        assert tuple(pos.shape) == shp and tuple(goal.shape) == shp
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_env_reset(self._h, _lib.ptr(pos), _lib.ptr(goal), _lib.stream_ptr()))
+        self.sync_state()
+
+    def step(self, actions):
+        assert actions.dtype == torch.int32 and actions.is_cuda and actions.numel() == self.n_inst * self.n_agents
+        actions = actions.contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_env_step(self._h, _lib.ptr(actions), _lib.stream_ptr()))
+
+    def state_ptrs(self):
+        p, g, d = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(_lib.lib().mgpt_env_state(self._h, ctypes.byref(p), ctypes.byref(g), ctypes.byref(d)))
+        return p, g, d
+
+    def sync_state(self):
+        """Refresh self.pos / self.goal / self.done (device tensors) from the library's state (async D2D)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_env_copy_state(self._h, _lib.ptr(self.pos), _lib.ptr(self.goal), _lib.ptr(self.done),
+                                                      _lib.stream_ptr()))
+        return self.pos, self.goal, self.done
+
+    def metrics(self):
+        """float32 [n_inst, 5] = CSR, ISR, SoC, makespan, ep_length (device tensor)."""
+        out = torch.empty((self.n_inst, 5), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_env_metrics(self._h, _lib.ptr(out), _lib.stream_ptr()))
+        return out
+
+
+class GridEnv:
+    """Single-instance env with the reference's list API (create_env.py:14-25), backed by BatchedEnv.
+
+    cfg keys follow the reference's Environment config (example.py:41-50): map (padded uint8 grid or a
+    named map), num_agents, seed, max_episode_steps, obs_radius (must be 5), on_target ("nothing"),
+    collision_system ("soft")."""
+
+    def __init__(self, map_name=None, grid=None, num_agents=32, seed=0, max_episode_steps=128, obs_radius=5,
+                 on_target="nothing", collision_system="soft", device="cuda"):
+        if obs_radius != 5 or on_target != "nothing" or collision_system != "soft":
+            raise NotImplementedError("only obs_radius=5, on_target='nothing', collision_system='soft' are implemented")
+        if grid is None:
+            self.grid, self.start_ok, self.goal_ok = maps.load_named(map_name)
+        else:
+            self.grid = maps.pad(np.asarray(grid, dtype=np.uint8))
+            self.start_ok = self.goal_ok = None
+        self.num_agents, self.seed, self.max_episode_steps = num_agents, seed, max_episode_steps
+        self._env = BatchedEnv(self.grid, 1, num_agents, max_episode_steps, device=device)
+        self._obst = self.grid.astype(np.float32)
+
+    def _obs(self):
+        pos, goal, _ = self._env.sync_state()
+        pos, goal = pos.cpu().numpy()[0], goal.cpu().numpy()[0]
+        return [{"global_xy": (int(pos[a, 0]), int(pos[a, 1])), "global_target_xy": (int(goal[a, 0]), int(goal[a, 1])),
+                 "global_obstacles": self._obst} for a in range(self.num_agents)]
+
+    def reset(self, seed=None, **kwargs):
+        if seed is not None:
+            self.seed = seed
+        pos, goal = maps.place_agents(self.grid, self.num_agents, self.seed, self.start_ok, self.goal_ok)
+        self._env.reset(torch.from_numpy(pos[None]), torch.from_numpy(goal[None]))
+        return self._obs(), {}
+
+    def step(self, actions):
+        act = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(1, -1)).to(self._env.device)
+        self._env.step(act)
+        obs = self._obs()
+        done = int(self._env.done.cpu()[0])
+        terminated = [done == 1] * self.num_agents
+        truncated = [done == 2] * self.num_agents
+        pos, goal = self._env.pos.cpu().numpy()[0], self._env.goal.cpu().numpy()[0]
+        rewards = [float((pos[a] == goal[a]).all()) for a in range(self.num_agents)]
+        infos = [{} for _ in range(self.num_agents)]
+        if done:
+            m = self._env.metrics().cpu().numpy()[0]
+            infos[0]["metrics"] = {k: float(v) for k, v in zip(METRIC_KEYS, m)}   # create_env.py:18-20
+        return obs, rewards, terminated, truncated, infos

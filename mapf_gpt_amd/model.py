@@ -1,0 +1,155 @@
+"""Host mirror of the reference policy class (mapf_gpt/model.py) over the HIP forward.
+
+`GPTConfig` / `GPT` keep the reference's names and call shapes for the inference surface:
+    GPT(config); load_state_dict(sd, strict=False); to(device); eval();
+    forward(idx) -> (logits [B,1,67], None)        (model.py:167-189, last position only)
+    act(idx, do_sample=True, generator=None) -> LongTensor [B]   (model.py:244-260)
+plus the device-resident fast path `act_tokens(tokens_u8, ...)` used by the batched runner.
+Training helpers of the reference (configure_optimizers, estimate_mfu, crop_block_size) are out of
+scope.  Every compute call goes through the C ABI; there is no
+PyTorch forward here.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+
+
+@dataclass
+class GPTConfig:          # = model.py:107-115 (same field names and defaults)
+    block_size: int = 161
+    vocab_size: int = 67
+    n_layer: int = 8
+    n_head: int = 8
+    n_embd: int = 256
+    dropout: float = 0.0
+    bias: bool = False
+
+
+class GPT:
+    def __init__(self, config, max_rows=2048, precision="f32", device="cuda"):
+        if config.vocab_size != 67:
+            raise ValueError("vocab_size must be 67 (observation_generator.cpp:321-344)")
+        if config.bias or config.dropout != 0.0:
+            raise ValueError("the released models use bias=False, dropout=0.0 (model.py:114-115); nothing else is implemented")
+        self.config = config
+        self.max_rows = int(max_rows)
+        self.precision = precision
+        self.device = torch.device(device)
+        self._h = None
+        self._loaded = False
+        self.training = False
+
+    # ---- lifecycle -------------------------------------------------------------------------
+    def _ensure(self):
+        if self._h is None:
+            _lib.require_gpu()
+            h = ctypes.c_void_p()
+            c = self.config
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().mgpt_gpt_create(ctypes.byref(h), c.n_layer, c.n_head, c.n_embd, c.block_size, self.max_rows))
+            self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().mgpt_gpt_destroy(h)
+            self._h = None
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("mapf_gpt_amd.GPT runs on a HIP device only (no CPU forward in this package)")
+        if self._h is not None and device != self.device and device.index is not None:
+            raise RuntimeError("move the model before loading weights")
+        self.device = device
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def load_state_dict(self, state_dict, strict=False):
+        """Accepts the reference checkpoint's state_dict (tensors or arrays, `_orig_mod.` prefixes allowed,
+        inference.py:33-44).  strict=False (the reference's choice, inference.py:83) skips unknown keys."""
+        self._ensure()
+        sd = weights.strip_prefix(state_dict)
+        unknown = []
+        for k, v in sd.items():
+            a = v.detach().to(torch.float32).cpu().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
+            a = np.ascontiguousarray(a)
+            rc = _lib.lib().mgpt_gpt_set_param(self._h, k.encode(), ctypes.c_void_p(a.ctypes.data), a.size, 0)
+            if rc == _lib.ERR_ARG and b"unknown parameter" in _lib.lib().mgpt_last_error():
+                unknown.append(k)
+                continue
+            _lib.check(rc)
+        if strict and unknown:
+            raise KeyError(f"unexpected keys: {unknown}")
+        _lib.check(_lib.lib().mgpt_gpt_finalize(self._h))
+        self._loaded = True
+        return unknown
+
+    # ---- compute ---------------------------------------------------------------------------
+    def _prec(self, precision):
+        return _lib.PRECISIONS[precision or self.precision]
+
+    def _tokens_u8(self, idx):
+        if idx.dim() != 2 or idx.shape[1] != self.config.block_size or self.config.block_size != 256:
+            raise ValueError(f"idx must be [B, 256] token rows, got {tuple(idx.shape)}")
+        return idx.to(device=self.device, dtype=torch.uint8).contiguous()
+
+    def logits_tokens(self, tokens_u8, precision=None, out=None):
+        """tokens uint8 [rows, 256] on the device -> float32 [rows, 67] (last-position logits)."""
+        assert self._loaded, "load_state_dict first"
+        rows = tokens_u8.shape[0]
+        if out is None:
+            out = torch.empty((rows, 67), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_gpt_forward(self._h, _lib.ptr(tokens_u8), rows, _lib.ptr(out), self._prec(precision),
+                                                   _lib.stream_ptr()))
+        return out
+
+    def act_tokens(self, tokens_u8, do_sample=True, seed=0, step=0, precision=None, out=None, logits_out=None):
+        """Fused forward + 5-way masked softmax + sampling on the device (library RNG keyed by
+        (seed, step, row)) -> int32 [rows]."""
+        assert self._loaded, "load_state_dict first"
+        rows = tokens_u8.shape[0]
+        if out is None:
+            out = torch.empty((rows,), dtype=torch.int32, device=self.device)
+        lp = _lib.ptr(logits_out) if logits_out is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_gpt_act(self._h, _lib.ptr(tokens_u8), rows, _lib.ptr(out), lp, 1 if do_sample else 0,
+                                               int(seed) & (2 ** 64 - 1), int(step), self._prec(precision), _lib.stream_ptr()))
+        return out
+
+    def forward(self, idx, targets=None):
+        if targets is not None:
+            raise NotImplementedError("training loss is out of scope (inference path only)")
+        logits = self.logits_tokens(self._tokens_u8(idx))
+        return logits[:, None, :], None
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def act(self, idx, do_sample=True, generator=None):
+        """= GPT.act (model.py:244-260).  With a torch `generator` the draw is torch.multinomial on the
+        device from OUR logits (same masking/softmax as the reference); without one the library's fused
+        sampler runs.  Returns an int64 tensor [B] (0-d for B == 1, like the reference's .squeeze())."""
+        tokens = self._tokens_u8(idx)
+        if do_sample and generator is not None:
+            logits = self.logits_tokens(tokens)
+            probs = torch.softmax(logits[:, :5], dim=-1)                       # model.py:250-254
+            nxt = torch.multinomial(probs, num_samples=1, generator=generator)  # model.py:257
+            return nxt.squeeze()
+        return self.act_tokens(tokens, do_sample=do_sample).to(torch.int64).squeeze()
+
+
+def build_model(name_or_args, seed=0, scale=1.0, max_rows=2048, precision="f32", device="cuda", state_dict=None):
+    """Convenience: GPT with the named shape ("2M", "6M", "85M", "tiny") and synthetic or given weights."""
+    args = weights.model_args(name_or_args)
+    net = GPT(GPTConfig(**args), max_rows=max_rows, precision=precision, device=device)
+    net.load_state_dict(state_dict if state_dict is not None else weights.synthetic_state_dict(args, seed=seed, scale=scale))
+    return net.eval()

@@ -1,0 +1,82 @@
+"""Host-side logic that needs no GPU: config surface, maps, placement, sampler restatement, sharding."""
+import numpy as np
+import pytest
+
+from mapf_gpt_amd import maps, sampling, weights
+from mapf_gpt_amd.runner import shard_range
+
+
+def test_config_mirrors_reference_fields_and_forbids_extras():
+    from pydantic import ValidationError
+    from mapf_gpt_amd.inference import MAPFGPTInferenceConfig
+    c = MAPFGPTInferenceConfig()
+    # defaults of mapf_gpt/inference.py:13-31
+    assert (c.name, c.num_agents, c.num_previous_actions, c.cost2go_value_limit, c.agents_radius, c.cost2go_radius) == \
+        ("MAPF-GPT", 13, 5, 20, 5, 5)
+    assert (c.path_to_weights, c.device, c.context_size, c.repo_id, c.grid_step, c.save_cost2go, c.batch_size, c.num_process) == \
+        ("weights/MAPF-GPT-2M.pt", None, 256, "aandreychuk/MAPF-GPT", 64, False, 2048, 8)
+    assert not (c.mask_actions_history or c.mask_goal or c.mask_cost2go or c.mask_greed_action)
+    MAPFGPTInferenceConfig(parallel_backend="balanced_dask", num_process=4)     # 01-random.yaml:147-148
+    with pytest.raises(ValidationError):
+        MAPFGPTInferenceConfig(not_a_field=1)                                   # extra=forbid, inference.py:13
+
+
+def test_named_maps_and_padding():
+    for name, shape in {"validation-random-seed-000": (30, 31), "validation-mazes-seed-000": (31, 31),
+                        "wfi_warehouse": (43, 56), "Berlin_1_256_00": (74, 74), "puzzle-00": (15, 15)}.items():
+        g, s, t = maps.load_named(name)
+        assert g.shape == shape and g[:5].all() and g[-5:].all() and g[:, :5].all() and g[:, -5:].all()
+        assert not (s & (g != 0)).any() and not (t & (g != 0)).any()
+    g, s, t = maps.load_named("wfi_warehouse")
+    assert s.sum() < (g == 0).sum() and t.sum() < (g == 0).sum()      # '@' / '$' restrict starts / goals
+
+
+def test_placement_distinct_connected_and_seeded():
+    g, s, t = maps.load_named("validation-mazes-seed-000")
+    p1, q1 = maps.place_agents(g, 64, 3, s, t)
+    p2, q2 = maps.place_agents(g, 64, 3, s, t)
+    assert np.array_equal(p1, p2) and np.array_equal(q1, q2)
+    assert len({tuple(x) for x in p1}) == 64 and len({tuple(x) for x in q1}) == 64
+    comp = maps.largest_component(g == 0)
+    assert comp[p1[:, 0], p1[:, 1]].all() and comp[q1[:, 0], q1[:, 1]].all()
+    with pytest.raises(ValueError):
+        maps.place_agents(maps.pad(np.zeros((3, 3), np.uint8)), 10, 0)
+
+
+def test_synthetic_generators_shapes():
+    m = maps.maze_map(21, 21, 5)
+    assert m.shape == (21, 21) and 0.15 < m.mean() < 0.5
+    r = maps.random_map(20, 21, 0.15, 1)
+    assert r.shape == (20, 21) and 0.05 < r.mean() < 0.3
+
+
+def test_weights_layout_matches_reference_key_list():
+    sd = weights.synthetic_state_dict("2M", seed=0)
+    assert sum(v.size for k, v in sd.items() if k != "lm_head.weight") == 1_589_440
+    assert sd["lm_head.weight"] is sd["transformer.wte.weight"]
+    assert sd["transformer.h.4.attn.c_attn.weight"].shape == (480, 160)
+    assert sum(v.size for k, v in weights.synthetic_state_dict("6M").items() if k != "lm_head.weight") == 6_378_496
+    again = weights.synthetic_state_dict("2M", seed=0)
+    assert all(np.array_equal(sd[k], again[k]) for k in sd)
+
+
+def test_sampler_restatement_statistics():
+    logits = np.tile(np.log(np.array([0.5, 0.2, 0.1, 0.1, 0.1], np.float32)), (200000, 1))
+    act, _ = sampling.sample(logits, seed=7, step=3)
+    freq = np.bincount(act, minlength=5) / len(act)
+    assert np.abs(freq - [0.5, 0.2, 0.1, 0.1, 0.1]).max() < 5e-3
+    a2, _ = sampling.sample(logits[:100], seed=7, step=3)
+    assert np.array_equal(a2, act[:100])                         # counter-based: prefix-stable
+    a3, _ = sampling.sample(logits[50:100], seed=7, step=3, row0=50)
+    assert np.array_equal(a3, act[50:100])                       # keyed by global row id
+    g, _ = sampling.sample(logits[:4], 0, 0, do_sample=False)
+    assert (g == 0).all()
+
+
+def test_shard_range_partitions():
+    for n, w in [(256, 8), (257, 8), (5, 8), (4096, 3)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
