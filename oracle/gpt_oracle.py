@@ -36,8 +36,8 @@ def forward_logits(sd, args, idx, dtype=torch.float32, return_layers=False):
         q = q.view(B, T, nh, hs).transpose(1, 2)                                    # model.py:51-53
         k = k.view(B, T, nh, hs).transpose(1, 2)
         v = v.view(B, T, nh, hs).transpose(1, 2)
-        att = torch.softmax((q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hs)), dim=-1)   # model.py:58-60, NON-causal
-        y = (att @ v).transpose(1, 2).contiguous().view(B, T, C)                    # model.py:68
+        y = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)   # model.py:58-60
+        y = y.transpose(1, 2).contiguous().view(B, T, C)                            # model.py:68
         x = x + y @ w[p + "attn.c_proj.weight"].t()                                 # model.py:71,102
         h = F.layer_norm(x, (C,), w[p + "ln_2.weight"], None, 1e-5)
         h = F.gelu(h @ w[p + "mlp.c_fc.weight"].t())                                # model.py:85-86 exact-erf GELU

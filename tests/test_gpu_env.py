@@ -1,0 +1,65 @@
+"""HIP env step vs our C restatement (parity of the env is UNPINNED against POGEMA -- see DESIGN.md) + invariants."""
+import numpy as np
+import pytest
+import torch
+
+from mapf_gpt_amd import maps
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,n_agents,n_inst", [("validation-random-seed-000", 32, 6), ("validation-mazes-seed-000", 64, 4),
+                                                  ("puzzle-00", 4, 9), ("wfi_warehouse", 192, 2)])
+def test_env_step_matches_spec_and_invariants(name, n_agents, n_inst):
+    from mapf_gpt_amd.env import BatchedEnv
+    from mapf_gpt_amd.runner import make_instances
+    grid, s_ok, g_ok = maps.load_named(name)
+    pos, goal = make_instances(grid, n_inst, n_agents, 0, s_ok, g_ok)
+    env = BatchedEnv(grid, n_inst, n_agents, max_episode_steps=40)
+    env.reset(pos, goal)
+    p = pos.numpy().astype(np.int32).copy()
+    g = goal.numpy().astype(np.int32)
+    rng = np.random.Generator(np.random.PCG64(11))
+    for t in range(40):
+        act = rng.integers(0, 5, (n_inst, n_agents)).astype(np.int32)
+        if t % 3 == 0:       # provoke swaps and chains: everybody pushes the same way
+            act[:] = rng.integers(1, 5)
+        env.step(torch.from_numpy(act).cuda())
+        got, _, done = env.sync_state()
+        got = got.cpu().numpy().astype(np.int32)
+        for i in range(n_inst):
+            exp, k = orc.env_step(grid, p[i], g[i], act[i])
+            assert np.array_equal(got[i], exp), f"step {t} instance {i}"
+            # invariants: no vertex conflict, never on an obstacle, no edge swap, moves of at most one cell
+            assert len({tuple(x) for x in exp}) == n_agents
+            assert (grid[exp[:, 0], exp[:, 1]] == 0).all()
+            assert (np.abs(exp - p[i]).sum(1) <= 1).all()
+            old = {tuple(x): a for a, x in enumerate(p[i])}
+            for a in range(n_agents):
+                b = old.get(tuple(exp[a]))
+                if b is not None and b != a:
+                    assert tuple(exp[b]) != tuple(p[i][a]), "edge swap"
+            p[i] = exp
+    m = env.metrics().cpu().numpy()
+    assert (m[:, 4] == 40).all() or (env.done.cpu().numpy() == 1).any()
+    on = (p == g).all(2)
+    assert np.allclose(m[:, 1], on.mean(1))
+    assert (env.done.cpu().numpy() != 0).all()          # truncated (2) or terminated (1) after 40 steps
+    frozen = env.sync_state()[0].cpu().numpy().copy()   # done instances ignore further actions
+    env.step(torch.from_numpy(rng.integers(0, 5, (n_inst, n_agents)).astype(np.int32)).cuda())
+    assert np.array_equal(env.sync_state()[0].cpu().numpy(), frozen)
+
+
+def test_grid_env_list_api_shape():
+    """create_env.py:14-25 call shape: reset -> (obs, info); step -> 5-tuple of per-agent lists; metrics at the end."""
+    from mapf_gpt_amd.env import GridEnv
+    env = GridEnv(map_name="validation-random-seed-000", num_agents=8, seed=0, max_episode_steps=5)
+    obs, info = env.reset()
+    assert len(obs) == 8 and set(obs[0]) == {"global_xy", "global_target_xy", "global_obstacles"}
+    assert obs[0]["global_obstacles"].shape == (30, 31)
+    for t in range(5):
+        obs, rew, term, trunc, infos = env.step([0] * 8)
+        assert len(rew) == len(term) == len(trunc) == len(infos) == 8
+    assert all(trunc) and set(infos[0]["metrics"]) == {"CSR", "ISR", "SoC", "makespan", "ep_length"}
+    assert infos[0]["metrics"]["ep_length"] == 5

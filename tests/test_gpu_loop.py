@@ -1,0 +1,97 @@
+"""End-to-end hot path on the device: adapter bookkeeping (inference.py:127-172) and the batched runner,
+teacher-forced against the oracle step by step."""
+import numpy as np
+import pytest
+import torch
+
+from mapf_gpt_amd import maps, weights
+from oracle import gpt_oracle
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+class _GreedyNet:
+    """inject-able `net` (inference.py:79-80) whose act() is deterministic (do_sample=False)."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def act(self, idx, generator=None):
+        return self.net.act(idx, do_sample=False)
+
+
+def test_adapter_act_batch_bookkeeping():
+    from mapf_gpt_amd.env import GridEnv
+    from mapf_gpt_amd.inference import MAPFGPTInference, MAPFGPTInferenceConfig
+    from mapf_gpt_amd.model import build_model
+    net = build_model("tiny", seed=0, max_rows=32)
+    algo = MAPFGPTInference(MAPFGPTInferenceConfig(path_to_weights="synthetic:tiny", batch_size=16), net=_GreedyNet(net))
+    envs = [GridEnv(map_name="validation-random-seed-000", num_agents=12, seed=s, max_episode_steps=8) for s in (0, 1)]
+    sd, args = weights.synthetic_state_dict("tiny", seed=0), weights.model_args("tiny")
+    algo.reset_states()
+    obs = [e.reset()[0] for e in envs]
+    gens = [orc.OracleGenerator(e.grid) for e in envs]
+    last = [np.full(12, -1, np.int32) for _ in envs]
+    for t in range(6):
+        acts = algo.act_batch(obs, positions=[10, 20])            # slot keys, inference.py:151-157
+        assert [len(a) for a in acts] == [12, 12] and all(isinstance(x, int) for x in acts[0])
+        for i, e in enumerate(envs):
+            p = np.array([o["global_xy"] for o in obs[i]], np.int32)
+            g = np.array([o["global_target_xy"] for o in obs[i]], np.int32)
+            if t == 0:
+                gens[i].create_agents(p, g)
+            gens[i].update_agents(p, g, last[i])                  # the adapter must feed ITS OWN previous actions back
+            rows = gens[i].generate_observations()
+            logits = gpt_oracle.forward_logits(sd, args, rows).numpy()
+            top2 = np.sort(logits[:, :5], axis=1)[:, -2:]
+            safe = (top2[:, 1] - top2[:, 0]) > 1e-4
+            exp = logits[:, :5].argmax(1)
+            assert np.array_equal(np.array(acts[i])[safe], exp[safe]), f"step {t} env {i}"
+            last[i] = np.array(acts[i], np.int32)
+            assert algo._last_actions[[10, 20][i]] == acts[i]     # inference.py:168
+        obs = [e.step(a)[0] for e, a in zip(envs, acts)]
+    single = algo.act(obs[0])                                     # inference.py:148-149 -> slot 0, fresh generator
+    assert len(single) == 12 and 0 in algo._obs_generators
+    algo.reset_states()
+    assert algo._obs_generators == {} and algo._last_actions == {}
+
+
+def test_adapter_accepts_pretokenised_rows_and_chunks():
+    from mapf_gpt_amd.inference import MAPFGPTInference, MAPFGPTInferenceConfig
+    from tests.helpers import load_tok
+    algo = MAPFGPTInference(MAPFGPTInferenceConfig(path_to_weights="synthetic:tiny", batch_size=5))
+    rows = load_tok("random000")["tokens"][2, :12].astype(int).tolist()       # inference.py:128,146 pass-through
+    out = algo.act_batch([rows[:7], rows[7:]])
+    assert [len(o) for o in out] == [7, 5] and all(0 <= a <= 4 for o in out for a in o)
+
+
+def test_batched_runner_teacher_forced_vs_oracle():
+    from mapf_gpt_amd.model import build_model
+    from mapf_gpt_amd.runner import BatchedRunner, make_instances
+    grid, s_ok, g_ok = maps.load_named("validation-mazes-seed-000")
+    n_inst, n = 3, 20
+    net = build_model("tiny", seed=0, max_rows=64)
+    pos, goal = make_instances(grid, n_inst, n, 0, s_ok, g_ok)
+    run = BatchedRunner(grid, n_inst, n, net, max_episode_steps=32, seed=5, do_sample=True)
+    run.reset(pos, goal)
+    gens = [orc.OracleGenerator(grid) for _ in range(n_inst)]
+    p, g = pos.numpy().astype(np.int32).copy(), goal.numpy().astype(np.int32)
+    last = np.full((n_inst, n), -1, np.int32)
+    for i in range(n_inst):
+        gens[i].create_agents(p[i], g[i])
+    for t in range(10):
+        run.step()
+        tokens = run.tokens.cpu().numpy().reshape(n_inst, n, 256)
+        actions = run.actions.cpu().numpy()
+        newpos = run.env.sync_state()[0].cpu().numpy().astype(np.int32)
+        for i in range(n_inst):
+            gens[i].update_agents(p[i], g[i], last[i])
+            assert np.array_equal(tokens[i], gens[i].generate_observations()), f"tokens step {t} inst {i}"
+            exp_pos, _ = orc.env_step(grid, p[i], g[i], actions[i])
+            assert np.array_equal(newpos[i], exp_pos), f"env step {t} inst {i}"
+            p[i] = exp_pos
+        assert actions.min() >= 0 and actions.max() <= 4
+        last = actions.copy()
+    m = run.metrics().cpu().numpy()
+    assert (m[:, 4] == 10).all()

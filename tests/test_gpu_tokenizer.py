@@ -1,0 +1,144 @@
+"""Parity proper: HIP tokenizer / BFS vs the reference's golden vectors and vs the C oracle, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mapf_gpt_amd import maps
+from oracle import oracle as orc
+from tests.helpers import GOLDEN, load_tok, sha_rows, tok_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def replay_gpu(case, n_inst=1, check_dist=False):
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    grid, P, G, A = case["grid"], case["pos"], case["goal"], case["actions"]
+    S, n = P.shape[0], P.shape[1]
+    tok = BatchedTokenizer(grid, n_inst, n)
+    out = []
+    for t in range(S):
+        pos = _dev(np.broadcast_to(P[t], (n_inst, n, 2)), torch.int16)
+        goal = _dev(np.broadcast_to(G[t], (n_inst, n, 2)), torch.int16)
+        act = _dev(np.broadcast_to(A[t].astype(np.int32), (n_inst, n)), torch.int32)
+        if t == 0:
+            tok.create_agents(pos, goal)
+            if check_dist:
+                d = tok.distance_fields()
+                for a in range(0, n, max(1, n // 8)):
+                    assert np.array_equal(d[0, a], orc.bfs(grid, G[0][a])), f"BFS field of agent {a} differs"
+        tok.update_agents(pos, goal, act, goals_may_change=True)
+        out.append(tok.generate_observations().cpu().numpy().reshape(n_inst, n, 256))
+    return np.array(out)       # [S, n_inst, n, 256]
+
+
+def test_known_answer_cpp_main():
+    """observation_generator.cpp:530-544 on the device (unpadded 256x256 grid: BFS runs in global-memory mode)."""
+    from mapf_gpt_amd.observation_generator import InputParameters, ObservationGenerator
+    g = np.load(os.path.join(GOLDEN, "tok_known_answer.npz"))
+    gen = ObservationGenerator([[0] * 256 for _ in range(256)], InputParameters(20, 13, 5, 256, 5, 5, 64, False))
+    gen.create_agents([(120, 120)], [(20, 200)])
+    gen.update_agents([(120, 120)], [(20, 200)], [0])
+    row = np.array(gen.generate_observations(), dtype=np.uint8)
+    assert np.array_equal(row, g["tokens"])
+    assert sha_rows(row[0]) == "896eb85aa89a369759917e5903f237dc28387e6b7d431fbd6703f302a97585e1"
+
+
+@pytest.mark.parametrize("name", tok_cases())
+def test_golden_trajectories_bit_exact(name):
+    case = load_tok(name)
+    got = replay_gpu(case, n_inst=1, check_dist=True)[:, 0]
+    assert sha_rows(got) == str(case["sha256_all_rows"])
+    assert np.array_equal(got[:, case["keep"]], case["tokens"])
+
+
+def test_batched_instances_share_one_map():
+    """Several instances on one shared map: every instance slot must reproduce the golden rows."""
+    case = load_tok("mazes000")
+    got = replay_gpu(case, n_inst=5)
+    for i in range(5):
+        assert np.array_equal(got[:, i], case["tokens"]), f"instance slot {i}"
+
+
+@pytest.mark.parametrize("n_inst,n_agents,h,w", [(7, 24, 20, 21), (3, 130, 40, 44), (2, 1, 8, 8), (4, 70, 90, 30)])
+def test_many_maps_vs_oracle(n_inst, n_agents, h, w):
+    """Distinct map per instance (n_grids == n_inst), ragged agent counts (1, 70, 130: not multiples of 16/64),
+    goal changes mid-way; checker = C oracle."""
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    rng = np.random.Generator(np.random.PCG64(n_inst * 1000 + n_agents))
+    grids = np.stack([maps.pad(maps.random_map(h, w, 0.12 + 0.03 * i, 50 + i)) for i in range(n_inst)])
+    pg = [maps.place_agents(grids[i], n_agents, i) for i in range(n_inst)]
+    pos = np.stack([p for p, _ in pg]).astype(np.int32)
+    goal = np.stack([g for _, g in pg]).astype(np.int32)
+    gens = [orc.OracleGenerator(grids[i]) for i in range(n_inst)]
+    tok = BatchedTokenizer(grids, n_inst, n_agents)
+    last = np.full((n_inst, n_agents), -1, np.int32)
+    for t in range(8):
+        if t == 4:      # change a third of the goals
+            for i in range(n_inst):
+                free = np.argwhere(maps.largest_component(grids[i] == 0))
+                who = rng.permutation(n_agents)[: max(1, n_agents // 3)]
+                goal[i, who] = free[rng.permutation(len(free))[: len(who)]]
+        dp, dg, da = _dev(pos, torch.int16), _dev(goal, torch.int16), _dev(last, torch.int32)
+        if t == 0:
+            tok.create_agents(dp, dg)
+            for i in range(n_inst):
+                gens[i].create_agents(pos[i], goal[i])
+        tok.update_agents(dp, dg, da, goals_may_change=True)
+        got = tok.generate_observations().cpu().numpy().reshape(n_inst, n_agents, 256)
+        for i in range(n_inst):
+            gens[i].update_agents(pos[i], goal[i], last[i])
+            assert np.array_equal(got[i], gens[i].generate_observations()), f"step {t} instance {i}"
+        last = rng.integers(-1, 6, (n_inst, n_agents)).astype(np.int32)     # includes out-of-range ids -> "n"
+        for i in range(n_inst):
+            pos[i], _ = orc.env_step(grids[i], pos[i], goal[i], np.clip(last[i], 0, 4))
+
+
+def test_static_goal_fast_path_equals_checked_path():
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    case = load_tok("random000")
+    grid, P, G, A = case["grid"], case["pos"], case["goal"], case["actions"]
+    n = P.shape[1]
+    tok = BatchedTokenizer(grid, 1, n)
+    for t in range(6):
+        pos, goal, act = _dev(P[t][None], torch.int16), _dev(G[t][None], torch.int16), _dev(A[t][None].astype(np.int32), torch.int32)
+        if t == 0:
+            tok.create_agents(pos, goal)
+        tok.update_agents(pos, goal, act, goals_may_change=False)
+        assert np.array_equal(tok.generate_observations().cpu().numpy(), case["tokens"][t])
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE cfg 2 size (256 instances x 64 agents): size-independent properties -- every token < 67, window
+    centre token is 20 (distance to self = 0), slot 0 is the agent itself (rel pos 20,20), pads are 66,
+    instances with identical inputs give identical rows, a second call is idempotent."""
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    from mapf_gpt_amd.runner import make_instances
+    grid, s_ok, g_ok = maps.load_named("validation-mazes-seed-000")
+    n_inst, n = 256, 64
+    pos, goal = make_instances(grid, n_inst, n, 0, s_ok, g_ok)
+    pos[200:] = pos[:56]
+    goal[200:] = goal[:56]
+    tok = BatchedTokenizer(grid, n_inst, n)
+    dp, dg = pos.cuda(), goal.cuda()
+    tok.create_agents(dp, dg)
+    tok.update_agents(dp, dg, torch.full((n_inst, n), -1, dtype=torch.int32).cuda(), goals_may_change=False)
+    t1 = tok.generate_observations().cpu().numpy().reshape(n_inst, n, 256)
+    t2 = tok.generate_observations().cpu().numpy().reshape(n_inst, n, 256)
+    assert np.array_equal(t1, t2)
+    assert t1.max() <= 66
+    assert (t1[:, :, 60] == 20).all()
+    assert (t1[:, :, 121] == 20).all() and (t1[:, :, 122] == 20).all()
+    assert (t1[:, :, 125:130] == 44).all()                     # own history is "n" x5 on the first step
+    assert (t1[:, :, 251:] == 66).all()
+    assert np.array_equal(t1[200:], t1[:56])
+    o = orc.OracleGenerator(grid)                              # spot-check 3 instances against the oracle
+    for i in (0, 101, 255):
+        o.create_agents(pos[i].numpy(), goal[i].numpy())
+        o.update_agents(pos[i].numpy(), goal[i].numpy(), np.full(n, -1, np.int32))
+        assert np.array_equal(o.generate_observations(), t1[i])
