@@ -137,8 +137,10 @@ def test_full_size_properties_cfg2():
     assert (t1[:, :, 125:130] == 44).all()                     # own history is "n" x5 on the first step
     assert (t1[:, :, 251:] == 66).all()
     assert np.array_equal(t1[200:], t1[:56])
-    o = orc.OracleGenerator(grid)                              # spot-check 3 instances against the oracle
-    for i in (0, 101, 255):
+    for i in (0, 101, 255):                                    # spot-check 3 instances against the oracle
+        # a fresh generator per instance: like the reference's (cpp:391-410), create_agents leaves the previous
+        # agents' occupancy marks behind, so a generator is never re-used across agent sets (inference.py:133-139)
+        o = orc.OracleGenerator(grid)
         o.create_agents(pos[i].numpy(), goal[i].numpy())
         o.update_agents(pos[i].numpy(), goal[i].numpy(), np.full(n, -1, np.int32))
         assert np.array_equal(o.generate_observations(), t1[i])
