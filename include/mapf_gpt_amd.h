@@ -167,6 +167,11 @@ int mgpt_gpt_act(mgpt_gpt *gpt, const uint8_t *d_tokens, int rows, int32_t *d_ac
  * [3][rows][n_head][256][hs], 3 = MLP hidden [rows*256, 4C]; n_elem floats from the start. */
 int mgpt_gpt_debug_copy(mgpt_gpt *gpt, int which, float *d_out, int64_t n_elem, void *stream);
 
+/* test/debug: raw bytes of a 16-bit-path workspace buffer (valid after a forward in `precision`):
+ * which 0 = LayerNorm stats float2[rows*256]; 1/2 = q|k planes hi/lo; 3/4 = v^T planes hi/lo;
+ * 5/6 = attention output planes hi/lo; 7/8 = MLP hidden planes hi/lo (lo only for MGPT_PREC_F16X3). */
+int mgpt_gpt_debug_copy_raw(mgpt_gpt *gpt, int precision, int which, void *d_out, int64_t nbytes, void *stream);
+
 /* sampling alone (same RNG as mgpt_gpt_act), for callers that already hold logits */
 int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_actions, int do_sample,
                         uint64_t seed, uint64_t step, void *stream);

@@ -106,6 +106,7 @@ extern "C" int mgpt_gpt_create(mgpt_gpt **out, int n_layer, int n_head, int n_em
 extern "C" int mgpt_gpt_destroy(mgpt_gpt *g)
 {
     if (!g) return MGPT_OK;
+    gpt_fast_destroy(g);
     (void)hipFree(g->params); (void)hipFree(g->x); (void)hipFree(g->xn); (void)hipFree(g->qkv);
     (void)hipFree(g->hbuf); (void)hipFree(g->logits_tmp);
     delete g;
@@ -153,15 +154,6 @@ extern "C" int mgpt_gpt_set_param(mgpt_gpt *g, const char *name, const float *da
     return MGPT_OK;
 }
 
-int gpt_fast_finalize(mgpt_gpt *g);   // gpt_fast.hip (packed operand planes); weak no-op until that path exists
-__attribute__((weak)) int gpt_fast_finalize(mgpt_gpt *) { return MGPT_OK; }
-int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, hipStream_t s);
-__attribute__((weak)) int gpt_fast_forward(mgpt_gpt *, const uint8_t *, int, float *, int precision, hipStream_t)
-{
-    set_error("precision %d is not built into this library", precision);
-    return MGPT_ERR_UNSUPPORTED;
-}
-
 extern "C" int mgpt_gpt_finalize(mgpt_gpt *g)
 {
     MGPT_REQUIRE(g, MGPT_ERR_ARG, "NULL argument");
@@ -170,6 +162,15 @@ extern "C" int mgpt_gpt_finalize(mgpt_gpt *g)
     int rc = gpt_fast_finalize(g);
     if (rc != MGPT_OK) return rc;
     g->finalized = true;
+    return MGPT_OK;
+}
+
+int gpt_launch_head(mgpt_gpt *g, int rows, float *d_logits, hipStream_t s)
+{
+    ProfScope ps(P_HEAD, s);
+    hipLaunchKernelGGL(f32k::head_kernel, dim3(rows), dim3(64), (size_t)g->C * sizeof(float), s, g->x, g->params + g->off_lnf,
+                       g->params + g->off_wte, d_logits, g->C, kV);
+    MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
 
@@ -253,13 +254,7 @@ static int forward_f32_chunk(mgpt_gpt *g, const uint8_t *d_tokens, int rows, flo
             if ((rc = launch_gemm<f32k::EPI_RESID>(g->hbuf, P + lo.proj2_w, g->x, M, C, 4 * C, ep, C, s)) != MGPT_OK) return rc;
         }
     }
-    {
-        ProfScope ps(P_HEAD, s);
-        hipLaunchKernelGGL(f32k::head_kernel, dim3(rows), dim3(64), (size_t)C * sizeof(float), s, g->x, P + g->off_lnf,
-                           P + g->off_wte, d_logits, C, kV);
-        MGPT_LAUNCH_CHECK();
-    }
-    return MGPT_OK;
+    return gpt_launch_head(g, rows, d_logits, s);
 }
 
 // debugging aid for the GPU parity tests: copy an fp32-path workspace buffer out after a forward
@@ -273,6 +268,12 @@ extern "C" int mgpt_gpt_debug_copy(mgpt_gpt *g, int which, float *d_out, int64_t
     MGPT_REQUIRE(src && n_elem <= cap, MGPT_ERR_ARG, "which=%d n_elem=%lld", which, (long long)n_elem);
     MGPT_HIP(hipMemcpyAsync(d_out, src, (size_t)n_elem * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MGPT_OK;
+}
+
+extern "C" int mgpt_gpt_debug_copy_raw(mgpt_gpt *g, int precision, int which, void *d_out, int64_t nbytes, void *stream)
+{
+    MGPT_REQUIRE(g && d_out && nbytes > 0, MGPT_ERR_ARG, "bad argument");
+    return gpt_fast_debug_copy(g, precision, which, d_out, nbytes, (hipStream_t)stream);
 }
 
 extern "C" int mgpt_gpt_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, void *stream)

@@ -23,3 +23,12 @@ struct mgpt_gpt {
     void *fast = nullptr;
 };
 
+
+// gpt_fast.hip: 16-bit-MFMA path (packed operand planes, own workspace)
+int gpt_fast_finalize(mgpt_gpt *g);
+void gpt_fast_destroy(mgpt_gpt *g);
+int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, hipStream_t s);
+int gpt_fast_debug_copy(mgpt_gpt *g, int precision, int which, void *d_out, int64_t nbytes, hipStream_t s);
+
+// gpt.hip: final LayerNorm + tied lm_head on the last position of g->x (shared by both paths)
+int gpt_launch_head(mgpt_gpt *g, int rows, float *d_logits, hipStream_t s);

@@ -1,0 +1,293 @@
+// gpt_fast.hip -- host side of the 16-bit-MFMA forward (MGPT_PREC_F16X3 / MGPT_PREC_BF16):
+// weight plane packing at finalize, workspace, and the per-chunk launch sequence
+//   embed+stats -> L x { LN1+QK gemm, LN1+V^T gemm, attention, proj+residual(+stats),
+//                        LN2+FC+GELU gemm, proj2+residual(+stats) } -> ln_f + head (fp32 kernel)
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "gpt_ctx.h"
+#include "gpt_kernels_fast.h"
+
+using namespace mgpt;
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kV = MGPT_VOCAB;
+
+struct PlaneSet {           // one weight matrix [N][K] as 16-bit planes
+    uint16_t *hi = nullptr, *lo = nullptr;
+    float inv_scale = 1.f;
+};
+
+struct ModeState {          // one precision mode
+    bool built = false;
+    int np = 0;             // planes per operand
+    std::vector<PlaneSet> attn, proj, fc, proj2;
+    // workspace (sized for max_rows)
+    float2 *stats = nullptr;
+    uint16_t *qk[2] = {nullptr, nullptr};      // [2 (q,k)][M][C] per plane
+    uint16_t *vt[2] = {nullptr, nullptr};      // [M][C]
+    uint16_t *y[2] = {nullptr, nullptr};       // [M][C]
+    uint16_t *hbuf[2] = {nullptr, nullptr};    // [M][4C]
+};
+
+struct FastState {
+    ModeState mode[3];      // indexed by MGPT_PREC_* (slot 0 unused)
+};
+
+template <class T, int NP>
+int pack_matrix(const float *d_w, size_t n_elem, float scale, PlaneSet *out, hipStream_t s)
+{
+    MGPT_HIP(hipMalloc(&out->hi, n_elem * sizeof(uint16_t)));
+    if (NP == 2) MGPT_HIP(hipMalloc(&out->lo, n_elem * sizeof(uint16_t)));
+    out->inv_scale = 1.0f / scale;
+    const int64_t n4 = (int64_t)(n_elem / 4);
+    ProfScope ps(P_PACK, s);
+    hipLaunchKernelGGL((fastk::pack_planes_kernel<T, NP>), dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, d_w, out->hi,
+                       out->lo, n4, scale);
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+float pick_scale(const float *h_w, size_t n, bool f16)
+{
+    if (!f16) return 1.0f;                       // bf16 has the fp32 exponent range
+    float mx = 0.f;
+    for (size_t i = 0; i < n; i++) mx = std::max(mx, fabsf(h_w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+    int e = (int)floorf(log2f(4096.0f / mx));    // largest |w| lands in [2048, 4096]: hi AND lo parts stay normal fp16
+    e = std::max(-8, std::min(e, 20));
+    return ldexpf(1.0f, e);
+}
+
+template <class T, int NP>
+int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
+{
+    const size_t C = g->C;
+    std::vector<float> host(g->n_params);
+    MGPT_HIP(hipMemcpy(host.data(), g->params, g->n_params * sizeof(float), hipMemcpyDeviceToHost));
+    m->np = NP;
+    m->attn.resize(g->L); m->proj.resize(g->L); m->fc.resize(g->L); m->proj2.resize(g->L);
+    int rc;
+    for (int l = 0; l < g->L; l++) {
+        const LayerOff &lo = g->layers[l];
+        struct { size_t off, n; PlaneSet *dst; } mats[4] = {{lo.attn_w, 3 * C * C, &m->attn[l]}, {lo.proj_w, C * C, &m->proj[l]},
+                                                           {lo.fc_w, 4 * C * C, &m->fc[l]}, {lo.proj2_w, 4 * C * C, &m->proj2[l]}};
+        for (auto &mt : mats) {
+            const float sc = pick_scale(host.data() + mt.off, mt.n, f16);
+            if ((rc = pack_matrix<T, NP>(g->params + mt.off, mt.n, sc, mt.dst, nullptr)) != MGPT_OK) return rc;
+        }
+    }
+    const size_t M = (size_t)g->max_rows * kT;
+    MGPT_HIP(hipMalloc(&m->stats, M * sizeof(float2)));
+    for (int p = 0; p < NP; p++) {
+        MGPT_HIP(hipMalloc(&m->qk[p], 2 * M * C * sizeof(uint16_t)));
+        MGPT_HIP(hipMalloc(&m->vt[p], M * C * sizeof(uint16_t)));
+        MGPT_HIP(hipMalloc(&m->y[p], M * C * sizeof(uint16_t)));
+        MGPT_HIP(hipMalloc(&m->hbuf[p], 4 * M * C * sizeof(uint16_t)));
+    }
+    MGPT_HIP(hipDeviceSynchronize());
+    m->built = true;
+    return MGPT_OK;
+}
+
+void free_mode(ModeState *m)
+{
+    auto fr = [](std::vector<PlaneSet> &v) { for (auto &p : v) { (void)hipFree(p.hi); (void)hipFree(p.lo); } v.clear(); };
+    fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
+    (void)hipFree(m->stats);
+    for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
+    *m = ModeState();
+}
+
+template <class T, int NP, int PRO, int EPI>
+int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
+{
+    MGPT_REQUIRE(a.M % 128 == 0 && a.K % 32 == 0, MGPT_ERR_UNSUPPORTED, "gemm16 shape M=%d K=%d", a.M, a.K);
+    const int mt = a.M / 128;
+    if (C == 160 && a.N % 160 == 0) {
+        a.n_tiles_n = a.N / 160;
+        hipLaunchKernelGGL((fastk::gemm16_kernel<T, NP, 160, 4, 1, PRO, EPI>), dim3(mt * a.n_tiles_n), dim3(256), 0, s, a);
+    } else if (C == 64 && a.N % 64 == 0) {
+        a.n_tiles_n = a.N / 64;
+        hipLaunchKernelGGL((fastk::gemm16_kernel<T, NP, 64, 4, 1, PRO, EPI>), dim3(mt * a.n_tiles_n), dim3(256), 0, s, a);
+    } else if (a.N % 128 == 0) {
+        a.n_tiles_n = a.N / 128;
+        if (EPI == fastk::EPI_RESID) a.stats_out = nullptr;          // rows span two waves: stats come from row_stats_kernel
+        hipLaunchKernelGGL((fastk::gemm16_kernel<T, NP, 128, 2, 2, PRO, EPI>), dim3(mt * a.n_tiles_n), dim3(256), 0, s, a);
+    } else {
+        set_error("gemm16: N=%d unsupported for C=%d", a.N, C);
+        return MGPT_ERR_UNSUPPORTED;
+    }
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+bool fused_stats(int C) { return C == 160 || C == 64; }
+
+int launch_row_stats(const float *x, float2 *stats, int64_t n_tok, int C, hipStream_t s)
+{
+    ProfScope ps(P_LAYERNORM, s);
+    const dim3 grid((unsigned)cdiv64(n_tok, 4));
+    if (C <= 256) hipLaunchKernelGGL((fastk::row_stats_kernel<1>), grid, dim3(256), 0, s, x, stats, n_tok, C);
+    else if (C <= 512) hipLaunchKernelGGL((fastk::row_stats_kernel<2>), grid, dim3(256), 0, s, x, stats, n_tok, C);
+    else if (C <= 768) hipLaunchKernelGGL((fastk::row_stats_kernel<3>), grid, dim3(256), 0, s, x, stats, n_tok, C);
+    else hipLaunchKernelGGL((fastk::row_stats_kernel<4>), grid, dim3(256), 0, s, x, stats, n_tok, C);
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+template <class T, int NP>
+int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, float *d_logits, hipStream_t s)
+{
+    const int C = g->C;
+    const int64_t M = (int64_t)rows * kT;
+    const float *P = g->params;
+    int rc;
+    {
+        ProfScope ps(P_EMBED, s);
+        const dim3 grid((unsigned)cdiv64(M, 4));
+        if (C <= 256) hipLaunchKernelGGL((fastk::embed_stats_kernel<1>), grid, dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, m->stats, M, C);
+        else if (C <= 512) hipLaunchKernelGGL((fastk::embed_stats_kernel<2>), grid, dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, m->stats, M, C);
+        else if (C <= 768) hipLaunchKernelGGL((fastk::embed_stats_kernel<3>), grid, dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, m->stats, M, C);
+        else hipLaunchKernelGGL((fastk::embed_stats_kernel<4>), grid, dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, m->stats, M, C);
+        MGPT_LAUNCH_CHECK();
+    }
+    const float scale_log2e = (1.0f / sqrtf((float)g->hs)) * 1.44269504088896340736f;
+    const size_t attn_lds = (size_t)NP * (kT * (g->hs + 8) * 2 + g->hs * (kT + 8) * 2);
+    for (int l = 0; l < g->L; l++) {
+        const LayerOff &lo = g->layers[l];
+        fastk::GemmArgs a = {};
+        a.M = (int)M; a.C = C; a.n_head = g->nh; a.hs = g->hs; a.plane = M * C;
+        // ---- LN1 + QK projection -> q|k planes ----
+        a.x = g->x; a.stats = m->stats; a.gain = P + lo.ln1; a.K = C;
+        a.w_hi = m->attn[l].hi; a.w_lo = m->attn[l].lo; a.out_scale = m->attn[l].inv_scale;
+        a.N = 2 * C; a.o_hi = m->qk[0]; a.o_lo = m->qk[1];
+        {
+            ProfScope ps(P_GEMM_QKV, s);
+            if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_QK>(a, C, s)) != MGPT_OK) return rc;
+            // ---- LN1 + V projection -> v^T planes ----
+            a.w_hi = m->attn[l].hi + (size_t)2 * C * C; a.w_lo = (NP == 2) ? m->attn[l].lo + (size_t)2 * C * C : nullptr;
+            a.N = C; a.o_hi = m->vt[0]; a.o_lo = m->vt[1];
+            if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_VT>(a, C, s)) != MGPT_OK) return rc;
+        }
+        {
+            ProfScope ps(P_ATTN, s);
+            const uint16_t *qh = m->qk[0], *ql = m->qk[1], *kh = m->qk[0] + M * C, *kl = (NP == 2) ? m->qk[1] + M * C : nullptr;
+            if (g->hs == 32)
+                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e);
+            else
+                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e);
+            MGPT_LAUNCH_CHECK();
+        }
+        // ---- attention output projection + residual (+ stats of the new rows) ----
+        a.a_hi = m->y[0]; a.a_lo = m->y[1]; a.K = C; a.N = C;
+        a.w_hi = m->proj[l].hi; a.w_lo = m->proj[l].lo; a.out_scale = m->proj[l].inv_scale;
+        a.x_out = g->x; a.stats_out = m->stats;
+        {
+            ProfScope ps(P_GEMM_PROJ, s);
+            if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
+        }
+        if (!fused_stats(C) && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
+        // ---- LN2 + FC + GELU -> hidden planes ----
+        a.x = g->x; a.stats = m->stats; a.gain = P + lo.ln2; a.K = C; a.N = 4 * C;
+        a.w_hi = m->fc[l].hi; a.w_lo = m->fc[l].lo; a.out_scale = m->fc[l].inv_scale;
+        a.o_hi = m->hbuf[0]; a.o_lo = m->hbuf[1];
+        {
+            ProfScope ps(P_GEMM_FC, s);
+            if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_GELU>(a, C, s)) != MGPT_OK) return rc;
+        }
+        // ---- MLP output projection + residual (+ stats) ----
+        a.a_hi = m->hbuf[0]; a.a_lo = m->hbuf[1]; a.K = 4 * C; a.N = C;
+        a.w_hi = m->proj2[l].hi; a.w_lo = m->proj2[l].lo; a.out_scale = m->proj2[l].inv_scale;
+        a.x_out = g->x; a.stats_out = m->stats;
+        {
+            ProfScope ps(P_GEMM_PROJ2, s);
+            if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
+        }
+        if (!fused_stats(C) && l + 1 < g->L && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
+    }
+    return gpt_launch_head(g, rows, d_logits, s);
+}
+
+template <class T, int NP, int HS>
+int raise_attn_lds(size_t bytes)
+{
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn16_kernel<T, NP, HS>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MGPT_OK;
+}
+
+}  // namespace
+
+// ---- entry points used by gpt.hip ----
+int gpt_fast_finalize(mgpt_gpt *g)
+{
+    FastState *f = static_cast<FastState *>(g->fast);
+    if (f) {                                             // parameters changed: planes are rebuilt lazily
+        for (auto &m : f->mode) free_mode(&m);
+    } else {
+        g->fast = new FastState();
+    }
+    return MGPT_OK;
+}
+
+void gpt_fast_destroy(mgpt_gpt *g)
+{
+    FastState *f = static_cast<FastState *>(g->fast);
+    if (!f) return;
+    for (auto &m : f->mode) free_mode(&m);
+    delete f;
+    g->fast = nullptr;
+}
+
+int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, hipStream_t s)
+{
+    MGPT_REQUIRE(precision == MGPT_PREC_F16X3 || precision == MGPT_PREC_BF16, MGPT_ERR_ARG, "unknown precision %d", precision);
+    FastState *f = static_cast<FastState *>(g->fast);
+    MGPT_REQUIRE(f, MGPT_ERR_STATE, "mgpt_gpt_finalize must precede forward");
+    ModeState *m = &f->mode[precision];
+    const size_t attn_lds = (size_t)(precision == MGPT_PREC_F16X3 ? 2 : 1) * (kT * (g->hs + 8) * 2 + g->hs * (kT + 8) * 2);
+    if (!m->built) {                                     // first use of this precision: pack planes, size workspace
+        int rc;
+        if (precision == MGPT_PREC_F16X3) {
+            rc = build_mode<fastk::F16T, 2>(g, m, true);
+            if (rc == MGPT_OK) rc = (g->hs == 32) ? raise_attn_lds<fastk::F16T, 2, 32>(attn_lds) : raise_attn_lds<fastk::F16T, 2, 64>(attn_lds);
+        } else {
+            rc = build_mode<fastk::BF16T, 1>(g, m, false);
+            if (rc == MGPT_OK) rc = (g->hs == 32) ? raise_attn_lds<fastk::BF16T, 1, 32>(attn_lds) : raise_attn_lds<fastk::BF16T, 1, 64>(attn_lds);
+        }
+        if (rc != MGPT_OK) return rc;
+    }
+    if (precision == MGPT_PREC_F16X3) return forward_chunk<fastk::F16T, 2>(g, m, d_tokens, rows, d_logits, s);
+    return forward_chunk<fastk::BF16T, 1>(g, m, d_tokens, rows, d_logits, s);
+}
+
+// test/debug: raw copy of a fast-path workspace buffer of the given precision
+//   which: 0 stats(float2[M]) 1 qk hi 2 qk lo 3 vT hi 4 vT lo 5 y hi 6 y lo 7 hidden hi 8 hidden lo
+int gpt_fast_debug_copy(mgpt_gpt *g, int precision, int which, void *d_out, int64_t nbytes, hipStream_t s)
+{
+    FastState *f = static_cast<FastState *>(g->fast);
+    MGPT_REQUIRE(f && precision >= 1 && precision <= 2 && f->mode[precision].built, MGPT_ERR_STATE, "precision %d not built", precision);
+    ModeState *m = &f->mode[precision];
+    const void *src = nullptr;
+    switch (which) {
+        case 0: src = m->stats; break;
+        case 1: src = m->qk[0]; break;
+        case 2: src = m->qk[1]; break;
+        case 3: src = m->vt[0]; break;
+        case 4: src = m->vt[1]; break;
+        case 5: src = m->y[0]; break;
+        case 6: src = m->y[1]; break;
+        case 7: src = m->hbuf[0]; break;
+        case 8: src = m->hbuf[1]; break;
+        default: break;
+    }
+    MGPT_REQUIRE(src, MGPT_ERR_ARG, "which=%d has no buffer in this mode", which);
+    MGPT_HIP(hipMemcpyAsync(d_out, src, (size_t)nbytes, hipMemcpyDeviceToDevice, s));
+    return MGPT_OK;
+}

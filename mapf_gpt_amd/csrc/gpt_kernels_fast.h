@@ -1,0 +1,551 @@
+// gpt_kernels_fast.h -- 16-bit-MFMA policy forward kernels (MGPT_PREC_F16X3 and MGPT_PREC_BF16), gfx950.
+//
+// Split precision (F16X3): every fp32 operand v is carried as two fp16 planes, hi = fp16(v) and
+// lo = fp16(v - hi) (22 significand bits together); a product is the 3-term expansion
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi            (dropped a_lo*b_lo ~ 2^-22 |ab|)
+// issued as three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator.  fp16 subnormal inputs are
+// honoured by the matrix core on gfx950 (probed: tools/probe_mfma.hip, profiles/r01_probe_mfma.txt), and
+// weights are pre-scaled by a power of two so their lo parts stay normal.  That buys ~fp32 accuracy
+// (logit error ~1e-6, tested against the reference goldens at 1e-5) at 1/3 of the 2.5 PFLOP/s fp16 rate
+// instead of the 157 TFLOP/s fp32-MFMA rate.  BF16 mode = one plane, one pass (the reference's autocast mode).
+//
+// MFMA conventions (wave64, 32x32x16): lane l = (r = l & 31, h = l >> 5) supplies 8 consecutive
+// 16-bit k-slots of row r for BOTH operands; C/D: lane (r, h), register g holds
+// D[(g & 3) + 8 * (g >> 2) + 4 * h][r].  Which matrix is passed as the first operand decides whether
+// tokens run along registers ("natural") or along lanes ("swapped"); every epilogue picks the
+// orientation that makes its stores 8 or 16 bytes wide.
+#pragma once
+#include "common.h"
+
+namespace mgpt {
+namespace fastk {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kT = 256;
+
+struct F16T {
+    static __device__ __forceinline__ uint16_t cvt(float v) { _Float16 x = (_Float16)v; return __builtin_bit_cast(uint16_t, x); }
+    static __device__ __forceinline__ float back(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    }
+};
+struct BF16T {
+    static __device__ __forceinline__ uint16_t cvt(float v)
+    {   // round-to-nearest-even
+        unsigned u = __builtin_bit_cast(unsigned, v);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    }
+    static __device__ __forceinline__ float back(uint16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+    }
+};
+
+// hi/lo split of 4 consecutive values -> two 8-byte packets
+template <class T, int NP>
+__device__ __forceinline__ void split4(const float v[4], u32x2 &hi, u32x2 &lo)
+{
+    uint16_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        // The value must exist as ONE rounded fp32 before it is split.  Without this fence hipcc contracts the
+        // caller's last multiply into the conversions (v_fma_mixlo_f16: fp16(a*b) from the unrounded product) for
+        // the residual but not for the stored hi part; when fp32(a*b) sits exactly on an fp16 tie (1 in 2^13
+        // values) the two roundings pick different neighbours and hi+lo is off by a whole fp16 ulp.
+        float x = v[i];
+        asm volatile("" : "+v"(x));
+        a[i] = T::cvt(x);
+        b[i] = (NP == 2) ? T::cvt(x - T::back(a[i])) : (uint16_t)0;
+    }
+    hi[0] = (unsigned)a[0] | ((unsigned)a[1] << 16); hi[1] = (unsigned)a[2] | ((unsigned)a[3] << 16);
+    lo[0] = (unsigned)b[0] | ((unsigned)b[1] << 16); lo[1] = (unsigned)b[2] | ((unsigned)b[3] << 16);
+}
+
+// acc += A*B with NP-plane operands (NP == 2: 3-term split product, NP == 1: single pass)
+template <class T, int NP>
+__device__ __forceinline__ f32x16 mma(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16 c)
+{
+    if (NP == 2) {
+        c = T::mfma(a[1], b[0], c);     // small terms first, then the leading one
+        c = T::mfma(a[0], b[1], c);
+    }
+    return T::mfma(a[0], b[0], c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: fp32 W[N][K] -> NP planes of 16-bit [N][K] (K contiguous), multiplied by `scale`
+// ---------------------------------------------------------------------------------------------
+template <class T, int NP>
+__global__ __launch_bounds__(256) void pack_planes_kernel(const float *__restrict__ w, uint16_t *__restrict__ hi,
+                                                          uint16_t *__restrict__ lo, int64_t n4, float scale)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = reinterpret_cast<const f32x4 *>(w)[i];
+    const float s[4] = {v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale};
+    u32x2 a, b;
+    split4<T, NP>(s, a, b);
+    reinterpret_cast<u32x2 *>(hi)[i] = a;
+    if (NP == 2) reinterpret_cast<u32x2 *>(lo)[i] = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding + LayerNorm statistics of the fresh residual rows: x = wte[idx] + wpe[pos] (model.py:171-175),
+// stats[tok] = (mean, rstd) over C with eps 1e-5 (model.py:20).  One wavefront per token.
+// ---------------------------------------------------------------------------------------------
+template <int kMaxV4>
+__global__ __launch_bounds__(256) void embed_stats_kernel(const uint8_t *__restrict__ tokens, const float *__restrict__ wte,
+                                                          const float *__restrict__ wpe, float *__restrict__ x,
+                                                          float2 *__restrict__ stats, int64_t n_tok, int C)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    const int c4n = C >> 2, t = (int)(tok & (kT - 1)), id = tokens[tok];
+    const f32x4 *pa = reinterpret_cast<const f32x4 *>(wte + (size_t)id * C);
+    const f32x4 *pb = reinterpret_cast<const f32x4 *>(wpe + (size_t)t * C);
+    f32x4 *px = reinterpret_cast<f32x4 *>(x + tok * C);
+    f32x4 v[kMaxV4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxV4; k++) {
+        const int i = lane + 64 * k;
+        if (i < c4n) {
+            v[k] = pa[i] + pb[i];
+            px[i] = v[k];
+            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxV4; k++) {
+        const int i = lane + 64 * k;
+        if (i < c4n) {
+            const f32x4 d = v[k] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) stats[tok] = make_float2(mean, rsqrtf(q / (float)C + 1e-5f));
+}
+
+// stats only (used where the producing GEMM cannot see whole rows)
+template <int kMaxV4>
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, float2 *__restrict__ stats,
+                                                        int64_t n_tok, int C)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    const int c4n = C >> 2;
+    const f32x4 *px = reinterpret_cast<const f32x4 *>(x + tok * C);
+    f32x4 v[kMaxV4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxV4; k++) {
+        const int i = lane + 64 * k;
+        if (i < c4n) { v[k] = px[i]; s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxV4; k++) {
+        const int i = lane + 64 * k;
+        if (i < c4n) { const f32x4 d = v[k] - mean; q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) stats[tok] = make_float2(mean, rsqrtf(q / (float)C + 1e-5f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM: D[M,N] = A[M,K] @ W[N,K]^T on 16-bit MFMA planes, 128 x BN output tile per workgroup,
+// K walked in tiles of 32 staged through LDS (register prefetch of the next tile during the MFMAs).
+//   PRO_LN     : A = LayerNorm(x) built on the fly from fp32 x, per-row (mean, rstd) and the gain vector
+//   PRO_PLANES : A given as NP 16-bit planes
+//   EPI_*      : see below; all but EPI_VT run "swapped" (tokens along lanes) so each lane owns 4
+//                consecutive output columns per register quad
+// ---------------------------------------------------------------------------------------------
+enum { PRO_LN = 0, PRO_PLANES = 1 };
+enum { EPI_QK = 0, EPI_VT = 1, EPI_RESID = 2, EPI_GELU = 3 };
+
+struct GemmArgs {
+    // A
+    const float *x; const float2 *stats; const float *gain;         // PRO_LN
+    const uint16_t *a_hi, *a_lo;                                    // PRO_PLANES, [M][K]
+    // W planes [N][K] (pre-scaled), result multiplier = 1/scale
+    const uint16_t *w_hi, *w_lo;
+    float out_scale;
+    int M, N, K, n_tiles_n, n_base;                                  // n_base: first output column of this launch
+    // outputs
+    float *x_out; float2 *stats_out;                                 // EPI_RESID: x_out[m][n] += d ; optional new row stats
+    uint16_t *o_hi, *o_lo;                                           // EPI_QK: q|k planes, EPI_VT: v^T planes, EPI_GELU: h planes
+    int C, n_head, hs;
+    int64_t plane;                                                   // EPI_QK: elements between the q and the k plane (= M*C)
+};
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <class T, int NP, int BN, int WM, int WN, int PRO, int EPI>
+__global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p)
+{
+    constexpr int BM = 128, BK = 32;
+    constexpr int RS = (BK + 8) * 2;                       // LDS row stride in bytes (80): conflict-free ds_read_b128
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr bool SWAP = (EPI != EPI_VT);
+    static_assert(WM * WN == 4 && TM * WM * 32 == BM && TN * WN * 32 == BN, "tile config");
+    static_assert(EPI != EPI_RESID || true, "");
+    __shared__ __attribute__((aligned(16))) unsigned char sA[NP][BM * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[NP][BN * RS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int mt = blockIdx.x / p.n_tiles_n, nt = blockIdx.x - mt * p.n_tiles_n;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;                                // row offset into the W planes of this launch
+    const int K = p.K;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
+
+    // ---- staging registers ----
+    constexpr int A_LN_V = 4;                              // PRO_LN: 4 float4 per thread (128 rows x 8 float4)
+    constexpr int A_PL_TOT = NP * BM * 4;                  // PRO_PLANES: 16-byte chunks per tile
+    constexpr int A_PL_V = (A_PL_TOT + 255) / 256;
+    constexpr int B_TOT = NP * BN * 4;
+    constexpr int B_V = (B_TOT + 255) / 256;
+    f32x4 ra_f[PRO == PRO_LN ? A_LN_V : 1];
+    u32x4 ra_p[PRO == PRO_PLANES ? A_PL_V : 1];
+    u32x4 rb[B_V];
+    float my_mean[4], my_rstd[4];
+    if (PRO == PRO_LN) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float2 st = p.stats[m0 + (tid >> 3) + 32 * i];
+            my_mean[i] = st.x; my_rstd[i] = st.y;
+        }
+    }
+
+#define MGPT_G16_LOAD(kt_)                                                                                          \
+    {                                                                                                               \
+        const int k0_ = (kt_) * BK;                                                                                 \
+        if (PRO == PRO_LN) {                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < A_LN_V; i++)                                                      \
+                ra_f[i] = *reinterpret_cast<const f32x4 *>(p.x + (m0 + (tid >> 3) + 32 * i) * K + k0_ + (tid & 7) * 4); \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < A_PL_V; i++) {                                                    \
+                const int idx = tid + 256 * i;                                                                      \
+                if (A_PL_TOT % 256 == 0 || idx < A_PL_TOT) {                                                        \
+                    const int pl = idx / (BM * 4), rem = idx - pl * (BM * 4), row = rem >> 2, c = rem & 3;          \
+                    const uint16_t *src = (pl == 0 ? p.a_hi : p.a_lo) + (m0 + row) * K + k0_ + c * 8;               \
+                    ra_p[i] = *reinterpret_cast<const u32x4 *>(src);                                                \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < B_V; i++) {                                                           \
+            const int idx = tid + 256 * i;                                                                          \
+            if (B_TOT % 256 == 0 || idx < B_TOT) {                                                                  \
+                const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4), row = rem >> 2, c = rem & 3;              \
+                const uint16_t *src = (pl == 0 ? p.w_hi : p.w_lo) + (size_t)(n0 + row) * K + k0_ + c * 8;           \
+                rb[i] = *reinterpret_cast<const u32x4 *>(src);                                                      \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+
+    const int nk = K / BK;
+    MGPT_G16_LOAD(0);
+    for (int kt = 0; kt < nk; kt++) {
+        __syncthreads();                                   // previous tile fully consumed
+        if (PRO == PRO_LN) {
+            const f32x4 gn = *reinterpret_cast<const f32x4 *>(p.gain + kt * BK + (tid & 7) * 4);
+#pragma unroll
+            for (int i = 0; i < A_LN_V; i++) {
+                const int row = (tid >> 3) + 32 * i;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = (ra_f[i][e] - my_mean[i]) * my_rstd[i] * gn[e];
+                u32x2 hi, lo;
+                split4<T, NP>(v, hi, lo);
+                *reinterpret_cast<u32x2 *>(&sA[0][row * RS + (tid & 7) * 8]) = hi;
+                if (NP == 2) *reinterpret_cast<u32x2 *>(&sA[NP - 1][row * RS + (tid & 7) * 8]) = lo;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PL_V; i++) {
+                const int idx = tid + 256 * i;
+                if (A_PL_TOT % 256 == 0 || idx < A_PL_TOT) {
+                    const int pl = idx / (BM * 4), rem = idx - pl * (BM * 4), row = rem >> 2, c = rem & 3;
+                    *reinterpret_cast<u32x4 *>(&sA[pl][row * RS + c * 16]) = ra_p[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_V; i++) {
+            const int idx = tid + 256 * i;
+            if (B_TOT % 256 == 0 || idx < B_TOT) {
+                const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4), row = rem >> 2, c = rem & 3;
+                *reinterpret_cast<u32x4 *>(&sB[pl][row * RS + c * 16]) = rb[i];
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) MGPT_G16_LOAD(kt + 1);            // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) {
+            u32x4 a[TM][2], b[TN][2];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    a[i][pl] = *reinterpret_cast<const u32x4 *>(&sA[pl][((wm * TM + i) * 32 + r) * RS + ks * 32 + h * 16]);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    b[j][pl] = *reinterpret_cast<const u32x4 *>(&sB[pl][((wn * TN + j) * 32 + r) * RS + ks * 32 + h * 16]);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = SWAP ? mma<T, NP>(b[j], a[i], acc[i][j]) : mma<T, NP>(a[i], b[j], acc[i][j]);
+        }
+    }
+#undef MGPT_G16_LOAD
+
+    const float os = p.out_scale;
+    if (EPI == EPI_VT) {
+        // natural: lane = output column n (-> head, d), registers = tokens; 4 consecutive tokens per register quad
+        // v^T planes [rows][n_head][hs][256]
+        const int64_t b = m0 >> 8;
+        const int tb = (int)(m0 & (kT - 1));
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + (wn * TN + j) * 32 + r;                         // column inside V (n_base handled by the W pointer)
+            const int head = n / p.hs, d = n - head * p.hs;
+            const int64_t rowbase = ((b * p.n_head + head) * p.hs + d) * kT;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int t = tb + (wm * TM + i) * 32 + 8 * gq + 4 * h;
+                    const float v[4] = {acc[i][j][4 * gq] * os, acc[i][j][4 * gq + 1] * os, acc[i][j][4 * gq + 2] * os,
+                                        acc[i][j][4 * gq + 3] * os};
+                    u32x2 hi, lo;
+                    split4<T, NP>(v, hi, lo);
+                    *reinterpret_cast<u32x2 *>(p.o_hi + rowbase + t) = hi;
+                    if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + rowbase + t) = lo;
+                }
+        }
+    } else {
+        // swapped: lane = token m, registers = 4 consecutive output columns per quad
+        float rsum[TM];
+#pragma unroll
+        for (int i = 0; i < TM; i++) rsum[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int64_t m = m0 + (wm * TM + i) * 32 + r;
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int n = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h;   // first of 4 consecutive columns
+                    float v[4] = {acc[i][j][4 * gq] * os, acc[i][j][4 * gq + 1] * os, acc[i][j][4 * gq + 2] * os,
+                                  acc[i][j][4 * gq + 3] * os};
+                    if (EPI == EPI_RESID) {
+                        f32x4 *dst = reinterpret_cast<f32x4 *>(p.x_out + m * p.N + n);
+                        f32x4 cur = *dst;
+                        cur[0] += v[0]; cur[1] += v[1]; cur[2] += v[2]; cur[3] += v[3];
+                        *dst = cur;
+                        acc[i][j][4 * gq] = cur[0]; acc[i][j][4 * gq + 1] = cur[1];          // keep the new row for the stats
+                        acc[i][j][4 * gq + 2] = cur[2]; acc[i][j][4 * gq + 3] = cur[3];
+                        rsum[i] += (cur[0] + cur[1]) + (cur[2] + cur[3]);
+                    } else if (EPI == EPI_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+                        u32x2 hi, lo;
+                        split4<T, NP>(v, hi, lo);
+                        *reinterpret_cast<u32x2 *>(p.o_hi + m * p.N + n) = hi;
+                        if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + m * p.N + n) = lo;
+                    } else {   // EPI_QK: q|k planes [which][rows][n_head][256][hs]
+                        const int which = n / p.C, cc = n - which * p.C;
+                        const int head = cc / p.hs, d = cc - head * p.hs;
+                        const int64_t bb = m >> 8;
+                        const int t = (int)(m & (kT - 1));
+                        const int64_t off = (int64_t)which * p.plane + ((bb * p.n_head + head) * kT + t) * p.hs + d;
+                        u32x2 hi, lo;
+                        split4<T, NP>(v, hi, lo);
+                        *reinterpret_cast<u32x2 *>(p.o_hi + off) = hi;
+                        if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + off) = lo;
+                    }
+                }
+        }
+        if (EPI == EPI_RESID && WN == 1 && p.stats_out != nullptr) {
+            // this wave holds complete rows (BN == N): LayerNorm statistics of the NEW residual rows for the next kernel
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                float s = rsum[i] + __shfl_xor(rsum[i], 32);
+                const float mean = s / (float)p.N;
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int g = 0; g < 16; g++) { const float d = acc[i][j][g] - mean; q += d * d; }
+                q += __shfl_xor(q, 32);
+                if (h == 0) p.stats_out[m0 + (wm * TM + i) * 32 + r] = make_float2(mean, rsqrtf(q / (float)p.N + 1e-5f));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Non-causal attention on planes (model.py:58-60): one workgroup per (row, head); K and V^T planes
+// staged once in LDS, each wave owns 2 query tiles of 32.  S^T = K Q^T so a lane owns one query:
+// running (max, sum) softmax is in-lane (+1 exchange with lane^32), P converts in-lane into the
+// B-operand of O^T = V^T P^T.  Keys inside a 32-key tile are visited in the order `bits 2<->3 swapped`
+// so that the 8 keys a lane holds for one PV MFMA are contiguous in V^T (one 16-byte LDS read).
+//   q, k planes [rows][n_head][256][HS]; v^T planes [rows][n_head][HS][256]; y planes [rows*256][C]
+// ---------------------------------------------------------------------------------------------
+template <class T, int NP, int HS>
+__global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict__ q_hi, const uint16_t *__restrict__ q_lo,
+                                                     const uint16_t *__restrict__ k_hi, const uint16_t *__restrict__ k_lo,
+                                                     const uint16_t *__restrict__ vt_hi, const uint16_t *__restrict__ vt_lo,
+                                                     uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo, int n_head,
+                                                     float scale_log2e)
+{
+    constexpr int KRS = (HS + 8) * 2;           // K row stride in bytes  (80 for HS = 32)
+    constexpr int VRS = (kT + 8) * 2;           // V^T row stride in bytes (528)
+    constexpr int KS = HS / 16;                 // k-steps of the S product
+    constexpr int DT = HS / 32;                 // d tiles of the output
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sK = smem;                                   // [NP][256][KRS]
+    unsigned char *sV = smem + NP * kT * KRS;                   // [NP][HS][VRS]
+
+    const int bh = blockIdx.x;
+    const int b = bh / n_head, head = bh - b * n_head;
+    const int C = n_head * HS;
+    const size_t base = (size_t)bh * kT * HS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // stage K [256][HS] and V^T [HS][256] planes (16-byte chunks)
+    for (int idx = tid; idx < NP * kT * (HS / 8); idx += 256) {
+        const int pl = idx / (kT * (HS / 8)), rem = idx - pl * (kT * (HS / 8)), row = rem / (HS / 8), c = rem - row * (HS / 8);
+        const uint16_t *src = (pl == 0 ? k_hi : k_lo) + base + (size_t)row * HS + c * 8;
+        *reinterpret_cast<u32x4 *>(sK + (size_t)pl * kT * KRS + row * KRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
+    }
+    for (int idx = tid; idx < NP * HS * (kT / 8); idx += 256) {
+        const int pl = idx / (HS * (kT / 8)), rem = idx - pl * (HS * (kT / 8)), row = rem / (kT / 8), c = rem - row * (kT / 8);
+        const uint16_t *src = (pl == 0 ? vt_hi : vt_lo) + base + (size_t)row * kT + c * 8;
+        *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VRS + row * VRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
+    }
+    __syncthreads();
+
+    // the S^T tile row this lane feeds as A-operand is key `kperm` of the tile (bits 2 and 3 of r swapped)
+    const int kperm = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);
+
+    for (int qt = wave; qt < kT / 32; qt += 4) {
+        u32x4 qf[KS][2];                                         // B operand: Q[query r][16 ks + 8 h ..]
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++)
+                qf[ks][pl] = *reinterpret_cast<const u32x4 *>((pl == 0 ? q_hi : q_lo) + base + (size_t)(qt * 32 + r) * HS + ks * 16 + h * 8);
+        f32x16 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) o[dt][g] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+
+#pragma unroll 1
+        for (int kt = 0; kt < kT / 32; kt++) {
+            f32x16 s;
+#pragma unroll
+            for (int g = 0; g < 16; g++) s[g] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                u32x4 kf[2];
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    kf[pl] = *reinterpret_cast<const u32x4 *>(sK + (size_t)pl * kT * KRS + (kt * 32 + kperm) * KRS + ks * 32 + h * 16);
+                s = mma<T, NP>(kf, qf[ks], s);
+            }
+            // s[g] = S[query r][key kt*32 + 16*(g>>3) + 8*h + (g&7)]   (after the bit-swap permutation)
+            float mx = s[0];
+#pragma unroll
+            for (int g = 1; g < 16; g++) mx = fmaxf(mx, s[g]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            float psum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                s[g] = __builtin_amdgcn_exp2f((s[g] - m_new) * scale_log2e);
+                psum += s[g];
+            }
+            psum += __shfl_xor(psum, 32);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) o[dt][g] *= alpha;
+#pragma unroll
+            for (int mm = 0; mm < 2; mm++) {                      // two PV MFMAs of 16 keys each
+                const float pv0[4] = {s[8 * mm], s[8 * mm + 1], s[8 * mm + 2], s[8 * mm + 3]};
+                const float pv1[4] = {s[8 * mm + 4], s[8 * mm + 5], s[8 * mm + 6], s[8 * mm + 7]};
+                u32x2 h0, l0, h1, l1;
+                split4<T, NP>(pv0, h0, l0);
+                split4<T, NP>(pv1, h1, l1);
+                u32x4 pf[2];
+                pf[0][0] = h0[0]; pf[0][1] = h0[1]; pf[0][2] = h1[0]; pf[0][3] = h1[1];
+                pf[1][0] = l0[0]; pf[1][1] = l0[1]; pf[1][2] = l1[0]; pf[1][3] = l1[1];
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++) {
+                    u32x4 vf[2];                                  // A operand: V^T[d = dt*32 + r][keys kt*32 + 16 mm + 8 h ..]
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++)
+                        vf[pl] = *reinterpret_cast<const u32x4 *>(sV + (size_t)pl * HS * VRS + (dt * 32 + r) * VRS + (kt * 32 + 16 * mm + 8 * h) * 2);
+                    o[dt] = mma<T, NP>(vf, pf, o[dt]);
+                }
+            }
+        }
+        const float inv = 1.0f / l_run;
+        // o[dt][g] = O[query r][d = dt*32 + (g&3) + 8*(g>>2) + 4*h] -> y planes [b*256 + t][head*HS + d]  (model.py:68)
+        const size_t yrow = ((size_t)b * kT + qt * 32 + r) * C + head * HS;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const float v[4] = {o[dt][4 * gq] * inv, o[dt][4 * gq + 1] * inv, o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv};
+                u32x2 hi, lo;
+                split4<T, NP>(v, hi, lo);
+                *reinterpret_cast<u32x2 *>(y_hi + yrow + dt * 32 + 8 * gq + 4 * h) = hi;
+                if (NP == 2) *reinterpret_cast<u32x2 *>(y_lo + yrow + dt * 32 + 8 * gq + 4 * h) = lo;
+            }
+    }
+}
+
+}  // namespace fastk
+}  // namespace mgpt

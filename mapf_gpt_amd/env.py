@@ -41,7 +41,10 @@ class BatchedEnv:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib().mgpt_env_destroy(h)
+            try:
+                _lib.lib().mgpt_env_destroy(h)
+            except Exception:      # interpreter shutdown: module globals may already be gone
+                pass
             self._h = None
 
     def reset(self, pos, goal):

@@ -56,7 +56,10 @@ class GPT:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib().mgpt_gpt_destroy(h)
+            try:
+                _lib.lib().mgpt_gpt_destroy(h)
+            except Exception:      # interpreter shutdown: module globals may already be gone
+                pass
             self._h = None
 
     def to(self, device):

@@ -65,7 +65,10 @@ class BatchedTokenizer:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib().mgpt_tokenizer_destroy(h)
+            try:
+                _lib.lib().mgpt_tokenizer_destroy(h)
+            except Exception:      # interpreter shutdown: module globals may already be gone
+                pass
             self._h = None
 
     def _chk(self, t, dtype, shape):
