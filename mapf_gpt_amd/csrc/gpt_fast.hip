@@ -3,6 +3,7 @@
 //   embed+stats -> L x { LN1+QK gemm, LN1+V^T gemm, attention, proj+residual(+stats),
 //                        LN2+FC+GELU gemm, proj2+residual(+stats) } -> ln_f + head (fp32 kernel)
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
@@ -33,6 +34,9 @@ struct ModeState {          // one precision mode
     uint16_t *vt[2] = {nullptr, nullptr};      // [M][C]
     uint16_t *y[2] = {nullptr, nullptr};       // [M][C]
     uint16_t *hbuf[2] = {nullptr, nullptr};    // [M][4C]
+    // fused MLP (C = 64 / 160): per layer one packed stream [hidden tile][fragment][plane][lane][8]
+    std::vector<uint16_t *> mlp_pk;
+    bool mlp_fused = false;
 };
 
 struct FastState {
@@ -82,6 +86,24 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             if ((rc = pack_matrix<T, NP>(g->params + mt.off, mt.n, sc, mt.dst, nullptr)) != MGPT_OK) return rc;
         }
     }
+    m->mlp_fused = (C == 160 || C == 64) && getenv("MGPT_NO_FUSED_MLP") == nullptr;
+    if (m->mlp_fused) {
+        const size_t frags = C / 16 + 2 * (C / 32), nt = 4 * C / 32;
+        const size_t n16 = nt * frags * NP * 512;
+        m->mlp_pk.assign(g->L, nullptr);
+        for (int l = 0; l < g->L; l++) {
+            MGPT_HIP(hipMalloc(&m->mlp_pk[l], n16 * sizeof(uint16_t)));
+            const LayerOff &lo = g->layers[l];
+            ProfScope ps(P_PACK, nullptr);
+            hipLaunchKernelGGL((fastk::pack_mlp_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)(nt * frags * 64), 256)), dim3(256), 0,
+                               nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, m->mlp_pk[l], (int)C,
+                               1.0f / m->fc[l].inv_scale, 1.0f / m->proj2[l].inv_scale);
+            MGPT_LAUNCH_CHECK();
+        }
+        const int pkt = (int)(frags * NP * 1024 * 2);
+        if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
+        else MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
+    }
     const size_t M = (size_t)g->max_rows * kT;
     MGPT_HIP(hipMalloc(&m->stats, M * sizeof(float2)));
     for (int p = 0; p < NP; p++) {
@@ -99,6 +121,7 @@ void free_mode(ModeState *m)
 {
     auto fr = [](std::vector<PlaneSet> &v) { for (auto &p : v) { (void)hipFree(p.hi); (void)hipFree(p.lo); } v.clear(); };
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
+    for (auto *p : m->mlp_pk) (void)hipFree(p);
     (void)hipFree(m->stats);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
@@ -193,6 +216,19 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
         if (!fused_stats(C) && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
+        if (m->mlp_fused) {
+            // ---- whole MLP block in one kernel (hidden stays in registers) ----
+            ProfScope ps(P_MLP_FUSED, s);
+            const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 2;
+            if (C == 160)
+                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5>), dim3((unsigned)(M / 128)), dim3(256), lds, s, g->x, P + lo.ln2,
+                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)M);
+            else
+                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 2>), dim3((unsigned)(M / 128)), dim3(256), lds, s, g->x, P + lo.ln2,
+                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)M);
+            MGPT_LAUNCH_CHECK();
+            continue;
+        }
         // ---- LN2 + FC + GELU -> hidden planes ----
         a.x = g->x; a.stats = m->stats; a.gain = P + lo.ln2; a.K = C; a.N = 4 * C;
         a.w_hi = m->fc[l].hi; a.w_lo = m->fc[l].lo; a.out_scale = m->fc[l].inv_scale;
