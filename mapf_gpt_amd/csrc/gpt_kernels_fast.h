@@ -63,7 +63,7 @@ __device__ __forceinline__ void split4(const float v[4], u32x2 &hi, u32x2 &lo)
         // the residual but not for the stored hi part; when fp32(a*b) sits exactly on an fp16 tie (1 in 2^13
         // values) the two roundings pick different neighbours and hi+lo is off by a whole fp16 ulp.
         float x = v[i];
-        asm volatile("" : "+v"(x));
+        asm("" : "+v"(x));   // not volatile: must stay freely schedulable
         a[i] = T::cvt(x);
         b[i] = (NP == 2) ? T::cvt(x - T::back(a[i])) : (uint16_t)0;
     }
@@ -627,30 +627,38 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <class T, int NP, int CT>
-__global__ __launch_bounds__(256, 2) void mlp_fused_kernel(float *__restrict__ x, const float *__restrict__ gain,
+// ABL: timing ablations for tools/ (results are WRONG unless ABL == 0): 1 no GELU, 2 no weight streaming,
+//      3 no c_proj MFMAs, 4 no c_fc MFMAs
+template <class T, int NP, int CT, int ABL = 0, int NW = 8, int NBUF = 3>
+__global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                             const uint16_t *__restrict__ wpk, float inv1, float inv2,
                                                             float2 *__restrict__ stats_out, int M)
 {
     constexpr int C = CT * 32, KS = C / 16, NT = 4 * CT;
     constexpr int FRAGS = KS + 2 * CT;                     // fragments per hidden tile
     constexpr int PKT = FRAGS * NP * 1024;                 // bytes per hidden-tile packet
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][PKT]
+    constexpr int PER_WAVE = (FRAGS * NP + NW - 1) / NW;   // DMA instructions a wave issues per packet
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NBUF][PKT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t m = (int64_t)blockIdx.x * 128 + wave * 32 + r;           // this lane's token
+    const int64_t m = (int64_t)blockIdx.x * (NW * 32) + wave * 32 + r;     // this lane's token
     float *xrow = x + m * C;
 
     // ---- stream helper: packet t -> LDS buffer (t & 1); every wave moves FRAGS*NP/4 fragment-planes of 1 KiB ----
     auto issue = [&](int t) {
         const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)t * PKT;
-        unsigned char *dst = smem + (size_t)(t & 1) * PKT;
+        unsigned char *dst = smem + (size_t)(t % NBUF) * PKT;
 #pragma unroll
-        for (int c = wave; c < FRAGS * NP; c += 4)
+        for (int i = 0; i < PER_WAVE; i++) {
+            // every wave issues exactly PER_WAVE pieces so that the counted vmcnt waits below are exact; a wave whose
+            // share runs past the packet re-loads the last piece (same bytes to the same place: harmless)
+            const int c = min(wave + NW * i, FRAGS * NP - 1);
             __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)c * 1024 + lane * 16),
                                              (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
+        }
     };
     issue(0);
+    if (NBUF > 2) issue(1);
 
     // ---- load the 32 x C row block in swapped layout, LayerNorm in-lane ----
     f32x16 acc[CT];                                        // x now, output accumulator later
@@ -695,32 +703,62 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(float *__restrict__ x
 #pragma unroll
         for (int g = 0; g < 16; g++) acc[j][g] = 0.f;
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // packet 0 must have landed; with 3 buffers packet 1 (the newest PER_WAVE pieces of this wave) may still fly
+    if (NBUF > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
 #pragma unroll 1
     for (int t = 0; t < NT; t++) {
-        if (t + 1 < NT) issue(t + 1);                      // lands in the other buffer while this tile is computed
-        const unsigned char *pk = smem + (size_t)(t & 1) * PKT + lane * 16;
-        // ---- hidden tile: hacc[g] = c_fc output for (token r, hidden 32 t + (g&3) + 8 (g>>2) + 4 h) ----
-        f32x16 hacc;
+        // refill the buffer that was read during tile t-1 (all waves are past the barrier that ended it)
+        if (ABL != 2 && t + NBUF - 1 < NT) issue(t + NBUF - 1);
+        const unsigned char *pk = smem + (size_t)(ABL == 2 ? 0 : (t % NBUF)) * PKT + lane * 16;
+        // ---- hidden tile: c_fc output for (token r, hidden 32 t + (g&3) + 8 (g>>2) + 4 h) ----
+        // Two partial accumulators (even / odd k-steps) with their MFMA passes interleaved: a 32x32x16 MFMA
+        // that reads the previous one's result as C waits for its full latency (~2x the issue interval), so a
+        // single dependent chain runs the matrix pipe at half rate (measured: tools/abl_mlp.sh).
+        f32x16 hacc, hacc1;
 #pragma unroll
-        for (int g = 0; g < 16; g++) hacc[g] = 0.f;
+        for (int g = 0; g < 16; g++) { hacc[g] = 0.f; hacc1[g] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            u32x4 wf[2];
+        for (int ks = 0; ks < KS; ks += 2) {
+            u32x4 w0[2], w1[2];
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(ks * NP + pl) * 1024);
-            hacc = mma<T, NP>(wf, xn[ks], hacc);
+            for (int pl = 0; pl < NP; pl++) {
+                w0[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(ks * NP + pl) * 1024);
+                w1[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + 1) * NP + pl) * 1024);
+            }
+            if (ABL != 4) {
+                if (NP == 2) {
+                    hacc = T::mfma(w0[1], xn[ks][0], hacc);
+                    hacc1 = T::mfma(w1[1], xn[ks + 1][0], hacc1);
+                    hacc = T::mfma(w0[0], xn[ks][1], hacc);
+                    hacc1 = T::mfma(w1[0], xn[ks + 1][1], hacc1);
+                }
+                hacc = T::mfma(w0[0], xn[ks][0], hacc);
+                hacc1 = T::mfma(w1[0], xn[ks + 1][0], hacc1);
+            } else {
+                asm volatile("" :: "v"(w0[0]), "v"(w0[NP - 1]), "v"(w1[0]), "v"(w1[NP - 1]));
+            }
         }
+        // fragment reads run one pair of k-steps ahead of the MFMAs that consume them
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            if (ks + 2 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NP == 2 ? 6 : 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 16; g++) hacc[g] += hacc1[g];
         u32x4 hf[2][2];                                    // [kk][plane]: B operand of c_proj
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             float v0[4], v1[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                v0[e] = gelu_erf(hacc[8 * kk + e] * inv1);
-                v1[e] = gelu_erf(hacc[8 * kk + 4 + e] * inv1);
+                v0[e] = (ABL == 1) ? hacc[8 * kk + e] * inv1 : gelu_erf(hacc[8 * kk + e] * inv1);
+                v1[e] = (ABL == 1) ? hacc[8 * kk + 4 + e] * inv1 : gelu_erf(hacc[8 * kk + 4 + e] * inv1);
             }
             u32x2 h0, l0, h1, l1;
             split4<T, NP>(v0, h0, l0);
@@ -728,18 +766,45 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(float *__restrict__ x
             hf[kk][0][0] = h0[0]; hf[kk][0][1] = h0[1]; hf[kk][0][2] = h1[0]; hf[kk][0][3] = h1[1];
             hf[kk][1][0] = l0[0]; hf[kk][1][1] = l0[1]; hf[kk][1][2] = l1[0]; hf[kk][1][3] = l1[1];
         }
+        // ---- c_proj: for each kk the CT output tiles are independent accumulators; interleave them pairwise ----
+        constexpr int NG = 2 * CT;                         // (kk, j) groups, visited kk-major so neighbours differ in j
 #pragma unroll
-        for (int j = 0; j < CT; j++)
+        for (int gi = 0; gi < NG; gi += 2) {
+            const int kk0 = gi / CT, j0 = gi % CT;
+            const int kk1 = (gi + 1 < NG) ? (gi + 1) / CT : kk0, j1 = (gi + 1 < NG) ? (gi + 1) % CT : j0;
+            u32x4 w0[2], w1[2];
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                u32x4 wf[2];
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++)
-                    wf[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((KS + 2 * j + kk) * NP + pl) * 1024);
-                acc[j] = mma<T, NP>(wf, hf[kk], acc[j]);
+            for (int pl = 0; pl < NP; pl++) {
+                w0[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((KS + 2 * j0 + kk0) * NP + pl) * 1024);
+                w1[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((KS + 2 * j1 + kk1) * NP + pl) * 1024);
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // packet t+1 has landed (this wave's share)
-        __syncthreads();                                   // ... everyone's share; and packet t is no longer read
+            if (ABL != 3) {
+                if (NP == 2) {
+                    acc[j0] = T::mfma(w0[1], hf[kk0][0], acc[j0]);
+                    if (gi + 1 < NG) acc[j1] = T::mfma(w1[1], hf[kk1][0], acc[j1]);
+                    acc[j0] = T::mfma(w0[0], hf[kk0][1], acc[j0]);
+                    if (gi + 1 < NG) acc[j1] = T::mfma(w1[0], hf[kk1][1], acc[j1]);
+                }
+                acc[j0] = T::mfma(w0[0], hf[kk0][0], acc[j0]);
+                if (gi + 1 < NG) acc[j1] = T::mfma(w1[0], hf[kk1][0], acc[j1]);
+            } else {
+                asm volatile("" :: "v"(w0[0]), "v"(w0[NP - 1]), "v"(w1[0]), "v"(w1[NP - 1]), "v"(hf[kk0][0]));
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
+#pragma unroll
+        for (int gi = 0; gi < NG; gi += 2) {
+            if (gi + 2 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, NP == 2 ? 6 : 2, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // packet t+1 must have landed before anyone reads it; the pieces of packet t+2 issued at the top of this
+        // iteration (the newest PER_WAVE of this wave) may stay in flight across the barrier.
+        // (raw s_barrier: __syncthreads() would drain every outstanding LDS-DMA, cdna guide section 5)
+        if (NBUF > 2 && t + NBUF - 1 < NT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // ... everyone's share landed; and packet t is no longer read
     }
 
     // ---- residual add, store, LayerNorm statistics of the new row for the next kernel ----
@@ -758,6 +823,255 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(float *__restrict__ x
     if (stats_out != nullptr) {
         s2 += __shfl_xor(s2, 32);
         const float mean2 = s2 / (float)C;
+        float q2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) { const float d = acc[j][g] - mean2; q2 += d * d; }
+        q2 += __shfl_xor(q2, 32);
+        if (h == 0) stats_out[m] = make_float2(mean2, rsqrtf(q2 / (float)C + 1e-5f));
+    }
+}
+
+// GELU with the 1/sqrt(2) and the powers of two folded into the rational's coefficients:
+// gelu(v) = hv + hv * erf(v / sqrt 2), hv = v / 2, erf(u / sqrt 2) ~= u N(u^2) / D(u^2) for |u| <= 4 sqrt 2 (1 beyond).
+// max abs error 1.6e-6 over [-9, 9] in fp32 arithmetic; 17 VALU instructions.
+__device__ __forceinline__ float gelu_folded(float v)
+{
+    const float u = __builtin_amdgcn_fmed3f(v, -5.6568542f, 5.6568542f);
+    const float z = u * u;
+    float p = -3.011990121e-12f;
+    p = fmaf(p, z, 6.122398825e-10f);
+    p = fmaf(p, z, -9.285302079e-08f);
+    p = fmaf(p, z, -5.031512342e-06f);
+    p = fmaf(p, z, -1.299292147e-04f);
+    p = fmaf(p, z, -1.044608780e-03f);
+    p = fmaf(p, z, -1.138161432e-02f);
+    p *= u;
+    float q = -9.103794904e-07f;
+    q = fmaf(q, z, -2.667175691e-05f);
+    q = fmaf(q, z, -4.207067436e-04f);
+    q = fmaf(q, z, -3.686664584e-03f);
+    q = fmaf(q, z, -1.426473905e-02f);
+    const float e = p * __builtin_amdgcn_rcpf(q);
+    const float hv = 0.5f * v;
+    return fmaf(hv, e, hv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused MLP, software-pipelined variant: ONE wave per SIMD (4 waves x 32 tokens per workgroup, up to 512
+// registers), and inside the wave the three stages of consecutive hidden tiles run skewed so that every MFMA
+// has VALU work to hide behind it:
+//     iteration t :  MFMA  c_fc(t+1)  and  c_proj(t-1)      ||      VALU  GELU + fp16 split of tile t
+// (measured on the lock-step version: MFMA time and VALU time simply added up -- tools/abl_mlp.sh -- because the
+// co-resident waves were in the same phase).  Weight packets are split into a c_fc stream and a c_proj stream,
+// each double-buffered in LDS by direct global->LDS loads issued one iteration ahead.
+// ---------------------------------------------------------------------------------------------
+template <class T, int NP, int CT>
+__global__ __launch_bounds__(256, 1) void mlp_fused2_kernel(float *__restrict__ x, const float *__restrict__ gain,
+                                                             const uint16_t *__restrict__ wpk, float inv1, float inv2,
+                                                             float2 *__restrict__ stats_out, int M)
+{
+    constexpr int C = CT * 32, KS = C / 16, NT = 4 * CT, NW = 4;
+    constexpr int F1 = KS * NP, F2 = 2 * CT * NP;          // fragment-planes (1 KiB each) of the c_fc / c_proj part of a packet
+    constexpr int PKT = (F1 + F2) * 1024;                  // global packet stride (pack_mlp_kernel layout)
+    constexpr int PW1 = (F1 + NW - 1) / NW, PW2 = (F2 + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][F1 KiB] c_fc buffers, then [2][F2 KiB] c_proj buffers
+    unsigned char *s1 = smem, *s2 = smem + 2 * F1 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t m = (int64_t)blockIdx.x * (NW * 32) + wave * 32 + r;
+    float *xrow = x + m * C;
+    const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(wpk);
+
+    auto issue1 = [&](int t) {                             // c_fc fragments of hidden tile t -> s1[t & 1]
+#pragma unroll
+        for (int i = 0; i < PW1; i++) {
+            const int c = min(wave + NW * i, F1 - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(wsrc + (size_t)t * PKT + (size_t)c * 1024 + lane * 16),
+                                             (lds_void_t *)(s1 + (size_t)(t & 1) * F1 * 1024 + (size_t)c * 1024), 16, 0, 0);
+        }
+    };
+    auto issue2 = [&](int t) {                             // c_proj fragments of hidden tile t -> s2[t & 1]
+#pragma unroll
+        for (int i = 0; i < PW2; i++) {
+            const int c = min(wave + NW * i, F2 - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(wsrc + (size_t)t * PKT + (size_t)(F1 + c) * 1024 + lane * 16),
+                                             (lds_void_t *)(s2 + (size_t)(t & 1) * F2 * 1024 + (size_t)c * 1024), 16, 0, 0);
+        }
+    };
+    issue1(0);
+    issue1(1);
+    issue2(0);
+
+    // ---- load the 32 x C row block in swapped layout, LayerNorm in-lane (as in mlp_fused_kernel) ----
+    f32x16 acc[CT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+            acc[j][4 * gq] = v[0]; acc[j][4 * gq + 1] = v[1]; acc[j][4 * gq + 2] = v[2]; acc[j][4 * gq + 3] = v[3];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) { const float d = acc[j][g] - mean; q += d * d; }
+    q += __shfl_xor(q, 32);
+    const float rstd = rsqrtf(q / (float)C + 1e-5f);
+    u32x4 xn[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const int j = ks >> 1, g0 = 8 * (ks & 1);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 4 * h);
+        const f32x4 gb = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 8 + 4 * h);
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v0[e] = (acc[j][g0 + e] - mean) * rstd * ga[e];
+            v1[e] = (acc[j][g0 + 4 + e] - mean) * rstd * gb[e];
+        }
+        u32x2 h0, l0, h1, l1;
+        split4<T, NP>(v0, h0, l0);
+        split4<T, NP>(v1, h1, l1);
+        xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
+        xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
+    }
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) acc[j][g] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- stage 1 of tile 0 (nothing to overlap with yet) ----
+    f32x16 hA;
+#pragma unroll
+    for (int g = 0; g < 16; g++) hA[g] = 0.f;
+    {
+        const unsigned char *p1 = s1 + lane * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            u32x4 wf[2];
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(p1 + (size_t)(ks * NP + pl) * 1024);
+            hA = mma<T, NP>(wf, xn[ks], hA);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // everyone is done reading s1[0] before it is refilled below
+
+    u32x4 hfp[2][2];                                       // split GELU output of the previous tile: B operand of c_proj(t-1)
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) hfp[kk][pl][e] = 0u;
+
+#pragma unroll 1
+    for (int t = 0; t < NT; t++) {
+        if (t + 2 < NT) issue1(t + 2);                     // -> s1[t & 1], last read for c_fc(t) in iteration t-1 (or the prologue)
+        if (t >= 1) issue2(t);                             // -> s2[t & 1], last read for c_proj(t-2) in iteration t-1
+        const unsigned char *p1 = s1 + (size_t)((t + 1) & 1) * F1 * 1024 + lane * 16;
+        // c_proj(t-1) reads s2[(t-1) & 1]; at t == 0 there is no previous tile: hfp is all zero and the (finite)
+        // fragments of packet 0 in s2[0] are multiplied by it, which adds exactly 0 -- keeps the body branch-free
+        // so that the scheduler may interleave the MFMA and VALU streams inside ONE basic block.
+        const unsigned char *p2 = s2 + (size_t)(t == 0 ? 0 : ((t + 1) & 1)) * F2 * 1024 + lane * 16;
+        // ---- MFMA stream: c_fc(t+1) -> hB (garbage, never used, in the last iteration);  c_proj(t-1) ----
+        f32x16 hB;
+#pragma unroll
+        for (int g = 0; g < 16; g++) hB[g] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            u32x4 wf[2];
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(p1 + (size_t)(ks * NP + pl) * 1024);
+            hB = mma<T, NP>(wf, xn[ks], hB);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int j = 0; j < CT; j++) {
+                u32x4 wf[2];
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(p2 + (size_t)((2 * j + kk) * NP + pl) * 1024);
+                acc[j] = mma<T, NP>(wf, hfp[kk], acc[j]);
+            }
+        // ---- VALU stream: GELU + split of tile t (independent of the MFMAs above) ----
+        u32x4 hfc[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            float v0[4], v1[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                v0[e] = gelu_folded(hA[8 * kk + e] * inv1);
+                v1[e] = gelu_folded(hA[8 * kk + 4 + e] * inv1);
+            }
+            u32x2 h0, l0, h1, l1;
+            split4<T, NP>(v0, h0, l0);
+            split4<T, NP>(v1, h1, l1);
+            hfc[kk][0][0] = h0[0]; hfc[kk][0][1] = h0[1]; hfc[kk][0][2] = h1[0]; hfc[kk][0][3] = h1[1];
+            hfc[kk][1][0] = l0[0]; hfc[kk][1][1] = l0[1]; hfc[kk][1][2] = l1[0]; hfc[kk][1][3] = l1[1];
+        }
+        // ---- tell the scheduler how to weave the two streams: fragment reads one MFMA-group ahead, and after
+        //      every MFMA a handful of VALU instructions (the matrix pipe takes 32 cycles per MFMA; ~6-7 VALU
+        //      issue slots fit behind it) ----
+        constexpr int N_MFMA_GROUPS = KS + 2 * CT;         // groups of (NP == 2 ? 3 : 1) MFMAs sharing one fragment pair
+        __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+#pragma unroll
+        for (int gI = 0; gI < N_MFMA_GROUPS; gI++) {
+            if (gI + 1 < N_MFMA_GROUPS) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+#pragma unroll
+            for (int pI = 0; pI < (NP == 2 ? 3 : 1); pI++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 6 : 18, 0);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++) hfp[kk][pl] = hfc[kk][pl];
+        hA = hB;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the packets issued above have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // ... everyone's; and the buffers read above are free again
+    }
+    {   // ---- drain: c_proj of the last tile ----
+        const unsigned char *p2 = s2 + (size_t)((NT - 1) & 1) * F2 * 1024 + lane * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int j = 0; j < CT; j++) {
+                u32x4 wf[2];
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(p2 + (size_t)((2 * j + kk) * NP + pl) * 1024);
+                acc[j] = mma<T, NP>(wf, hfp[kk], acc[j]);
+            }
+    }
+
+    // ---- residual add, store, LayerNorm statistics of the new row ----
+    float s2sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+            f32x4 cur = *dst;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { cur[e] += acc[j][4 * gq + e] * inv2; acc[j][4 * gq + e] = cur[e]; }
+            *dst = cur;
+            s2sum += (cur[0] + cur[1]) + (cur[2] + cur[3]);
+        }
+    if (stats_out != nullptr) {
+        s2sum += __shfl_xor(s2sum, 32);
+        const float mean2 = s2sum / (float)C;
         float q2 = 0.f;
 #pragma unroll
         for (int j = 0; j < CT; j++)

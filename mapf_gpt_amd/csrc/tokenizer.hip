@@ -194,25 +194,32 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
     const int cells = H * W;
 
     const int a_begin = chunk * kAgentsPerBlock;
-    for (int k = wave; k < kAgentsPerBlock; k += 4) {
-        const int a = a_begin + k;
+    // Issue the window gathers of ALL agents this wave owns before touching any of them: the kernel is bound by
+    // HBM latency (two 2-byte gathers per agent), so bytes in flight per wave, not instructions, set the rate.
+    constexpr int kPerWave = kAgentsPerBlock / 4;
+    const int p0 = lane, i0 = p0 / kWin, j0 = p0 - i0 * kWin;
+    const int p1 = lane + 64, i1 = p1 / kWin, j1 = p1 - i1 * kWin;
+    int w0[kPerWave], w1[kPerWave];
+#pragma unroll
+    for (int q = 0; q < kPerWave; q++) {
+        const int a = a_begin + wave + 4 * q;
+        w0[q] = kUnreach; w1[q] = kUnreach;
+        if (a < n_agents) {                                             // wave-uniform
+            const int pr = srec[a].pr, pc = srec[a].pc;
+            const uint16_t *d = dist + ((size_t)inst * n_agents + a) * cells;
+            const int rr0 = pr - kR + i0, cc0 = pc - kR + j0;
+            if (rr0 >= 0 && rr0 < H && cc0 >= 0 && cc0 < W) w0[q] = (int)d[rr0 * W + cc0];
+            const int rr1 = pr - kR + i1, cc1 = pc - kR + j1;
+            if (p1 < kWin * kWin && rr1 >= 0 && rr1 < H && cc1 >= 0 && cc1 < W) w1[q] = (int)d[rr1 * W + cc1];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kPerWave; q++) {
+        const int a = a_begin + wave + 4 * q;
         if (a >= n_agents) break;                                       // wave-uniform
         const AgentRec me = srec[a];
         const int pr = me.pr, pc = me.pc;
-        const uint16_t *d = dist + ((size_t)inst * n_agents + a) * cells;
-
-        // --- window gather (two passes of 64 lanes over the 121 cells) ---
-        int v0, v1 = kUnreach;
-        {
-            const int p = lane, i = p / kWin, j = p - i * kWin;
-            const int rr = pr - kR + i, cc = pc - kR + j;
-            v0 = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? (int)d[rr * W + cc] : kUnreach;
-        }
-        if (lane + 64 < kWin * kWin) {
-            const int p = lane + 64, i = p / kWin, j = p - i * kWin;
-            const int rr = pr - kR + i, cc = pc - kR + j;
-            v1 = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? (int)d[rr * W + cc] : kUnreach;
-        }
+        const int v0 = w0[q], v1 = w1[q];
 
         row32[lane] = 0x42424242u;                                      // whole row <- "!" (66), cpp:375-376,386-387
 
