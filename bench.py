@@ -6,6 +6,8 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over every instance of the workload (one env step of every agent).
+Arithmetic: --precision f16x3 (default; split-fp16 3-pass MFMA with fp32 accumulate, logits within 1e-5 of the
+reference fp32 forward -- tests/test_gpu_gpt.py), f32 (exact fp32 MFMA) or bf16 (reduced precision, not the headline).
 Workload (BASELINE.json configs[1]): map validation-mazes-seed-000, 64 agents, MAPF-GPT-2M shape,
 256 parallel instances PER GPU (weak scaling: instances shard across ranks with no per-step
 collective; one metrics all_gather after the timed region).  Synthetic data: seeded starts/goals
@@ -134,7 +136,7 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default=os.environ.get("MGPT_BENCH_PRECISION", "f32"), choices=["f32", "f16x3", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("MGPT_BENCH_PRECISION", "f16x3"), choices=["f32", "f16x3", "bf16"])
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event hooks")

@@ -15,8 +15,8 @@ timeout 900 python bench.py --steps 8 --warmup 2 > $OUT/bench.log 2> $OUT/bench.
 cat $OUT/bench.log >> $OUT/summary.txt; tail -5 $OUT/bench.err >> $OUT/summary.txt
 if [ "$1" != "quick" ]; then
   echo "== rocprofv3 kernel trace ==" | tee -a $OUT/summary.txt
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-prof > $OLDPWD/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
-  find $OUT/prof -name "*kernel_stats*" | head -3 >> $OUT/summary.txt
-  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" >> $OUT/summary.txt
+  R=$PWD
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-prof > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
+  python tools/rocpd_summary.py $OUT/prof/bench_results.db $OUT/kernel_stats.txt | cut -c1-210 | head -24 >> $OUT/summary.txt
 fi
 cat $OUT/summary.txt
