@@ -220,21 +220,6 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             // ---- whole MLP block in one kernel (hidden stays in registers) ----
             ProfScope ps(P_MLP_FUSED, s);
             const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 3;
-            static const int mlp_v = getenv("MGPT_MLP_V") ? atoi(getenv("MGPT_MLP_V")) : 1;
-            if (mlp_v == 2) {
-                const size_t lds2 = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 2;
-                if (C == 160) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused2_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                    hipLaunchKernelGGL((fastk::mlp_fused2_kernel<T, NP, 5>), dim3((unsigned)(M / 128)), dim3(256), lds2, s, g->x, P + lo.ln2,
-                                       m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)M);
-                } else {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused2_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                    hipLaunchKernelGGL((fastk::mlp_fused2_kernel<T, NP, 2>), dim3((unsigned)(M / 128)), dim3(256), lds2, s, g->x, P + lo.ln2,
-                                       m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)M);
-                }
-                MGPT_LAUNCH_CHECK();
-                continue;
-            }
             static const int abl = getenv("MGPT_MLP_ABL") ? atoi(getenv("MGPT_MLP_ABL")) : 0;   // timing experiments only
             if (C == 160 && NP == 2 && abl != 0) {
 #define MGPT_ABL_LAUNCH(A_)                                                                                                         \

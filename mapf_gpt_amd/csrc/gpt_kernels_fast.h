@@ -223,6 +223,32 @@ __device__ __forceinline__ float erf_fast(float x)
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
 
+// GELU with the 1/sqrt(2) and the powers of two folded into the rational's coefficients:
+// gelu(v) = hv + hv * erf(v / sqrt 2), hv = v / 2, erf(u / sqrt 2) ~= u N(u^2) / D(u^2) for |u| <= 4 sqrt 2 (1 beyond).
+// max abs error 1.6e-6 over [-9, 9] in fp32 arithmetic; 17 VALU instructions.
+__device__ __forceinline__ float gelu_folded(float v)
+{
+    const float u = __builtin_amdgcn_fmed3f(v, -5.6568542f, 5.6568542f);
+    const float z = u * u;
+    float p = -3.011990121e-12f;
+    p = fmaf(p, z, 6.122398825e-10f);
+    p = fmaf(p, z, -9.285302079e-08f);
+    p = fmaf(p, z, -5.031512342e-06f);
+    p = fmaf(p, z, -1.299292147e-04f);
+    p = fmaf(p, z, -1.044608780e-03f);
+    p = fmaf(p, z, -1.138161432e-02f);
+    p *= u;
+    float q = -9.103794904e-07f;
+    q = fmaf(q, z, -2.667175691e-05f);
+    q = fmaf(q, z, -4.207067436e-04f);
+    q = fmaf(q, z, -3.686664584e-03f);
+    q = fmaf(q, z, -1.426473905e-02f);
+    const float e = p * __builtin_amdgcn_rcpf(q);
+    const float hv = 0.5f * v;
+    return fmaf(hv, e, hv);
+}
+
+
 template <class T, int NP, int BN, int WM, int WN, int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p)
 {
@@ -403,7 +429,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p)
                         rsum[i] += (cur[0] + cur[1]) + (cur[2] + cur[3]);
                     } else if (EPI == EPI_GELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+                        for (int e = 0; e < 4; e++) v[e] = gelu_folded(v[e]);
                         u32x2 hi, lo;
                         split4<T, NP>(v, hi, lo);
                         *reinterpret_cast<u32x2 *>(p.o_hi + m * p.N + n) = hi;
@@ -757,8 +783,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
             float v0[4], v1[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                v0[e] = (ABL == 1) ? hacc[8 * kk + e] * inv1 : gelu_erf(hacc[8 * kk + e] * inv1);
-                v1[e] = (ABL == 1) ? hacc[8 * kk + 4 + e] * inv1 : gelu_erf(hacc[8 * kk + 4 + e] * inv1);
+                v0[e] = (ABL == 1) ? hacc[8 * kk + e] * inv1 : gelu_folded(hacc[8 * kk + e] * inv1);
+                v1[e] = (ABL == 1) ? hacc[8 * kk + 4 + e] * inv1 : gelu_folded(hacc[8 * kk + 4 + e] * inv1);
             }
             u32x2 h0, l0, h1, l1;
             split4<T, NP>(v0, h0, l0);
@@ -823,255 +849,6 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
     if (stats_out != nullptr) {
         s2 += __shfl_xor(s2, 32);
         const float mean2 = s2 / (float)C;
-        float q2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < CT; j++)
-#pragma unroll
-            for (int g = 0; g < 16; g++) { const float d = acc[j][g] - mean2; q2 += d * d; }
-        q2 += __shfl_xor(q2, 32);
-        if (h == 0) stats_out[m] = make_float2(mean2, rsqrtf(q2 / (float)C + 1e-5f));
-    }
-}
-
-// GELU with the 1/sqrt(2) and the powers of two folded into the rational's coefficients:
-// gelu(v) = hv + hv * erf(v / sqrt 2), hv = v / 2, erf(u / sqrt 2) ~= u N(u^2) / D(u^2) for |u| <= 4 sqrt 2 (1 beyond).
-// max abs error 1.6e-6 over [-9, 9] in fp32 arithmetic; 17 VALU instructions.
-__device__ __forceinline__ float gelu_folded(float v)
-{
-    const float u = __builtin_amdgcn_fmed3f(v, -5.6568542f, 5.6568542f);
-    const float z = u * u;
-    float p = -3.011990121e-12f;
-    p = fmaf(p, z, 6.122398825e-10f);
-    p = fmaf(p, z, -9.285302079e-08f);
-    p = fmaf(p, z, -5.031512342e-06f);
-    p = fmaf(p, z, -1.299292147e-04f);
-    p = fmaf(p, z, -1.044608780e-03f);
-    p = fmaf(p, z, -1.138161432e-02f);
-    p *= u;
-    float q = -9.103794904e-07f;
-    q = fmaf(q, z, -2.667175691e-05f);
-    q = fmaf(q, z, -4.207067436e-04f);
-    q = fmaf(q, z, -3.686664584e-03f);
-    q = fmaf(q, z, -1.426473905e-02f);
-    const float e = p * __builtin_amdgcn_rcpf(q);
-    const float hv = 0.5f * v;
-    return fmaf(hv, e, hv);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fused MLP, software-pipelined variant: ONE wave per SIMD (4 waves x 32 tokens per workgroup, up to 512
-// registers), and inside the wave the three stages of consecutive hidden tiles run skewed so that every MFMA
-// has VALU work to hide behind it:
-//     iteration t :  MFMA  c_fc(t+1)  and  c_proj(t-1)      ||      VALU  GELU + fp16 split of tile t
-// (measured on the lock-step version: MFMA time and VALU time simply added up -- tools/abl_mlp.sh -- because the
-// co-resident waves were in the same phase).  Weight packets are split into a c_fc stream and a c_proj stream,
-// each double-buffered in LDS by direct global->LDS loads issued one iteration ahead.
-// ---------------------------------------------------------------------------------------------
-template <class T, int NP, int CT>
-__global__ __launch_bounds__(256, 1) void mlp_fused2_kernel(float *__restrict__ x, const float *__restrict__ gain,
-                                                             const uint16_t *__restrict__ wpk, float inv1, float inv2,
-                                                             float2 *__restrict__ stats_out, int M)
-{
-    constexpr int C = CT * 32, KS = C / 16, NT = 4 * CT, NW = 4;
-    constexpr int F1 = KS * NP, F2 = 2 * CT * NP;          // fragment-planes (1 KiB each) of the c_fc / c_proj part of a packet
-    constexpr int PKT = (F1 + F2) * 1024;                  // global packet stride (pack_mlp_kernel layout)
-    constexpr int PW1 = (F1 + NW - 1) / NW, PW2 = (F2 + NW - 1) / NW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][F1 KiB] c_fc buffers, then [2][F2 KiB] c_proj buffers
-    unsigned char *s1 = smem, *s2 = smem + 2 * F1 * 1024;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int64_t m = (int64_t)blockIdx.x * (NW * 32) + wave * 32 + r;
-    float *xrow = x + m * C;
-    const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(wpk);
-
-    auto issue1 = [&](int t) {                             // c_fc fragments of hidden tile t -> s1[t & 1]
-#pragma unroll
-        for (int i = 0; i < PW1; i++) {
-            const int c = min(wave + NW * i, F1 - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(wsrc + (size_t)t * PKT + (size_t)c * 1024 + lane * 16),
-                                             (lds_void_t *)(s1 + (size_t)(t & 1) * F1 * 1024 + (size_t)c * 1024), 16, 0, 0);
-        }
-    };
-    auto issue2 = [&](int t) {                             // c_proj fragments of hidden tile t -> s2[t & 1]
-#pragma unroll
-        for (int i = 0; i < PW2; i++) {
-            const int c = min(wave + NW * i, F2 - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(wsrc + (size_t)t * PKT + (size_t)(F1 + c) * 1024 + lane * 16),
-                                             (lds_void_t *)(s2 + (size_t)(t & 1) * F2 * 1024 + (size_t)c * 1024), 16, 0, 0);
-        }
-    };
-    issue1(0);
-    issue1(1);
-    issue2(0);
-
-    // ---- load the 32 x C row block in swapped layout, LayerNorm in-lane (as in mlp_fused_kernel) ----
-    f32x16 acc[CT];
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < CT; j++)
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
-            acc[j][4 * gq] = v[0]; acc[j][4 * gq + 1] = v[1]; acc[j][4 * gq + 2] = v[2]; acc[j][4 * gq + 3] = v[3];
-            s += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-    s += __shfl_xor(s, 32);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < CT; j++)
-#pragma unroll
-        for (int g = 0; g < 16; g++) { const float d = acc[j][g] - mean; q += d * d; }
-    q += __shfl_xor(q, 32);
-    const float rstd = rsqrtf(q / (float)C + 1e-5f);
-    u32x4 xn[KS][2];
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-        const int j = ks >> 1, g0 = 8 * (ks & 1);
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 4 * h);
-        const f32x4 gb = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 8 + 4 * h);
-        float v0[4], v1[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            v0[e] = (acc[j][g0 + e] - mean) * rstd * ga[e];
-            v1[e] = (acc[j][g0 + 4 + e] - mean) * rstd * gb[e];
-        }
-        u32x2 h0, l0, h1, l1;
-        split4<T, NP>(v0, h0, l0);
-        split4<T, NP>(v1, h1, l1);
-        xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
-        xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
-    }
-#pragma unroll
-    for (int j = 0; j < CT; j++)
-#pragma unroll
-        for (int g = 0; g < 16; g++) acc[j][g] = 0.f;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // ---- stage 1 of tile 0 (nothing to overlap with yet) ----
-    f32x16 hA;
-#pragma unroll
-    for (int g = 0; g < 16; g++) hA[g] = 0.f;
-    {
-        const unsigned char *p1 = s1 + lane * 16;
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            u32x4 wf[2];
-#pragma unroll
-            for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(p1 + (size_t)(ks * NP + pl) * 1024);
-            hA = mma<T, NP>(wf, xn[ks], hA);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // everyone is done reading s1[0] before it is refilled below
-
-    u32x4 hfp[2][2];                                       // split GELU output of the previous tile: B operand of c_proj(t-1)
-#pragma unroll
-    for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-        for (int pl = 0; pl < 2; pl++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) hfp[kk][pl][e] = 0u;
-
-#pragma unroll 1
-    for (int t = 0; t < NT; t++) {
-        if (t + 2 < NT) issue1(t + 2);                     // -> s1[t & 1], last read for c_fc(t) in iteration t-1 (or the prologue)
-        if (t >= 1) issue2(t);                             // -> s2[t & 1], last read for c_proj(t-2) in iteration t-1
-        const unsigned char *p1 = s1 + (size_t)((t + 1) & 1) * F1 * 1024 + lane * 16;
-        // c_proj(t-1) reads s2[(t-1) & 1]; at t == 0 there is no previous tile: hfp is all zero and the (finite)
-        // fragments of packet 0 in s2[0] are multiplied by it, which adds exactly 0 -- keeps the body branch-free
-        // so that the scheduler may interleave the MFMA and VALU streams inside ONE basic block.
-        const unsigned char *p2 = s2 + (size_t)(t == 0 ? 0 : ((t + 1) & 1)) * F2 * 1024 + lane * 16;
-        // ---- MFMA stream: c_fc(t+1) -> hB (garbage, never used, in the last iteration);  c_proj(t-1) ----
-        f32x16 hB;
-#pragma unroll
-        for (int g = 0; g < 16; g++) hB[g] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            u32x4 wf[2];
-#pragma unroll
-            for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(p1 + (size_t)(ks * NP + pl) * 1024);
-            hB = mma<T, NP>(wf, xn[ks], hB);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-            for (int j = 0; j < CT; j++) {
-                u32x4 wf[2];
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(p2 + (size_t)((2 * j + kk) * NP + pl) * 1024);
-                acc[j] = mma<T, NP>(wf, hfp[kk], acc[j]);
-            }
-        // ---- VALU stream: GELU + split of tile t (independent of the MFMAs above) ----
-        u32x4 hfc[2][2];
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            float v0[4], v1[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                v0[e] = gelu_folded(hA[8 * kk + e] * inv1);
-                v1[e] = gelu_folded(hA[8 * kk + 4 + e] * inv1);
-            }
-            u32x2 h0, l0, h1, l1;
-            split4<T, NP>(v0, h0, l0);
-            split4<T, NP>(v1, h1, l1);
-            hfc[kk][0][0] = h0[0]; hfc[kk][0][1] = h0[1]; hfc[kk][0][2] = h1[0]; hfc[kk][0][3] = h1[1];
-            hfc[kk][1][0] = l0[0]; hfc[kk][1][1] = l0[1]; hfc[kk][1][2] = l1[0]; hfc[kk][1][3] = l1[1];
-        }
-        // ---- tell the scheduler how to weave the two streams: fragment reads one MFMA-group ahead, and after
-        //      every MFMA a handful of VALU instructions (the matrix pipe takes 32 cycles per MFMA; ~6-7 VALU
-        //      issue slots fit behind it) ----
-        constexpr int N_MFMA_GROUPS = KS + 2 * CT;         // groups of (NP == 2 ? 3 : 1) MFMAs sharing one fragment pair
-        __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
-#pragma unroll
-        for (int gI = 0; gI < N_MFMA_GROUPS; gI++) {
-            if (gI + 1 < N_MFMA_GROUPS) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
-#pragma unroll
-            for (int pI = 0; pI < (NP == 2 ? 3 : 1); pI++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 6 : 18, 0);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-            for (int pl = 0; pl < 2; pl++) hfp[kk][pl] = hfc[kk][pl];
-        hA = hB;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the packets issued above have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // ... everyone's; and the buffers read above are free again
-    }
-    {   // ---- drain: c_proj of the last tile ----
-        const unsigned char *p2 = s2 + (size_t)((NT - 1) & 1) * F2 * 1024 + lane * 16;
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-            for (int j = 0; j < CT; j++) {
-                u32x4 wf[2];
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(p2 + (size_t)((2 * j + kk) * NP + pl) * 1024);
-                acc[j] = mma<T, NP>(wf, hfp[kk], acc[j]);
-            }
-    }
-
-    // ---- residual add, store, LayerNorm statistics of the new row ----
-    float s2sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < CT; j++)
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
-            f32x4 cur = *dst;
-#pragma unroll
-            for (int e = 0; e < 4; e++) { cur[e] += acc[j][4 * gq + e] * inv2; acc[j][4 * gq + e] = cur[e]; }
-            *dst = cur;
-            s2sum += (cur[0] + cur[1]) + (cur[2] + cur[3]);
-        }
-    if (stats_out != nullptr) {
-        s2sum += __shfl_xor(s2sum, 32);
-        const float mean2 = s2sum / (float)C;
         float q2 = 0.f;
 #pragma unroll
         for (int j = 0; j < CT; j++)
