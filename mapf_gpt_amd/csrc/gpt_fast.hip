@@ -37,6 +37,9 @@ struct ModeState {          // one precision mode
     // fused MLP (C = 64 / 160): per layer one packed stream [hidden tile][fragment][plane][lane][8]
     std::vector<uint16_t *> mlp_pk;
     bool mlp_fused = false;
+    // register-resident LN+QKV (C = 64 / 160): per layer [tile][k-step][plane][lane][8] of c_attn.weight
+    std::vector<uint16_t *> qkv_pk;
+    bool qkv_fused = false;
 };
 
 struct FastState {
@@ -104,6 +107,18 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
         else MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
     }
+    m->qkv_fused = (C == 160 || C == 64) && getenv("MGPT_NO_FUSED_QKV") == nullptr;
+    if (m->qkv_fused) {
+        const size_t ks = C / 16, ntile = 3 * C / 32;
+        m->qkv_pk.assign(g->L, nullptr);
+        for (int l = 0; l < g->L; l++) {
+            MGPT_HIP(hipMalloc(&m->qkv_pk[l], ntile * ks * NP * 512 * sizeof(uint16_t)));
+            ProfScope ps(P_PACK, nullptr);
+            hipLaunchKernelGGL((fastk::pack_rows_perm_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)(ntile * ks * 64), 256)), dim3(256), 0,
+                               nullptr, g->params + g->layers[l].attn_w, m->qkv_pk[l], (int)ntile, (int)C, 1.0f / m->attn[l].inv_scale);
+            MGPT_LAUNCH_CHECK();
+        }
+    }
     const size_t M = (size_t)g->max_rows * kT;
     MGPT_HIP(hipMalloc(&m->stats, M * sizeof(float2)));
     for (int p = 0; p < NP; p++) {
@@ -122,6 +137,7 @@ void free_mode(ModeState *m)
     auto fr = [](std::vector<PlaneSet> &v) { for (auto &p : v) { (void)hipFree(p.hi); (void)hipFree(p.lo); } v.clear(); };
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
     for (auto *p : m->mlp_pk) (void)hipFree(p);
+    for (auto *p : m->qkv_pk) (void)hipFree(p);
     (void)hipFree(m->stats);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
@@ -190,7 +206,17 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         a.x = g->x; a.stats = m->stats; a.gain = P + lo.ln1; a.K = C;
         a.w_hi = m->attn[l].hi; a.w_lo = m->attn[l].lo; a.out_scale = m->attn[l].inv_scale;
         a.N = 2 * C; a.o_hi = m->qk[0]; a.o_lo = m->qk[1];
-        {
+        if (m->qkv_fused) {
+            ProfScope ps(P_LNQKV_FUSED, s);
+            const size_t lds = (size_t)(C / 16) * NP * 1024 * 2;
+            if (C == 160)
+                hipLaunchKernelGGL((fastk::ln_qkv_kernel<T, NP, 5>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, m->qkv_pk[l],
+                                   m->attn[l].inv_scale, m->qk[0], m->qk[1], m->vt[0], m->vt[1], g->nh, g->hs, (int64_t)(M * C));
+            else
+                hipLaunchKernelGGL((fastk::ln_qkv_kernel<T, NP, 2>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, m->qkv_pk[l],
+                                   m->attn[l].inv_scale, m->qk[0], m->qk[1], m->vt[0], m->vt[1], g->nh, g->hs, (int64_t)(M * C));
+            MGPT_LAUNCH_CHECK();
+        } else {
             ProfScope ps(P_GEMM_QKV, s);
             if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_QK>(a, C, s)) != MGPT_OK) return rc;
             // ---- LN1 + V projection -> v^T planes ----

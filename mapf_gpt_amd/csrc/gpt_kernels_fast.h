@@ -859,5 +859,187 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused LayerNorm + QKV projection in the register-resident style of mlp_fused_kernel: a workgroup = one row
+// (8 waves x 32 tokens), every wave normalises its 32 tokens once, keeps them as MFMA operand planes in registers
+// and walks all 3C/32 output tiles; weight fragments stream through an LDS ring by direct global->LDS loads.
+// Q and K tiles run "swapped" (lane = token: 4 consecutive d per store into the head-major planes), V tiles run
+// "natural" (lane = d: 4 consecutive tokens per store into the transposed planes).  No A-tile staging, no barrier
+// besides the ring hand-over, no LayerNorm statistics input.
+//   wpk: [tile][k-step][plane][lane][8]  (rows 32 tile .. +32 of c_attn.weight, k-slots permuted like the MLP's)
+// ---------------------------------------------------------------------------------------------
+template <class T, int NP>
+__global__ __launch_bounds__(256) void pack_rows_perm_kernel(const float *__restrict__ w, uint16_t *__restrict__ out,
+                                                             int n_tiles, int C, float scale)
+{
+    const int KS = C / 16;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)n_tiles * KS * 64) return;
+    const int lane = (int)(gid & 63), ks = (int)((gid >> 6) % KS), t = (int)((gid >> 6) / KS);
+    const int i = lane & 31, h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int g = 8 * (ks & 1) + e;
+        const int feat = 32 * (ks >> 1) + (g & 3) + 8 * (g >> 2) + 4 * h;
+        v[e] = w[(size_t)(32 * t + i) * C + feat] * scale;
+    }
+    u32x2 h0, l0, h1, l1;
+    split4<T, NP>(v, h0, l0);
+    split4<T, NP>(v + 4, h1, l1);
+    u32x4 hi, lo;
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+    uint16_t *dst = out + (((size_t)t * KS + ks) * NP) * 512 + (size_t)lane * 8;
+    *reinterpret_cast<u32x4 *>(dst) = hi;
+    if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
+}
+
+template <class T, int NP, int CT>
+__global__ __launch_bounds__(512, 2) void ln_qkv_kernel(const float *__restrict__ x, const float *__restrict__ gain,
+                                                         const uint16_t *__restrict__ wpk, float inv_scale,
+                                                         uint16_t *__restrict__ qk_hi, uint16_t *__restrict__ qk_lo,
+                                                         uint16_t *__restrict__ vt_hi, uint16_t *__restrict__ vt_lo,
+                                                         int n_head, int hs, int64_t plane)
+{
+    constexpr int C = CT * 32, KS = C / 16, NTILE = 3 * CT, NW = 8, NBUF = 2;
+    constexpr int F = KS * NP;                             // fragment-planes (1 KiB) per tile packet
+    constexpr int PKT = F * 1024;
+    constexpr int PER_WAVE = (F + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NBUF][PKT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.x;                                          // row (256 tokens)
+    const int tok0 = wave * 32;                                            // first token of this wave inside the row
+    const float *xrow = x + (b * kT + tok0 + r) * C;
+    const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(wpk);
+
+    auto issue = [&](int t) {
+        unsigned char *dst = smem + (size_t)(t % NBUF) * PKT;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; i++) {
+            const int c = min(wave + NW * i, F - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(wsrc + (size_t)t * PKT + (size_t)c * 1024 + lane * 16),
+                                             (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+
+    // ---- LayerNorm of this lane's token (in-lane + one exchange), operand planes in registers ----
+    f32x16 xv[CT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+            xv[j][4 * gq] = v[0]; xv[j][4 * gq + 1] = v[1]; xv[j][4 * gq + 2] = v[2]; xv[j][4 * gq + 3] = v[3];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) { const float d = xv[j][g] - mean; q += d * d; }
+    q += __shfl_xor(q, 32);
+    const float rstd = rsqrtf(q / (float)C + 1e-5f);
+    u32x4 xn[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const int j = ks >> 1, g0 = 8 * (ks & 1);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 4 * h);
+        const f32x4 gb = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 8 + 4 * h);
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v0[e] = (xv[j][g0 + e] - mean) * rstd * ga[e];
+            v1[e] = (xv[j][g0 + 4 + e] - mean) * rstd * gb[e];
+        }
+        u32x2 h0, l0, h1, l1;
+        split4<T, NP>(v0, h0, l0);
+        split4<T, NP>(v1, h1, l1);
+        xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
+        xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // packet 0 landed
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll 1
+    for (int t = 0; t < NTILE; t++) {
+        if (t + NBUF - 1 < NTILE) issue(t + NBUF - 1);
+        const unsigned char *pk = smem + (size_t)(t % NBUF) * PKT + lane * 16;
+        const bool is_v = t >= 2 * CT;                                     // workgroup-uniform
+        f32x16 a0, a1;
+#pragma unroll
+        for (int g = 0; g < 16; g++) { a0[g] = 0.f; a1[g] = 0.f; }
+        if (!is_v) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks += 2) {
+                u32x4 w0[2], w1[2];
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) {
+                    w0[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(ks * NP + pl) * 1024);
+                    w1[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + 1) * NP + pl) * 1024);
+                }
+                a0 = mma<T, NP>(w0, xn[ks], a0);                           // swapped: rows = output features, cols = tokens
+                a1 = mma<T, NP>(w1, xn[ks + 1], a1);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks += 2) {
+                u32x4 w0[2], w1[2];
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) {
+                    w0[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(ks * NP + pl) * 1024);
+                    w1[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + 1) * NP + pl) * 1024);
+                }
+                a0 = mma<T, NP>(xn[ks], w0, a0);                           // natural: rows = tokens, cols = output features
+                a1 = mma<T, NP>(xn[ks + 1], w1, a1);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g++) a0[g] = (a0[g] + a1[g]) * inv_scale;
+        // ---- epilogue of the tile ----
+        const int n0 = 32 * (t % CT);                                      // first feature of this tile inside q, k or v
+        if (!is_v) {
+            // lane = token tok0 + r; registers = features n0 + (g&3) + 8 (g>>2) + 4 h
+            const int which = t / CT;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const int n = n0 + 8 * gq + 4 * h;
+                const int head = n / hs, d = n - head * hs;
+                const int64_t off = (int64_t)which * plane + ((b * n_head + head) * kT + tok0 + r) * hs + d;
+                const float v[4] = {a0[4 * gq], a0[4 * gq + 1], a0[4 * gq + 2], a0[4 * gq + 3]};
+                u32x2 hi, lo;
+                split4<T, NP>(v, hi, lo);
+                *reinterpret_cast<u32x2 *>(qk_hi + off) = hi;
+                if (NP == 2) *reinterpret_cast<u32x2 *>(qk_lo + off) = lo;
+            }
+        } else {
+            // lane = feature n0 + r; registers = tokens tok0 + (g&3) + 8 (g>>2) + 4 h
+            const int n = n0 + r;
+            const int head = n / hs, d = n - head * hs;
+            const int64_t rowbase = ((b * n_head + head) * hs + d) * kT + tok0;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const float v[4] = {a0[4 * gq], a0[4 * gq + 1], a0[4 * gq + 2], a0[4 * gq + 3]};
+                u32x2 hi, lo;
+                split4<T, NP>(v, hi, lo);
+                *reinterpret_cast<u32x2 *>(vt_hi + rowbase + 8 * gq + 4 * h) = hi;
+                if (NP == 2) *reinterpret_cast<u32x2 *>(vt_lo + rowbase + 8 * gq + 4 * h) = lo;
+            }
+        }
+        // hand the ring over: packet t+1 (issued at the top of this iteration) must have landed everywhere.
+        // Plain vmcnt(0): this wave's epilogue stores share the counter and may retire out of order with the
+        // LDS-DMA loads, so a counted wait could not tell them apart.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 }  // namespace fastk
 }  // namespace mgpt
