@@ -206,7 +206,25 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         a.x = g->x; a.stats = m->stats; a.gain = P + lo.ln1; a.K = C;
         a.w_hi = m->attn[l].hi; a.w_lo = m->attn[l].lo; a.out_scale = m->attn[l].inv_scale;
         a.N = 2 * C; a.o_hi = m->qk[0]; a.o_lo = m->qk[1];
-        if (m->qkv_fused) {
+        static const bool no_attn_block = getenv("MGPT_NO_ATTN_BLOCK") != nullptr;
+        const bool attn_block = m->qkv_fused && g->hs == 32 && !no_attn_block;
+        if (attn_block) {
+            // ---- LN1 + QKV + attention in one kernel (q, k, v stay on chip) ----
+            ProfScope ps(P_ATTN, s);
+            const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 2;
+            if (C == 160) {
+                static bool once160 = false;
+                if (!once160) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once160 = true; }
+                hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, 5>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, m->qkv_pk[l],
+                                   m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e);
+            } else {
+                static bool once64 = false;
+                if (!once64) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once64 = true; }
+                hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, 2>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, m->qkv_pk[l],
+                                   m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e);
+            }
+            MGPT_LAUNCH_CHECK();
+        } else if (m->qkv_fused) {
             ProfScope ps(P_LNQKV_FUSED, s);
             const size_t lds = (size_t)(C / 16) * NP * 1024 * 2;
             if (C == 160)
@@ -224,7 +242,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             a.N = C; a.o_hi = m->vt[0]; a.o_lo = m->vt[1];
             if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_VT>(a, C, s)) != MGPT_OK) return rc;
         }
-        {
+        if (!attn_block) {
             ProfScope ps(P_ATTN, s);
             const uint16_t *qh = m->qk[0], *ql = m->qk[1], *kh = m->qk[0] + M * C, *kl = (NP == 2) ? m->qk[1] + M * C : nullptr;
             if (g->hs == 32)

@@ -1041,5 +1041,228 @@ __global__ __launch_bounds__(512, 2) void ln_qkv_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused attention block front half: LayerNorm + QKV projection + non-causal attention for ONE row per
+// workgroup (8 waves x 32 tokens), heads visited one after the other; q, k, v never touch HBM.
+//   per head:  q,k (swapped) and v (natural) tiles from the wave's register-resident normalised tokens and the
+//              DMA-streamed c_attn fragments  ->  k, v^T planes of the head into LDS (all 8 waves contribute
+//              their 32 keys), q stays in registers as the B operand  ->  barrier  ->  every wave runs its 32
+//              queries against the 256 keys (online softmax as in attn16_kernel)  ->  y planes of the head.
+// Layout trick that makes this transposition-free: the C/D register -> row map tau(g,h) = (g&3)+8(g>>2)+4h is
+// the same for "d of a token" (swapped q/k tiles), "token of a d" (natural v tile) and "key of a query" (S^T
+// tile), so register octets [8m, 8m+8) are directly MFMA k-slot groups everywhere, and the LDS images are written
+// and read with the same (row, octet, half) address.
+// ---------------------------------------------------------------------------------------------
+template <class T, int NP, int CT>
+__global__ __launch_bounds__(512, 2) void attn_block_kernel(const float *__restrict__ x, const float *__restrict__ gain,
+                                                             const uint16_t *__restrict__ wpk, float inv_scale,
+                                                             uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo,
+                                                             int n_head, float scale_log2e)
+{
+    constexpr int C = CT * 32, KS = C / 16, NW = 8, HS = 32;
+    constexpr int F = KS * NP, PKT = F * 1024, PER_WAVE = (F + NW - 1) / NW;
+    constexpr int KROW = 80, VROW = 528;                                  // padded LDS rows (bytes): conflict-free b128 reads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sK = smem;                                             // [NP][256][KROW]
+    unsigned char *sV = sK + NP * kT * KROW;                              // [NP][32][VROW]
+    unsigned char *sW = sV + NP * HS * VROW;                              // [2][PKT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.x;
+    const int tok0 = wave * 32;
+    const float *xrow = x + (b * kT + tok0 + r) * C;
+    const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(wpk);
+    const int n_seq = 3 * n_head;                                         // (head, which) packets in visiting order
+
+    auto issue = [&](int sq) {                                            // packet sq = (head sq/3, which sq%3) -> sW[sq & 1]
+        const int tile = (sq % 3) * CT + sq / 3;                          // hs == 32: one tile per (which, head)
+        unsigned char *dst = sW + (size_t)(sq & 1) * PKT;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; i++) {
+            const int c = min(wave + NW * i, F - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(wsrc + (size_t)tile * PKT + (size_t)c * 1024 + lane * 16),
+                                             (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+
+    // ---- LayerNorm of this lane's token, operand planes in registers (as ln_qkv_kernel) ----
+    u32x4 xn[KS][2];
+    {
+        f32x16 xv[CT];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; j++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+                xv[j][4 * gq] = v[0]; xv[j][4 * gq + 1] = v[1]; xv[j][4 * gq + 2] = v[2]; xv[j][4 * gq + 3] = v[3];
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        s += __shfl_xor(s, 32);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) { const float d = xv[j][g] - mean; q += d * d; }
+        q += __shfl_xor(q, 32);
+        const float rstd = rsqrtf(q / (float)C + 1e-5f);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int j = ks >> 1, g0 = 8 * (ks & 1);
+            const f32x4 ga = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 4 * h);
+            const f32x4 gb = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 8 + 4 * h);
+            float v0[4], v1[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                v0[e] = (xv[j][g0 + e] - mean) * rstd * ga[e];
+                v1[e] = (xv[j][g0 + 4 + e] - mean) * rstd * gb[e];
+            }
+            u32x2 h0, l0, h1, l1;
+            split4<T, NP>(v0, h0, l0);
+            split4<T, NP>(v1, h1, l1);
+            xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
+            xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // one projection tile from the packet in sW[sq & 1]; SWAP: lane = token, registers = features (else the transpose)
+    auto project = [&](int sq, bool swapped, f32x16 &out) {
+        const unsigned char *pk = sW + (size_t)(sq & 1) * PKT + lane * 16;
+        f32x16 a0, a1;
+#pragma unroll
+        for (int g = 0; g < 16; g++) { a0[g] = 0.f; a1[g] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            u32x4 w0[2], w1[2];
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) {
+                w0[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(ks * NP + pl) * 1024);
+                w1[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + 1) * NP + pl) * 1024);
+            }
+            if (swapped) { a0 = mma<T, NP>(w0, xn[ks], a0); a1 = mma<T, NP>(w1, xn[ks + 1], a1); }
+            else { a0 = mma<T, NP>(xn[ks], w0, a0); a1 = mma<T, NP>(xn[ks + 1], w1, a1); }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g++) out[g] = (a0[g] + a1[g]) * inv_scale;
+    };
+    // register octet m (registers 8m .. 8m+7) of a tile -> one 16-byte k-slot group per plane
+    auto pack_octet = [&](const f32x16 &v, int m, u32x4 (&dst)[2]) {
+        const float v0[4] = {v[8 * m], v[8 * m + 1], v[8 * m + 2], v[8 * m + 3]};
+        const float v1[4] = {v[8 * m + 4], v[8 * m + 5], v[8 * m + 6], v[8 * m + 7]};
+        u32x2 h0, l0, h1, l1;
+        split4<T, NP>(v0, h0, l0);
+        split4<T, NP>(v1, h1, l1);
+        dst[0][0] = h0[0]; dst[0][1] = h0[1]; dst[0][2] = h1[0]; dst[0][3] = h1[1];
+        dst[1][0] = l0[0]; dst[1][1] = l0[1]; dst[1][2] = l1[0]; dst[1][3] = l1[1];
+    };
+    // barrier that also publishes this wave's LDS writes / retires its DMA pieces
+    auto ring_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+#pragma unroll 1
+    for (int hd = 0; hd < n_head; hd++) {
+        const int sq0 = 3 * hd;
+        f32x16 tile;
+        u32x4 qf[2][2];                                                   // B operand of S^T = K Q^T: [k-step][plane]
+        // ---- q ----
+        issue(sq0 + 1);
+        project(sq0, true, tile);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) pack_octet(tile, ks, qf[ks]);
+        ring_sync();
+        // ---- k -> sK[pl][key = tok0 + r][octet ks][half h] ----
+        issue(sq0 + 2);
+        project(sq0 + 1, true, tile);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            u32x4 kp[2];
+            pack_octet(tile, ks, kp);
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++)
+                *reinterpret_cast<u32x4 *>(sK + (size_t)pl * kT * KROW + (tok0 + r) * KROW + ks * 32 + h * 16) = kp[pl];
+        }
+        ring_sync();
+        // ---- v (natural: lane = d, registers = tokens) -> sV[pl][d = r][(wave, octet mm)][half h] ----
+        if (sq0 + 3 < n_seq) issue(sq0 + 3);
+        project(sq0 + 2, false, tile);
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++) {
+            u32x4 vp[2];
+            pack_octet(tile, mm, vp);
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++)
+                *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VROW + r * VROW + (wave * 2 + mm) * 32 + h * 16) = vp[pl];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // K and V^T of this head complete (next packet may still fly)
+
+        // ---- attention of this wave's 32 queries against the 256 keys of the head ----
+        f32x16 o;
+#pragma unroll
+        for (int g = 0; g < 16; g++) o[g] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < kT / 32; kt++) {
+            f32x16 sc;
+#pragma unroll
+            for (int g = 0; g < 16; g++) sc[g] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                u32x4 kf[2];
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    kf[pl] = *reinterpret_cast<const u32x4 *>(sK + (size_t)pl * kT * KROW + (kt * 32 + r) * KROW + ks * 32 + h * 16);
+                sc = mma<T, NP>(kf, qf[ks], sc);
+            }
+            // sc[g] = S[query r][key 32 kt + tau(g, h)]
+            float mx = sc[0];
+#pragma unroll
+            for (int g = 1; g < 16; g++) mx = fmaxf(mx, sc[g]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            float psum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                sc[g] = __builtin_amdgcn_exp2f((sc[g] - m_new) * scale_log2e);
+                psum += sc[g];
+            }
+            psum += __shfl_xor(psum, 32);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int g = 0; g < 16; g++) o[g] *= alpha;
+#pragma unroll
+            for (int mm = 0; mm < 2; mm++) {
+                u32x4 pf[2], vf[2];
+                pack_octet(sc, mm, pf);
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    vf[pl] = *reinterpret_cast<const u32x4 *>(sV + (size_t)pl * HS * VROW + r * VROW + (kt * 2 + mm) * 32 + h * 16);
+                o = mma<T, NP>(vf, pf, o);
+            }
+        }
+        const float inv = 1.0f / l_run;
+        // o[g] = O[query r][d = tau(g, h)] -> y planes [b*256 + tok0 + r][hd*32 + d]
+        const size_t yrow = ((size_t)b * kT + tok0 + r) * C + hd * HS;
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const float v[4] = {o[4 * gq] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv};
+            u32x2 hi, lo;
+            split4<T, NP>(v, hi, lo);
+            *reinterpret_cast<u32x2 *>(y_hi + yrow + 8 * gq + 4 * h) = hi;
+            if (NP == 2) *reinterpret_cast<u32x2 *>(y_lo + yrow + 8 * gq + 4 * h) = lo;
+        }
+        ring_sync();       // everyone is done with this head's K / V^T (and the next head's q packet has landed)
+    }
+}
+
 }  // namespace fastk
 }  // namespace mgpt
