@@ -40,6 +40,8 @@ struct ModeState {          // one precision mode
     // register-resident LN+QKV (C = 64 / 160): per layer [tile][k-step][plane][lane][8] of c_attn.weight
     std::vector<uint16_t *> qkv_pk;
     bool qkv_fused = false;
+    // out-projection slices per head for attn_block_kernel<PROJ>: [head][out tile][kk][plane][lane][8]
+    std::vector<uint16_t *> proj_pk;
 };
 
 struct FastState {
@@ -118,6 +120,17 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                nullptr, g->params + g->layers[l].attn_w, m->qkv_pk[l], (int)ntile, (int)C, 1.0f / m->attn[l].inv_scale);
             MGPT_LAUNCH_CHECK();
         }
+        if (g->hs == 32) {
+            const size_t ct = C / 32;
+            m->proj_pk.assign(g->L, nullptr);
+            for (int l = 0; l < g->L; l++) {
+                MGPT_HIP(hipMalloc(&m->proj_pk[l], (size_t)g->nh * 2 * ct * NP * 512 * sizeof(uint16_t)));
+                ProfScope ps(P_PACK, nullptr);
+                hipLaunchKernelGGL((fastk::pack_cols_perm_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)(g->nh * 2 * ct * 64), 256)), dim3(256), 0,
+                                   nullptr, g->params + g->layers[l].proj_w, m->proj_pk[l], g->nh, (int)C, (int)C, 1.0f / m->proj[l].inv_scale);
+                MGPT_LAUNCH_CHECK();
+            }
+        }
     }
     const size_t M = (size_t)g->max_rows * kT;
     MGPT_HIP(hipMalloc(&m->stats, M * sizeof(float2)));
@@ -138,6 +151,7 @@ void free_mode(ModeState *m)
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
     for (auto *p : m->mlp_pk) (void)hipFree(p);
     for (auto *p : m->qkv_pk) (void)hipFree(p);
+    for (auto *p : m->proj_pk) (void)hipFree(p);
     (void)hipFree(m->stats);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
@@ -208,21 +222,27 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         a.N = 2 * C; a.o_hi = m->qk[0]; a.o_lo = m->qk[1];
         static const bool no_attn_block = getenv("MGPT_NO_ATTN_BLOCK") != nullptr;
         const bool attn_block = m->qkv_fused && g->hs == 32 && !no_attn_block;
+        static const bool no_proj_fuse = getenv("MGPT_NO_PROJ_FUSE") != nullptr;
+        const bool proj_fused = attn_block && !no_proj_fuse;
         if (attn_block) {
-            // ---- LN1 + QKV + attention in one kernel (q, k, v stay on chip) ----
+            // ---- LN1 + QKV + attention (+ out-projection + residual) in one kernel: q, k, v (, y) stay on chip ----
             ProfScope ps(P_ATTN, s);
             const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 2;
-            if (C == 160) {
-                static bool once160 = false;
-                if (!once160) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once160 = true; }
-                hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, 5>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, m->qkv_pk[l],
-                                   m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e);
-            } else {
-                static bool once64 = false;
-                if (!once64) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once64 = true; }
-                hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, 2>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, m->qkv_pk[l],
-                                   m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e);
-            }
+#define MGPT_ATTN_BLOCK(CT_, PROJ_)                                                                                              \
+    {                                                                                                                            \
+        static bool once = false;                                                                                                \
+        if (!once) {                                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, CT_, PROJ_>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+            once = true;                                                                                                         \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, PROJ_>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, \
+                           m->qkv_pk[l], m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e, m->proj_pk[l],               \
+                           m->proj[l].inv_scale, m->stats);                                                                      \
+    }
+            if (C == 160) { if (proj_fused) MGPT_ATTN_BLOCK(5, true) else MGPT_ATTN_BLOCK(5, false) }
+            else { if (proj_fused) MGPT_ATTN_BLOCK(2, true) else MGPT_ATTN_BLOCK(2, false) }
+#undef MGPT_ATTN_BLOCK
             MGPT_LAUNCH_CHECK();
         } else if (m->qkv_fused) {
             ProfScope ps(P_LNQKV_FUSED, s);
@@ -255,7 +275,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         a.a_hi = m->y[0]; a.a_lo = m->y[1]; a.K = C; a.N = C;
         a.w_hi = m->proj[l].hi; a.w_lo = m->proj[l].lo; a.out_scale = m->proj[l].inv_scale;
         a.x_out = g->x; a.stats_out = m->stats;
-        {
+        if (!proj_fused) {
             ProfScope ps(P_GEMM_PROJ, s);
             if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }

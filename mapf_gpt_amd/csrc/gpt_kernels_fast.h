@@ -1041,6 +1041,34 @@ __global__ __launch_bounds__(512, 2) void ln_qkv_kernel(const float *__restrict_
     }
 }
 
+// out-projection weights for attn_block_kernel: [head t][out tile j][kk][plane][lane][8]; A rows = output features
+// 32 j + i, k-slots = head features 32 t + tau(8 kk + e, h)  (w is [C_out][K_total] row-major)
+template <class T, int NP>
+__global__ __launch_bounds__(256) void pack_cols_perm_kernel(const float *__restrict__ w, uint16_t *__restrict__ out,
+                                                             int n_ktiles, int C_out, int K_total, float scale)
+{
+    const int CT = C_out / 32;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)n_ktiles * CT * 2 * 64) return;
+    const int lane = (int)(gid & 63), f = (int)((gid >> 6) % (2 * CT)), t = (int)((gid >> 6) / (2 * CT));
+    const int j = f >> 1, kk = f & 1, i = lane & 31, h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int g = 8 * kk + e;
+        v[e] = w[(size_t)(32 * j + i) * K_total + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h] * scale;
+    }
+    u32x2 h0, l0, h1, l1;
+    split4<T, NP>(v, h0, l0);
+    split4<T, NP>(v + 4, h1, l1);
+    u32x4 hi, lo;
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+    uint16_t *dst = out + (((size_t)t * 2 * CT + f) * NP) * 512 + (size_t)lane * 8;
+    *reinterpret_cast<u32x4 *>(dst) = hi;
+    if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused attention block front half: LayerNorm + QKV projection + non-causal attention for ONE row per
 // workgroup (8 waves x 32 tokens), heads visited one after the other; q, k, v never touch HBM.
@@ -1053,11 +1081,15 @@ __global__ __launch_bounds__(512, 2) void ln_qkv_kernel(const float *__restrict_
 // tile), so register octets [8m, 8m+8) are directly MFMA k-slot groups everywhere, and the LDS images are written
 // and read with the same (row, octet, half) address.
 // ---------------------------------------------------------------------------------------------
-template <class T, int NP, int CT>
-__global__ __launch_bounds__(512, 2) void attn_block_kernel(const float *__restrict__ x, const float *__restrict__ gain,
+// PROJ: also apply the output projection per head (c_proj fragments are the 4th packet of every head) and the
+// residual add: x <- x + c_proj(attention), LayerNorm statistics of the new row to stats_out; y planes unused.
+template <class T, int NP, int CT, bool PROJ>
+__global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                              const uint16_t *__restrict__ wpk, float inv_scale,
                                                              uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo,
-                                                             int n_head, float scale_log2e)
+                                                             int n_head, float scale_log2e,
+                                                             const uint16_t *__restrict__ ppk, float inv_scale_p,
+                                                             float2 *__restrict__ stats_out)
 {
     constexpr int C = CT * 32, KS = C / 16, NW = 8, HS = 32;
     constexpr int F = KS * NP, PKT = F * 1024, PER_WAVE = (F + NW - 1) / NW;
@@ -1070,17 +1102,22 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(const float *__restr
     const int r = lane & 31, h = lane >> 5;
     const int64_t b = blockIdx.x;
     const int tok0 = wave * 32;
-    const float *xrow = x + (b * kT + tok0 + r) * C;
+    float *xrow = x + (b * kT + tok0 + r) * C;
     const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(wpk);
-    const int n_seq = 3 * n_head;                                         // (head, which) packets in visiting order
+    const unsigned char *psrc = reinterpret_cast<const unsigned char *>(ppk);
+    constexpr int PH = PROJ ? 4 : 3;                                      // packets per head: q, k, v (, c_proj slice)
+    const int n_seq = PH * n_head;                                        // packets in visiting order
+    static_assert(2 * CT * NP == F, "c_proj slice packet has the same size as a c_attn tile packet");
 
-    auto issue = [&](int sq) {                                            // packet sq = (head sq/3, which sq%3) -> sW[sq & 1]
-        const int tile = (sq % 3) * CT + sq / 3;                          // hs == 32: one tile per (which, head)
+    auto issue = [&](int sq) {                                            // packet sq = (head sq/PH, which sq%PH) -> sW[sq & 1]
+        const int which = sq % PH, hd_ = sq / PH;
+        const unsigned char *src = (which < 3) ? wsrc + (size_t)(which * CT + hd_) * PKT     // hs == 32: one tile per (which, head)
+                                               : psrc + (size_t)hd_ * PKT;
         unsigned char *dst = sW + (size_t)(sq & 1) * PKT;
 #pragma unroll
         for (int i = 0; i < PER_WAVE; i++) {
             const int c = min(wave + NW * i, F - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(wsrc + (size_t)tile * PKT + (size_t)c * 1024 + lane * 16),
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)c * 1024 + lane * 16),
                                              (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
         }
     };
@@ -1166,9 +1203,15 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(const float *__restr
         __builtin_amdgcn_s_barrier();
     };
 
+    f32x16 pacc[PROJ ? CT : 1];                                            // c_proj output accumulators (swapped layout)
+#pragma unroll
+    for (int j = 0; j < (PROJ ? CT : 1); j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) pacc[j][g] = 0.f;
+
 #pragma unroll 1
     for (int hd = 0; hd < n_head; hd++) {
-        const int sq0 = 3 * hd;
+        const int sq0 = PH * hd;
         f32x16 tile;
         u32x4 qf[2][2];                                                   // B operand of S^T = K Q^T: [k-step][plane]
         // ---- q ----
@@ -1250,17 +1293,65 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(const float *__restr
             }
         }
         const float inv = 1.0f / l_run;
-        // o[g] = O[query r][d = tau(g, h)] -> y planes [b*256 + tok0 + r][hd*32 + d]
-        const size_t yrow = ((size_t)b * kT + tok0 + r) * C + hd * HS;
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            const float v[4] = {o[4 * gq] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv};
-            u32x2 hi, lo;
-            split4<T, NP>(v, hi, lo);
-            *reinterpret_cast<u32x2 *>(y_hi + yrow + 8 * gq + 4 * h) = hi;
-            if (NP == 2) *reinterpret_cast<u32x2 *>(y_lo + yrow + 8 * gq + 4 * h) = lo;
+        for (int g = 0; g < 16; g++) o[g] *= inv;
+        // o[g] = O[query r][d = tau(g, h)]
+        if (!PROJ) {                                                      // -> y planes [b*256 + tok0 + r][hd*32 + d]
+            const size_t yrow = ((size_t)b * kT + tok0 + r) * C + hd * HS;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const float v[4] = {o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]};
+                u32x2 hi, lo;
+                split4<T, NP>(v, hi, lo);
+                *reinterpret_cast<u32x2 *>(y_hi + yrow + 8 * gq + 4 * h) = hi;
+                if (NP == 2) *reinterpret_cast<u32x2 *>(y_lo + yrow + 8 * gq + 4 * h) = lo;
+            }
+            ring_sync();   // everyone is done with this head's K / V^T (and the next head's q packet has landed)
+        } else {
+            // the head's output is, as it stands, the B operand of its slice of c_proj: pacc += Wp[:, head] y_head
+            ring_sync();   // the c_proj packet (issued before the attention loop) has landed; K / V^T are free again
+            if (sq0 + 4 < n_seq) issue(sq0 + 4);                          // next head's q packet -> the buffer q,v used
+            u32x4 yf[2][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) pack_octet(o, kk, yf[kk]);
+            const unsigned char *pk = sW + (size_t)((sq0 + 3) & 1) * PKT + lane * 16;
+#pragma unroll
+            for (int j = 0; j < CT; j++)
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    u32x4 wf[2];
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((2 * j + kk) * NP + pl) * 1024);
+                    pacc[j] = mma<T, NP>(wf, yf[kk], pacc[j]);
+                }
+            ring_sync();   // c_proj packet consumed by everyone; next head's q packet landed
         }
-        ring_sync();       // everyone is done with this head's K / V^T (and the next head's q packet has landed)
+    }
+    if (PROJ) {
+        // ---- residual add, store, LayerNorm statistics of the new row (as the GEMM / MLP epilogues) ----
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; j++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+                f32x4 cur = *dst;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { cur[e] += pacc[j][4 * gq + e] * inv_scale_p; pacc[j][4 * gq + e] = cur[e]; }
+                *dst = cur;
+                s2 += (cur[0] + cur[1]) + (cur[2] + cur[3]);
+            }
+        if (stats_out != nullptr) {
+            s2 += __shfl_xor(s2, 32);
+            const float mean2 = s2 / (float)C;
+            float q2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < CT; j++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) { const float d = pacc[j][g] - mean2; q2 += d * d; }
+            q2 += __shfl_xor(q2, 32);
+            if (h == 0) stats_out[b * kT + tok0 + r] = make_float2(mean2, rsqrtf(q2 / (float)C + 1e-5f));
+        }
     }
 }
 
