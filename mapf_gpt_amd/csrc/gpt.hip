@@ -165,13 +165,19 @@ extern "C" int mgpt_gpt_finalize(mgpt_gpt *g)
     return MGPT_OK;
 }
 
-int gpt_launch_head(mgpt_gpt *g, int rows, float *d_logits, hipStream_t s)
+int gpt_launch_head_at(mgpt_gpt *g, const float *xsrc, int64_t row_stride, int64_t row_offset, int rows, float *d_logits,
+                       hipStream_t s)
 {
     ProfScope ps(P_HEAD, s);
-    hipLaunchKernelGGL(f32k::head_kernel, dim3(rows), dim3(64), (size_t)g->C * sizeof(float), s, g->x, g->params + g->off_lnf,
-                       g->params + g->off_wte, d_logits, g->C, kV);
+    hipLaunchKernelGGL(f32k::head_kernel, dim3(rows), dim3(64), (size_t)g->C * sizeof(float), s, xsrc, g->params + g->off_lnf,
+                       g->params + g->off_wte, d_logits, g->C, kV, row_stride, row_offset);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
+}
+
+int gpt_launch_head(mgpt_gpt *g, int rows, float *d_logits, hipStream_t s)
+{
+    return gpt_launch_head_at(g, g->x, (int64_t)kT * g->C, (int64_t)(kT - 1) * g->C, rows, d_logits, s);
 }
 
 // ----- fp32 forward -----

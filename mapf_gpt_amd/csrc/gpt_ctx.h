@@ -32,3 +32,5 @@ int gpt_fast_debug_copy(mgpt_gpt *g, int precision, int which, void *d_out, int6
 
 // gpt.hip: final LayerNorm + tied lm_head on the last position of g->x (shared by both paths)
 int gpt_launch_head(mgpt_gpt *g, int rows, float *d_logits, hipStream_t s);
+int gpt_launch_head_at(mgpt_gpt *g, const float *xsrc, int64_t row_stride, int64_t row_offset, int rows, float *d_logits,
+                       hipStream_t s);

@@ -42,6 +42,8 @@ struct ModeState {          // one precision mode
     bool qkv_fused = false;
     // out-projection slices per head for attn_block_kernel<PROJ>: [head][out tile][kk][plane][lane][8]
     std::vector<uint16_t *> proj_pk;
+    // last-layer shortcut: new residual rows of token 255 only, [round_up(max_rows, 256)][C] fp32
+    float *x_last = nullptr;
 };
 
 struct FastState {
@@ -132,6 +134,11 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             }
         }
     }
+    {
+        const size_t nl = (size_t)((g->max_rows + 255) / 256) * 256 * C;
+        MGPT_HIP(hipMalloc(&m->x_last, nl * sizeof(float)));
+        MGPT_HIP(hipMemset(m->x_last, 0, nl * sizeof(float)));           // padding rows stay finite
+    }
     const size_t M = (size_t)g->max_rows * kT;
     MGPT_HIP(hipMalloc(&m->stats, M * sizeof(float2)));
     for (int p = 0; p < NP; p++) {
@@ -153,6 +160,7 @@ void free_mode(ModeState *m)
     for (auto *p : m->qkv_pk) (void)hipFree(p);
     for (auto *p : m->proj_pk) (void)hipFree(p);
     (void)hipFree(m->stats);
+    (void)hipFree(m->x_last);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
 }
@@ -224,24 +232,27 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         const bool attn_block = m->qkv_fused && g->hs == 32 && !no_attn_block;
         static const bool no_proj_fuse = getenv("MGPT_NO_PROJ_FUSE") != nullptr;
         const bool proj_fused = attn_block && !no_proj_fuse;
+        // last layer: only token 255 is needed downstream (model.py:186) -> compact buffer, MLP and head on `rows` tokens
+        static const bool no_last = getenv("MGPT_NO_LAST_SHORTCUT") != nullptr;
+        const bool last_short = proj_fused && m->mlp_fused && l == g->L - 1 && !no_last;
         if (attn_block) {
             // ---- LN1 + QKV + attention (+ out-projection + residual) in one kernel: q, k, v (, y) stay on chip ----
             ProfScope ps(P_ATTN, s);
             const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 2;
-#define MGPT_ATTN_BLOCK(CT_, PROJ_)                                                                                              \
+#define MGPT_ATTN_BLOCK(CT_, PROJ_, LAST_)                                                                                       \
     {                                                                                                                            \
         static bool once = false;                                                                                                \
         if (!once) {                                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, CT_, PROJ_>),              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, CT_, PROJ_, LAST_>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
             once = true;                                                                                                         \
         }                                                                                                                        \
-        hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, PROJ_>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, \
-                           m->qkv_pk[l], m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e, m->proj_pk[l],               \
-                           m->proj[l].inv_scale, m->stats);                                                                      \
+        hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, PROJ_, LAST_>), dim3((unsigned)rows), dim3(512), lds, s, g->x,  \
+                           P + lo.ln1, m->qkv_pk[l], m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e, m->proj_pk[l],   \
+                           m->proj[l].inv_scale, m->stats, m->x_last);                                                           \
     }
-            if (C == 160) { if (proj_fused) MGPT_ATTN_BLOCK(5, true) else MGPT_ATTN_BLOCK(5, false) }
-            else { if (proj_fused) MGPT_ATTN_BLOCK(2, true) else MGPT_ATTN_BLOCK(2, false) }
+            if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, true) else if (proj_fused) MGPT_ATTN_BLOCK(5, true, false) else MGPT_ATTN_BLOCK(5, false, false) }
+            else { if (last_short) MGPT_ATTN_BLOCK(2, true, true) else if (proj_fused) MGPT_ATTN_BLOCK(2, true, false) else MGPT_ATTN_BLOCK(2, false, false) }
 #undef MGPT_ATTN_BLOCK
             MGPT_LAUNCH_CHECK();
         } else if (m->qkv_fused) {
@@ -280,6 +291,8 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
         if (!fused_stats(C) && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
+        float *mlp_x = last_short ? m->x_last : g->x;
+        const int64_t mlp_M = last_short ? (int64_t)((rows + 255) / 256) * 256 : M;
         if (m->mlp_fused) {
             // ---- whole MLP block in one kernel (hidden stays in registers) ----
             ProfScope ps(P_MLP_FUSED, s);
@@ -290,17 +303,17 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     {                                                                                                                               \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5, A_>),                           \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                            \
-        hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5, A_>), dim3((unsigned)(M / 256)), dim3(512), lds, s, g->x, P + lo.ln2, \
-                           m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)M);                              \
+        hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5, A_>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2, \
+                           m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);                              \
     }
                 if (abl == 1) MGPT_ABL_LAUNCH(1) else if (abl == 2) MGPT_ABL_LAUNCH(2) else if (abl == 3) MGPT_ABL_LAUNCH(3) else MGPT_ABL_LAUNCH(4)
 #undef MGPT_ABL_LAUNCH
             } else if (C == 160)
-                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5>), dim3((unsigned)(M / 256)), dim3(512), lds, s, g->x, P + lo.ln2,
-                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)M);
+                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
+                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
             else
-                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 2>), dim3((unsigned)(M / 256)), dim3(512), lds, s, g->x, P + lo.ln2,
-                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)M);
+                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 2>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
+                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
             MGPT_LAUNCH_CHECK();
             continue;
         }
@@ -321,6 +334,12 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
         if (!fused_stats(C) && l + 1 < g->L && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
+    }
+    {
+        static const bool no_last = getenv("MGPT_NO_LAST_SHORTCUT") != nullptr;
+        static const bool no_proj_fuse = getenv("MGPT_NO_PROJ_FUSE") != nullptr, no_attn_block = getenv("MGPT_NO_ATTN_BLOCK") != nullptr;
+        if (m->qkv_fused && g->hs == 32 && m->mlp_fused && !no_last && !no_proj_fuse && !no_attn_block)
+            return gpt_launch_head_at(g, m->x_last, (int64_t)C, 0, rows, d_logits, s);
     }
     return gpt_launch_head(g, rows, d_logits, s);
 }

@@ -295,14 +295,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float *__restrict__
 }
 
 // ----- final LayerNorm + tied lm_head on the last position only (model.py:178,186) -----
+// row i reads C floats at x + i * row_stride + row_offset  (full residual stream: stride 256*C, offset 255*C;
+// compact last-token buffer: stride C, offset 0)
 __global__ __launch_bounds__(64) void head_kernel(const float *__restrict__ x, const float *__restrict__ lnf,
                                                   const float *__restrict__ wte, float *__restrict__ logits, int C,
-                                                  int V)
+                                                  int V, int64_t row_stride, int64_t row_offset)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xn = reinterpret_cast<float *>(smem);
     const int row = blockIdx.x, lane = threadIdx.x;
-    const float *px = x + ((size_t)row * kT + (kT - 1)) * C;
+    const float *px = x + (int64_t)row * row_stride + row_offset;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += px[c];
 #pragma unroll

@@ -1083,14 +1083,18 @@ __global__ __launch_bounds__(256) void pack_cols_perm_kernel(const float *__rest
 // ---------------------------------------------------------------------------------------------
 // PROJ: also apply the output projection per head (c_proj fragments are the 4th packet of every head) and the
 // residual add: x <- x + c_proj(attention), LayerNorm statistics of the new row to stats_out; y planes unused.
-template <class T, int NP, int CT, bool PROJ>
+// LAST (needs PROJ): last layer -- only position 255 feeds ln_f and the head (model.py:186), so only K and V are
+// needed for all tokens; q, the attention, c_proj and the residual run for the wave that owns token 255 only, and
+// the new row of token 255 goes to the compact buffer x_last[row][C] (the MLP and the head then run on that).
+template <class T, int NP, int CT, bool PROJ, bool LAST = false>
 __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                              const uint16_t *__restrict__ wpk, float inv_scale,
                                                              uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo,
                                                              int n_head, float scale_log2e,
                                                              const uint16_t *__restrict__ ppk, float inv_scale_p,
-                                                             float2 *__restrict__ stats_out)
+                                                             float2 *__restrict__ stats_out, float *__restrict__ x_last)
 {
+    static_assert(!LAST || PROJ, "LAST implies PROJ");
     constexpr int C = CT * 32, KS = C / 16, NW = 8, HS = 32;
     constexpr int F = KS * NP, PKT = F * 1024, PER_WAVE = (F + NW - 1) / NW;
     constexpr int KROW = 80, VROW = 528;                                  // padded LDS rows (bytes): conflict-free b128 reads
@@ -1108,6 +1112,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
     constexpr int PH = PROJ ? 4 : 3;                                      // packets per head: q, k, v (, c_proj slice)
     const int n_seq = PH * n_head;                                        // packets in visiting order
     static_assert(2 * CT * NP == F, "c_proj slice packet has the same size as a c_attn tile packet");
+    const bool full = !LAST || wave == NW - 1;                            // wave-uniform: does this wave run q / attention / c_proj?
 
     auto issue = [&](int sq) {                                            // packet sq = (head sq/PH, which sq%PH) -> sW[sq & 1]
         const int which = sq % PH, hd_ = sq / PH;
@@ -1216,9 +1221,11 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
         u32x4 qf[2][2];                                                   // B operand of S^T = K Q^T: [k-step][plane]
         // ---- q ----
         issue(sq0 + 1);
-        project(sq0, true, tile);
+        if (full) {
+            project(sq0, true, tile);
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) pack_octet(tile, ks, qf[ks]);
+            for (int ks = 0; ks < 2; ks++) pack_octet(tile, ks, qf[ks]);
+        }
         ring_sync();
         // ---- k -> sK[pl][key = tok0 + r][octet ks][half h] ----
         issue(sq0 + 2);
@@ -1252,7 +1259,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
         for (int g = 0; g < 16; g++) o[g] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
 #pragma unroll 1
-        for (int kt = 0; kt < kT / 32; kt++) {
+        for (int kt = 0; kt < (full ? kT / 32 : 0); kt++) {
             f32x16 sc;
 #pragma unroll
             for (int g = 0; g < 16; g++) sc[g] = 0.f;
@@ -1292,7 +1299,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
                 o = mma<T, NP>(vf, pf, o);
             }
         }
-        const float inv = 1.0f / l_run;
+        const float inv = full ? 1.0f / l_run : 0.f;
 #pragma unroll
         for (int g = 0; g < 16; g++) o[g] *= inv;
         // o[g] = O[query r][d = tau(g, h)]
@@ -1315,33 +1322,37 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) pack_octet(o, kk, yf[kk]);
             const unsigned char *pk = sW + (size_t)((sq0 + 3) & 1) * PKT + lane * 16;
+            if (full) {
 #pragma unroll
-            for (int j = 0; j < CT; j++)
+                for (int j = 0; j < CT; j++)
 #pragma unroll
-                for (int kk = 0; kk < 2; kk++) {
-                    u32x4 wf[2];
+                    for (int kk = 0; kk < 2; kk++) {
+                        u32x4 wf[2];
 #pragma unroll
-                    for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((2 * j + kk) * NP + pl) * 1024);
-                    pacc[j] = mma<T, NP>(wf, yf[kk], pacc[j]);
-                }
+                        for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((2 * j + kk) * NP + pl) * 1024);
+                        pacc[j] = mma<T, NP>(wf, yf[kk], pacc[j]);
+                    }
+            }
             ring_sync();   // c_proj packet consumed by everyone; next head's q packet landed
         }
     }
-    if (PROJ) {
+    if (PROJ && full) {
         // ---- residual add, store, LayerNorm statistics of the new row (as the GEMM / MLP epilogues) ----
+        // LAST: only token 255 (lanes 31 and 63 of the last wave) is kept, in the compact buffer
+        const bool keep = !LAST || r == 31;
+        float *orow = LAST ? x_last + b * C : xrow;
         float s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < CT; j++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
-                f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
-                f32x4 cur = *dst;
+                f32x4 cur = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; e++) { cur[e] += pacc[j][4 * gq + e] * inv_scale_p; pacc[j][4 * gq + e] = cur[e]; }
-                *dst = cur;
+                if (keep) *reinterpret_cast<f32x4 *>(orow + 32 * j + 8 * gq + 4 * h) = cur;
                 s2 += (cur[0] + cur[1]) + (cur[2] + cur[3]);
             }
-        if (stats_out != nullptr) {
+        if (stats_out != nullptr && !LAST) {
             s2 += __shfl_xor(s2, 32);
             const float mean2 = s2 / (float)C;
             float q2 = 0.f;
