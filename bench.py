@@ -216,15 +216,26 @@ def main():
                           "gflop_per_agent_step": f_total / 1e9,
                           "mean_ISR_after_run": float(metrics[:, 1].mean().item())}}
         if prof:
-            gpt = {k: v for k, v in prof.items() if k in f_class}
-            if gpt:
-                dom = max(gpt, key=lambda k: gpt[k][0])
-                ms, n = gpt[dom]
-                launches_rows = rows / max(1, -(-rows // chunk))        # rows per launch (forward is chunked)
-                ach = f_class[dom] * launches_rows / (ms / n * 1e-3) / 1e12
+            # algorithmic (reference-executed) flops per step of every kernel class that actually ran; fused classes
+            # carry the flops of everything they absorbed (LN+QKV and the out-projection live in "gpt_attention" when
+            # their own classes are absent).  The last-layer shortcut is OUR saving: flops stay the reference's.
+            L_ = margs["n_layer"]
+            cls = {k: f_class[k] * L_ * rows for k in f_class if k in prof}
+            if "gpt_attention" in prof:
+                if "gpt_gemm_qkv" not in prof and "gpt_ln_qkv_fused" not in prof:
+                    cls["gpt_attention"] += f_class["gpt_gemm_qkv"] * L_ * rows
+                if "gpt_gemm_attn_proj" not in prof:
+                    cls["gpt_attention"] += f_class["gpt_gemm_attn_proj"] * L_ * rows
+            if cls:
+                dom = max(cls, key=lambda k: prof[k][0])
+                ms, n = prof[dom]
+                ach = cls[dom] * a.steps / (ms * 1e-3) / 1e12
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[a.precision],
                                    "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.precision], "traffic": None,
-                                   "avg_launch_ms": ms / n, "launches": n}
+                                   "avg_launch_ms": ms / n, "launches": n,
+                                   "algorithmic_gflop_per_launch": cls[dom] * a.steps / n / 1e9,
+                                   "note": "algorithmic flops (reference-executed) / HIP-event time of the class over the timed region"
+                                           + ("; f16x3 issues 3 fp16 MFMAs per product, peak is the fp16 dense rate" if a.precision == "f16x3" else "")}
             if "tok_generate_observations" in prof:
                 ms, n = prof["tok_generate_observations"]
                 ach = TOKENIZER_BYTES_PER_ROW * rows / (ms / n * 1e-3) / 1e9
