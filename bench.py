@@ -230,8 +230,15 @@ def main():
                 dom = max(cls, key=lambda k: prof[k][0])
                 ms, n = prof[dom]
                 ach = cls[dom] * a.steps / (ms * 1e-3) / 1e12
+                traffic = None      # HBM bytes per launch from the committed PMC passes (same workload), if this is that workload
+                tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+                if a.workload == "cfg2" and a.precision == "f16x3" and os.path.exists(tf):
+                    t = json.load(open(tf)).get(dom)
+                    if t:
+                        traffic = {"hbm_bytes_per_launch": t["fetch_corrected_x2"] + t["write"], "fetch_raw": t["fetch_raw"],
+                                   "write": t["write"], "source": "profiles/r01_hbm_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 gfx950 correction)"}
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[a.precision],
-                                   "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.precision], "traffic": None,
+                                   "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.precision], "traffic": traffic,
                                    "avg_launch_ms": ms / n, "launches": n,
                                    "algorithmic_gflop_per_launch": cls[dom] * a.steps / n / 1e9,
                                    "note": "algorithmic flops (reference-executed) / HIP-event time of the class over the timed region"
