@@ -145,10 +145,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MGPT_BENCH_BACKEND=gloo + MGPT_BENCH_SHARE_GPU=1: control-flow test of the N>1 path on a one-GPU box
+    # (all ranks on cuda:0, collectives on CPU tensors); the real runs use RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("MGPT_BENCH_BACKEND", "nccl")
+    if os.environ.get("MGPT_BENCH_SHARE_GPU"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
 
@@ -197,10 +206,10 @@ def main():
         _lib.prof_enable(False)
         prof = _lib.prof_read()
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    metrics = gather_metrics(run.metrics(), n_total, rank, world)       # the job's one collective
+    metrics = gather_metrics(run.metrics().to(coll_dev), n_total, rank, world)       # the job's one collective
     torch.cuda.synchronize()
 
     if rank == 0:
