@@ -238,7 +238,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         if (attn_block) {
             // ---- LN1 + QKV + attention (+ out-projection + residual) in one kernel: q, k, v (, y) stay on chip ----
             ProfScope ps(P_ATTN, s);
-            const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 2;
+            const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 4;   // K, V^T planes + 4 weight packet slots
 #define MGPT_ATTN_BLOCK(CT_, PROJ_, LAST_)                                                                                       \
     {                                                                                                                            \
         static bool once = false;                                                                                                \

@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sK = smem;                                             // [NP][256][KROW]
     unsigned char *sV = sK + NP * kT * KROW;                              // [NP][32][VROW]
-    unsigned char *sW = sV + NP * HS * VROW;                              // [2][PKT]
+    unsigned char *sW = sV + NP * HS * VROW;                              // [4][PKT]: q, k, v packets of the head, c_proj slice
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t b = blockIdx.x;
@@ -1109,16 +1109,15 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
     float *xrow = x + (b * kT + tok0 + r) * C;
     const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(wpk);
     const unsigned char *psrc = reinterpret_cast<const unsigned char *>(ppk);
-    constexpr int PH = PROJ ? 4 : 3;                                      // packets per head: q, k, v (, c_proj slice)
-    const int n_seq = PH * n_head;                                        // packets in visiting order
     static_assert(2 * CT * NP == F, "c_proj slice packet has the same size as a c_attn tile packet");
     const bool full = !LAST || wave == NW - 1;                            // wave-uniform: does this wave run q / attention / c_proj?
 
-    auto issue = [&](int sq) {                                            // packet sq = (head sq/PH, which sq%PH) -> sW[sq & 1]
-        const int which = sq % PH, hd_ = sq / PH;
-        const unsigned char *src = (which < 3) ? wsrc + (size_t)(which * CT + hd_) * PKT     // hs == 32: one tile per (which, head)
-                                               : psrc + (size_t)hd_ * PKT;
-        unsigned char *dst = sW + (size_t)(sq & 1) * PKT;
+    // Two barriers per head:
+    //   A(hd): q|k|v packets of head hd landed (issued right after B(hd-1)), K/V^T and the c_proj slot are free
+    //          -> issue c_proj(hd); project q, k, v; publish k, v^T
+    //   B(hd): k, v^T of the head complete, c_proj(hd) landed, q|k|v slots free -> issue q|k|v(hd+1); attention; c_proj
+    auto dma = [&](const unsigned char *src, int slot_) {
+        unsigned char *dst = sW + (size_t)slot_ * PKT;
 #pragma unroll
         for (int i = 0; i < PER_WAVE; i++) {
             const int c = min(wave + NW * i, F - 1);
@@ -1126,7 +1125,11 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
                                              (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
         }
     };
-    issue(0);
+    auto issue_qkv = [&](int hd_) {                                       // hs == 32: one tile per (which, head)
+#pragma unroll
+        for (int which = 0; which < 3; which++) dma(wsrc + (size_t)(which * CT + hd_) * PKT, which);
+    };
+    issue_qkv(0);
 
     // ---- LayerNorm of this lane's token, operand planes in registers (as ln_qkv_kernel) ----
     u32x4 xn[KS][2];
@@ -1168,12 +1171,12 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
             xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 
-    // one projection tile from the packet in sW[sq & 1]; SWAP: lane = token, registers = features (else the transpose)
-    auto project = [&](int sq, bool swapped, f32x16 &out) {
-        const unsigned char *pk = sW + (size_t)(sq & 1) * PKT + lane * 16;
+    // one projection tile from packet slot `slot_`; swapped: lane = token, registers = features (else the transpose).
+    // The result stays in the weights' power-of-two scale (1/inv_scale); the scale is folded into the softmax
+    // exponent (q, k) and into the final 1/l (v) instead of costing 16 multiplies per tile.
+    auto project = [&](int slot_, bool swapped, f32x16 &out) {
+        const unsigned char *pk = sW + (size_t)slot_ * PKT + lane * 16;
         f32x16 a0, a1;
 #pragma unroll
         for (int g = 0; g < 16; g++) { a0[g] = 0.f; a1[g] = 0.f; }
@@ -1189,7 +1192,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
             else { a0 = mma<T, NP>(xn[ks], w0, a0); a1 = mma<T, NP>(xn[ks + 1], w1, a1); }
         }
 #pragma unroll
-        for (int g = 0; g < 16; g++) out[g] = (a0[g] + a1[g]) * inv_scale;
+        for (int g = 0; g < 16; g++) out[g] = a0[g] + a1[g];
     };
     // register octet m (registers 8m .. 8m+7) of a tile -> one 16-byte k-slot group per plane
     auto pack_octet = [&](const f32x16 &v, int m, u32x4 (&dst)[2]) {
@@ -1201,8 +1204,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
         dst[0][0] = h0[0]; dst[0][1] = h0[1]; dst[0][2] = h1[0]; dst[0][3] = h1[1];
         dst[1][0] = l0[0]; dst[1][1] = l0[1]; dst[1][2] = l1[0]; dst[1][3] = l1[1];
     };
-    // barrier that also publishes this wave's LDS writes / retires its DMA pieces
-    auto ring_sync = [&]() {
+    auto sync_all = [&]() {                                                // this wave's DMA pieces landed + LDS writes visible, then barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1213,23 +1215,21 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
     for (int j = 0; j < (PROJ ? CT : 1); j++)
 #pragma unroll
         for (int g = 0; g < 16; g++) pacc[j][g] = 0.f;
+    const float sc2 = scale_log2e * inv_scale * inv_scale;                // softmax exponent scale for q.k in weight-scaled units
 
+    sync_all();                                                            // A(0)
 #pragma unroll 1
     for (int hd = 0; hd < n_head; hd++) {
-        const int sq0 = PH * hd;
+        if (PROJ) dma(psrc + (size_t)hd * PKT, 3);                         // c_proj slice of this head (needed after the attention)
         f32x16 tile;
         u32x4 qf[2][2];                                                   // B operand of S^T = K Q^T: [k-step][plane]
-        // ---- q ----
-        issue(sq0 + 1);
         if (full) {
-            project(sq0, true, tile);
+            project(0, true, tile);
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) pack_octet(tile, ks, qf[ks]);
         }
-        ring_sync();
         // ---- k -> sK[pl][key = tok0 + r][octet ks][half h] ----
-        issue(sq0 + 2);
-        project(sq0 + 1, true, tile);
+        project(1, true, tile);
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             u32x4 kp[2];
@@ -1238,10 +1238,8 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
             for (int pl = 0; pl < NP; pl++)
                 *reinterpret_cast<u32x4 *>(sK + (size_t)pl * kT * KROW + (tok0 + r) * KROW + ks * 32 + h * 16) = kp[pl];
         }
-        ring_sync();
         // ---- v (natural: lane = d, registers = tokens) -> sV[pl][d = r][(wave, octet mm)][half h] ----
-        if (sq0 + 3 < n_seq) issue(sq0 + 3);
-        project(sq0 + 2, false, tile);
+        project(2, false, tile);
 #pragma unroll
         for (int mm = 0; mm < 2; mm++) {
             u32x4 vp[2];
@@ -1250,8 +1248,8 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
             for (int pl = 0; pl < NP; pl++)
                 *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VROW + r * VROW + (wave * 2 + mm) * 32 + h * 16) = vp[pl];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                     // K and V^T of this head complete (next packet may still fly)
+        sync_all();                                                        // B(hd)
+        if (hd + 1 < n_head) issue_qkv(hd + 1);                            // flies during the attention below
 
         // ---- attention of this wave's 32 queries against the 256 keys of the head ----
         f32x16 o;
@@ -1271,24 +1269,28 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
                     kf[pl] = *reinterpret_cast<const u32x4 *>(sK + (size_t)pl * kT * KROW + (kt * 32 + r) * KROW + ks * 32 + h * 16);
                 sc = mma<T, NP>(kf, qf[ks], sc);
             }
-            // sc[g] = S[query r][key 32 kt + tau(g, h)]
+            // sc[g] = S[query r][key 32 kt + tau(g, h)]  (times 1/inv_scale^2)
             float mx = sc[0];
 #pragma unroll
             for (int g = 1; g < 16; g++) mx = fmaxf(mx, sc[g]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {            // some query's running max moved: rescale (wave-uniform branch)
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
+                l_run *= alpha;
+#pragma unroll
+                for (int g = 0; g < 16; g++) o[g] *= alpha;
+                m_run = m_new;
+            }
+            const float nm = -m_run * sc2;
             float psum = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; g++) {
-                sc[g] = __builtin_amdgcn_exp2f((sc[g] - m_new) * scale_log2e);
+                sc[g] = __builtin_amdgcn_exp2f(fmaf(sc[g], sc2, nm));
                 psum += sc[g];
             }
             psum += __shfl_xor(psum, 32);
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int g = 0; g < 16; g++) o[g] *= alpha;
+            l_run += psum;
 #pragma unroll
             for (int mm = 0; mm < 2; mm++) {
                 u32x4 pf[2], vf[2];
@@ -1299,7 +1301,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
                 o = mma<T, NP>(vf, pf, o);
             }
         }
-        const float inv = full ? 1.0f / l_run : 0.f;
+        const float inv = full ? inv_scale / l_run : 0.f;                  // 1/l and the v projection's weight scale
 #pragma unroll
         for (int g = 0; g < 16; g++) o[g] *= inv;
         // o[g] = O[query r][d = tau(g, h)]
@@ -1313,28 +1315,23 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
                 *reinterpret_cast<u32x2 *>(y_hi + yrow + 8 * gq + 4 * h) = hi;
                 if (NP == 2) *reinterpret_cast<u32x2 *>(y_lo + yrow + 8 * gq + 4 * h) = lo;
             }
-            ring_sync();   // everyone is done with this head's K / V^T (and the next head's q packet has landed)
-        } else {
+        } else if (full) {
             // the head's output is, as it stands, the B operand of its slice of c_proj: pacc += Wp[:, head] y_head
-            ring_sync();   // the c_proj packet (issued before the attention loop) has landed; K / V^T are free again
-            if (sq0 + 4 < n_seq) issue(sq0 + 4);                          // next head's q packet -> the buffer q,v used
             u32x4 yf[2][2];
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) pack_octet(o, kk, yf[kk]);
-            const unsigned char *pk = sW + (size_t)((sq0 + 3) & 1) * PKT + lane * 16;
-            if (full) {
+            const unsigned char *pk = sW + (size_t)3 * PKT + lane * 16;
 #pragma unroll
-                for (int j = 0; j < CT; j++)
+            for (int j = 0; j < CT; j++)
 #pragma unroll
-                    for (int kk = 0; kk < 2; kk++) {
-                        u32x4 wf[2];
+                for (int kk = 0; kk < 2; kk++) {
+                    u32x4 wf[2];
 #pragma unroll
-                        for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((2 * j + kk) * NP + pl) * 1024);
-                        pacc[j] = mma<T, NP>(wf, yf[kk], pacc[j]);
-                    }
-            }
-            ring_sync();   // c_proj packet consumed by everyone; next head's q packet landed
+                    for (int pl = 0; pl < NP; pl++) wf[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((2 * j + kk) * NP + pl) * 1024);
+                    pacc[j] = mma<T, NP>(wf, yf[kk], pacc[j]);
+                }
         }
+        sync_all();                                                        // A(hd+1)
     }
     if (PROJ && full) {
         // ---- residual add, store, LayerNorm statistics of the new row (as the GEMM / MLP epilogues) ----
