@@ -93,7 +93,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             if ((rc = pack_matrix<T, NP>(g->params + mt.off, mt.n, sc, mt.dst, nullptr)) != MGPT_OK) return rc;
         }
     }
-    m->mlp_fused = (C == 160 || C == 64) && getenv("MGPT_NO_FUSED_MLP") == nullptr;
+    m->mlp_fused = (C == 160 || C == 64 || C == 256) && getenv("MGPT_NO_FUSED_MLP") == nullptr;
     if (m->mlp_fused) {
         const size_t frags = C / 16 + 2 * (C / 32), nt = 4 * C / 32;
         const size_t n16 = nt * frags * NP * 512;
@@ -107,8 +107,9 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                1.0f / m->fc[l].inv_scale, 1.0f / m->proj2[l].inv_scale);
             MGPT_LAUNCH_CHECK();
         }
-        const int pkt = (int)(frags * NP * 1024 * 3);
-        if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
+        const int pkt = (int)(frags * NP * 1024 * (C == 256 ? 2 : 3));
+        if (C == 256) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
+        else if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
         else MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
     }
     m->qkv_fused = (C == 160 || C == 64) && getenv("MGPT_NO_FUSED_QKV") == nullptr;
@@ -296,7 +297,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         if (m->mlp_fused) {
             // ---- whole MLP block in one kernel (hidden stays in registers) ----
             ProfScope ps(P_MLP_FUSED, s);
-            const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 3;
+            const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * (C == 256 ? 2 : 3);
             static const int abl = getenv("MGPT_MLP_ABL") ? atoi(getenv("MGPT_MLP_ABL")) : 0;   // timing experiments only
             if (C == 160 && NP == 2 && abl != 0) {
 #define MGPT_ABL_LAUNCH(A_)                                                                                                         \
@@ -308,7 +309,10 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     }
                 if (abl == 1) MGPT_ABL_LAUNCH(1) else if (abl == 2) MGPT_ABL_LAUNCH(2) else if (abl == 3) MGPT_ABL_LAUNCH(3) else MGPT_ABL_LAUNCH(4)
 #undef MGPT_ABL_LAUNCH
-            } else if (C == 160)
+            } else if (C == 256)
+                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1>), dim3((unsigned)(mlp_M / 128)), dim3(256), lds, s, mlp_x, P + lo.ln2,
+                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)mlp_M);
+            else if (C == 160)
                 hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
                                    m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
             else

@@ -655,8 +655,9 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 // ABL: timing ablations for tools/ (results are WRONG unless ABL == 0): 1 no GELU, 2 no weight streaming,
 //      3 no c_proj MFMAs, 4 no c_fc MFMAs
-template <class T, int NP, int CT, int ABL = 0, int NW = 8, int NBUF = 3>
-__global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict__ x, const float *__restrict__ gain,
+// C = 256 (6M) instantiates NW = 4, NBUF = 2, MINW = 1: the row block needs ~330 registers, i.e. one wave per SIMD.
+template <class T, int NP, int CT, int ABL = 0, int NW = 8, int NBUF = 3, int MINW = 2>
+__global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                             const uint16_t *__restrict__ wpk, float inv1, float inv2,
                                                             float2 *__restrict__ stats_out, int M)
 {
