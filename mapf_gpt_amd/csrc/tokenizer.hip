@@ -3,13 +3,16 @@
 // State is a structure-of-arrays over (instance, agent) resident in HBM:
 //   grids   uint8  [n_grids, H, W]            obstacle maps (instance i uses map i % n_grids)
 //   dist    uint16 [n_inst, n_agents, H, W]   4-connected BFS distance-to-goal fields (65535 = wall/unreached)
+//   dist8   uint8  [n_inst, n_agents, H, W]   the same fields in one byte (255 = wall/unreached), valid while every
+//                                             finite distance is <= 253 (device flag `u8_ok`); halves the window traffic
 //   recs    16 B   [n_inst, n_agents]         {pos, goal, 5 history tokens, greedy-bits token}
 // Kernels (all integer, bit-exact against the reference):
 //   bfs_kernel        one 256-thread workgroup per agent, monotone relaxation in LDS    (cpp:200-286)
 //   create/update     one thread per agent                                              (cpp:391-410, 432-485)
-//   tokens_kernel     one wavefront per agent, 4 agents in flight per workgroup, the instance's
-//                     agent records staged in LDS, window gathered straight from the agent's own
-//                     distance field, neighbours ranked wave-parallel                    (cpp:288-311, 487-528, 352-389)
+//   tokens_kernel     one wavefront per agent row, 4 rows in flight per wavefront, the instance's agent
+//                     records staged in LDS, window gathered straight from the agent's own distance field,
+//                     neighbours ranked by ballot-bucket counting, row assembled in LDS
+//                                                                                        (cpp:288-311, 487-528, 352-389)
 #include "common.h"
 
 using namespace mgpt;
@@ -26,6 +29,7 @@ static_assert(sizeof(AgentRec) == 16, "AgentRec must be 16 bytes");
 
 constexpr int kUnreach = 65535;
 constexpr int kFreeUnset = 65534;   // transient marker inside bfs_kernel only
+constexpr int kMaxU8Dist = 253;     // longest finite distance the one-byte field represents exactly
 constexpr int kR = 5;               // obs_radius == agents_radius == 5 (inference.py:18-19)
 constexpr int kWin = 2 * kR + 1;    // 11
 constexpr int kLimit = 20;          // cost2go_value_limit (inference.py:17)
@@ -43,7 +47,8 @@ constexpr int TOK_UNREACH = 41, TOK_NEG = 42, TOK_POS = 43, TOK_N = 44, TOK_BITS
 template <bool kLds>
 __global__ __launch_bounds__(256) void bfs_kernel(const uint8_t *__restrict__ grids, int n_grids, int n_agents,
                                                   int H, int W, const AgentRec *__restrict__ recs,
-                                                  const uint8_t *__restrict__ dirty, uint16_t *__restrict__ dist_all)
+                                                  const uint8_t *__restrict__ dirty, uint16_t *__restrict__ dist_all,
+                                                  uint8_t *__restrict__ dist8_all, int *__restrict__ u8_ok)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ag = blockIdx.x;
@@ -52,6 +57,7 @@ __global__ __launch_bounds__(256) void bfs_kernel(const uint8_t *__restrict__ gr
     const int cells = H * W;
     const uint8_t *grid = grids + (size_t)(inst % n_grids) * cells;
     uint16_t *out = dist_all + (size_t)ag * cells;
+    uint8_t *out8 = dist8_all + (size_t)ag * cells;
     uint16_t *d = kLds ? reinterpret_cast<uint16_t *>(smem) : out;
     const AgentRec r = recs[ag];
     const int tid = threadIdx.x;
@@ -82,11 +88,15 @@ __global__ __launch_bounds__(256) void bfs_kernel(const uint8_t *__restrict__ gr
             if (!__syncthreads_or(changed)) break;
         }
     }
+    int too_long = 0;
     for (int i = tid; i < cells; i += 256) {
         int v = d[i];
         if (v == kFreeUnset) v = kUnreach;
         out[i] = (uint16_t)v;
+        too_long |= (v != kUnreach && v > kMaxU8Dist);
+        out8[i] = (uint8_t)(v == kUnreach ? 255 : min(v, 254));
     }
+    if (too_long) *u8_ok = 0;     // benign race: every writer stores 0
 }
 
 // greedy-direction bits, cpp:412-430: order u(-1,0) d(+1,0) l(0,-1) r(0,+1); bit = neighbour strictly closer
@@ -103,9 +113,11 @@ __device__ __forceinline__ int next_action_token(const uint16_t *__restrict__ d,
 
 // create_agents, cpp:391-410 (history <- "n" x 5)
 __global__ __launch_bounds__(256) void tok_create_kernel(AgentRec *__restrict__ recs, const int16_t *__restrict__ pos,
-                                                         const int16_t *__restrict__ goal, int total)
+                                                         const int16_t *__restrict__ goal, int total,
+                                                         int *__restrict__ u8_ok)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *u8_ok = 1;          // every field is rebuilt next; bfs_kernel clears it if one does not fit a byte
     if (i >= total) return;
     AgentRec r;
     r.pr = pos[2 * i]; r.pc = pos[2 * i + 1];
@@ -152,129 +164,273 @@ __global__ __launch_bounds__(256) void tok_next_kernel(AgentRec *__restrict__ re
 }
 
 // ---------------------------------------------------------------------------------------------
-// generate_observations, cpp:516-528.  Workgroup = 4 wavefronts = one chunk of kAgentsPerBlock
-// agents of ONE instance; a wavefront owns one agent (one 256-token row) at a time.
-//   LDS: the instance's agent records (16 B each), per wave a 256-B row image and a candidate list.
-//   HBM reads per row: 121 x u16 window of the agent's own distance field (11 row segments of 22 B);
-//   HBM writes per row: one coalesced 256-B store (64 lanes x 4 B).
-// Neighbour order = (Manhattan distance, agent id) ascending, first 13 (cpp:496-506); the key
-// (md << 16 | id) is unique, so rank = number of smaller keys is a permutation -- computed by all
-// candidates in parallel, no serial sort.
+// generate_observations, cpp:516-528.  Workgroup = 4 wavefronts = one chunk of 4*RPW agents of ONE
+// instance; a wavefront owns one agent (one 256-token row) at a time, RPW rows in flight.
+//   LDS: token LUT, the instance's agent records (16 B each) + their biased packed positions, per wave
+//        a row image (token t lives at byte t+1 so the 10-token neighbour records are 2-byte aligned)
+//        and a 12-entry distance-bucket table.
+//   HBM reads per row: the 121-cell window of the agent's own distance field (one byte per cell from
+//        `dist8` when every field fits a byte, else two from `dist`); writes: one coalesced 256-B store.
+// Measured (tools/bench_tokenizer.py, tools/probe_salu.hip): the kernel is instruction-issue bound before
+// it is HBM bound -- a wave64 VALU instruction costs its SIMD ~1.6 ns, a scalar one ~1.8 ns, and an LDS
+// store whose lanes collide on one address serialises -- so the row body is written around issue count:
+//   * window token = LUT[med3(v - (mid-21), 0, 42)] (43 = unreachable);
+//   * neighbour test on packed 16-bit positions (v_pk_sub_u16 / v_pk_max_u16 / v_sad_u16);
+//   * neighbour order = (Manhattan distance, agent id) ascending, first 13 (cpp:496-506):
+//     rank = #candidates in lower distance buckets + #lower ids in the own bucket.
+//       KP == 1 (<= 64 agents, lane == agent id): every candidate ORs its lane bit into bucket[md] in LDS,
+//       16 lanes prefix-sum the bucket populations (DPP row scan), then each candidate reads its bucket once:
+//       rank = prefix + popcount(bucket mask below my lane).  ~15 VALU, no per-distance loop.
+//       KP > 1: one ballot per distance value and pass (stops once 13 are ranked) + mbcnt.
+//   * only the <= 13 ranked lanes write their agent's 10-token record (conflict-free LDS stores).
+// KP = ceil(n_agents / 64) candidate passes per row.
 // ---------------------------------------------------------------------------------------------
-constexpr int kAgentsPerBlock = 16;
-constexpr int kMaxCand = 128;
+constexpr int kRowImage = 1024;     // bytes per wave: two 512-B row images (token t at byte t+1; bytes >= 264 are dump space)
+constexpr int kDumpTok = 320;       // where lanes without a second window cell put their byte (inside the 512-B half image, never read)
+constexpr int kBktBytes = 1024;     // per wave: 64 x 16 B {mask lo, mask hi, prefix, -}; entries 0..10 = distances, 11 = "not a neighbour"
+constexpr int kNoRank = 64;
+constexpr int kLutBytes = 64;
 
-__device__ __forceinline__ int window_token(int v, int mid)
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_shr_add(int x)      // x + (x of the lane CTRL-0x110 to the left in its row of 16, 0 if none)
 {
-    if (v == kUnreach) return TOK_UNREACH;          // cpp:308-309 (-80)
-    const int w = v - mid;                          // cpp:304
-    return w > kLimit ? TOK_POS : (w < -kLimit ? TOK_NEG : w + kLimit);   // cpp:305-306
+    return x + __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
 }
 
-__global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict__ recs, const uint16_t *__restrict__ dist,
-                                                     int n_agents, int H, int W, int chunks_per_inst,
-                                                     uint8_t *__restrict__ tokens)
+template <class DT, int KP, int RPW>
+__device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, const DT *__restrict__ dist, int n_agents,
+                                            int H, int W, int chunks_per_inst, uint8_t *__restrict__ tokens, char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    AgentRec *srec = reinterpret_cast<AgentRec *>(smem);                                  // [n_agents]
-    uint32_t *scand = reinterpret_cast<uint32_t *>(smem + (size_t)n_agents * 16);         // [4][kMaxCand]
-    uint8_t *srow = reinterpret_cast<uint8_t *>(scand + 4 * kMaxCand);                    // [4][256]
+    constexpr int UNR = sizeof(DT) == 1 ? 255 : kUnreach;
+    constexpr int APB = 4 * RPW;
+    uint8_t *lut = reinterpret_cast<uint8_t *>(smem);                                      // LDS offset 0
+    int4 *hdr = reinterpret_cast<int4 *>(smem + kLutBytes);                                // [APB] {pos, centre offset, state}
+    uint4 *srec = reinterpret_cast<uint4 *>(smem + kLutBytes + APB * 16);                  // [n_agents]
+    uint32_t *spos = reinterpret_cast<uint32_t *>(smem + kLutBytes + APB * 16 + (size_t)n_agents * 16);   // [KP*64] biased (r,c)
+    uint8_t *srow = reinterpret_cast<uint8_t *>(spos + KP * 64);                           // [4][kRowImage]
+    uint8_t *sbkt = srow + 4 * kRowImage;                                                  // [4][kBktBytes] (KP == 1)
 
     const int inst = blockIdx.x / chunks_per_inst;
     const int chunk = blockIdx.x - inst * chunks_per_inst;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const AgentRec *grec = recs + (size_t)inst * n_agents;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t row0 = (size_t)inst * n_agents;
+    const uint4 *grec = reinterpret_cast<const uint4 *>(recs) + row0;
+    const int a_begin = chunk * APB;
 
-    for (int i = tid; i < n_agents; i += 256) srec[i] = grec[i];      // one 16-B load/store per record
+    for (int i = tid; i < KP * 64; i += 256) {
+        uint32_t bp = 0xffffffffu;                       // sentinel: never inside a window (H, W <= 16384)
+        if (i < n_agents) {
+            const uint4 r = grec[i];                     // {pr|pc<<16, gr|gc<<16, hist0..3, hist4|next<<8}
+            srec[i] = r;
+            bp = r.x ^ 0x80008000u;                      // int16 -> order-preserving uint16
+        }
+        spos[i] = bp;
+    }
+    if (tid < APB) {                                     // per-row scalars, prepared once
+        const int a = a_begin + tid;
+        int4 h = make_int4(0, 0, -1, 0);                 // state -1: no such agent
+        if (a < n_agents) {
+            const uint32_t my0 = grec[a].x;
+            const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
+            const bool inside = pr >= kR && pr + kR < H && pc >= kR && pc + kR < W;   // whole window inside the frame
+            h = make_int4((int)my0, pr * W + pc, inside ? 1 : 0, 0);
+        }
+        hdr[tid] = h;
+    }
+    if (tid >= 64 && tid < 64 + kLutBytes) {             // idx = clamp(w + 21, 0, 42): 0 -> -40, 1..41 -> w+20, 42 -> +40; 43 -> -80
+        const int t = tid - 64;
+        lut[t] = (uint8_t)(t == 0 ? TOK_NEG : t <= 41 ? t - 1 : t == 42 ? TOK_POS : TOK_UNREACH);
+    }
     __syncthreads();
 
-    uint32_t *cand = scand + wave * kMaxCand;
-    uint8_t *row = srow + wave * 256;
-    uint32_t *row32 = reinterpret_cast<uint32_t *>(row);
+    uint8_t *row = srow + wave * kRowImage;
+    uint4 *bkt = reinterpret_cast<uint4 *>(sbkt + wave * kBktBytes);
     const int cells = H * W;
+    const int i0 = lane / kWin, j0 = lane - i0 * kWin;                  // window cell of this lane: index lane ...
+    const bool has1 = lane < kWin * kWin - 64;
+    const int l1 = has1 ? lane + 64 : lane;                             // ... and lane + 64 (lanes >= 57 repeat their first cell)
+    const int i1 = l1 / kWin, j1 = l1 - i1 * kWin;
+    const int off0 = (i0 - kR) * W + (j0 - kR), off1 = (i1 - kR) * W + (j1 - kR);
+    uint8_t *tok0_at = row + 1 + lane;
+    uint8_t *tok1_at = row + (has1 ? 65 + lane : kDumpTok + lane);
+    // lane bit and "lanes below me" masks for the bucket ranking
+    const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane < 32 ? 0u : 1u << (lane - 32);
+    const uint32_t lt_lo = lane < 32 ? bit_lo - 1u : 0xffffffffu, lt_hi = lane < 32 ? 0u : bit_hi - 1u;
 
-    const int a_begin = chunk * kAgentsPerBlock;
-    // Issue the window gathers of ALL agents this wave owns before touching any of them: the kernel is bound by
-    // HBM latency (two 2-byte gathers per agent), so bytes in flight per wave, not instructions, set the rate.
-    constexpr int kPerWave = kAgentsPerBlock / 4;
-    const int p0 = lane, i0 = p0 / kWin, j0 = p0 - i0 * kWin;
-    const int p1 = lane + 64, i1 = p1 / kWin, j1 = p1 - i1 * kWin;
-    int w0[kPerWave], w1[kPerWave];
+    // Issue the window gathers of ALL rows this wave owns before touching any of them (bytes in flight).
+    int w0[RPW], w1[RPW];
+    uint32_t my0s[RPW];
+    int state[RPW];
 #pragma unroll
-    for (int q = 0; q < kPerWave; q++) {
-        const int a = a_begin + wave + 4 * q;
-        w0[q] = kUnreach; w1[q] = kUnreach;
-        if (a < n_agents) {                                             // wave-uniform
-            const int pr = srec[a].pr, pc = srec[a].pc;
-            const uint16_t *d = dist + ((size_t)inst * n_agents + a) * cells;
-            const int rr0 = pr - kR + i0, cc0 = pc - kR + j0;
+    for (int q = 0; q < RPW; q++) {
+        const int4 h = hdr[wave + 4 * q];
+        const uint32_t my0 = __builtin_amdgcn_readfirstlane(h.x);
+        const int centre = __builtin_amdgcn_readfirstlane(h.y);
+        const int st = __builtin_amdgcn_readfirstlane(h.z);
+        my0s[q] = my0; state[q] = st;
+        w0[q] = UNR; w1[q] = UNR;
+        const DT *d = dist + (row0 + a_begin + wave + 4 * q) * cells;
+        if (st > 0) {                                                   // wave-uniform; always taken for env states
+            w0[q] = (int)d[(uint32_t)(centre + off0)];
+            w1[q] = (int)d[(uint32_t)(centre + off1)];
+        } else if (st == 0) {                                           // out-of-frame cells read as walls
+            const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
+            const int rr0 = pr - kR + i0, cc0 = pc - kR + j0, rr1 = pr - kR + i1, cc1 = pc - kR + j1;
             if (rr0 >= 0 && rr0 < H && cc0 >= 0 && cc0 < W) w0[q] = (int)d[rr0 * W + cc0];
-            const int rr1 = pr - kR + i1, cc1 = pc - kR + j1;
-            if (p1 < kWin * kWin && rr1 >= 0 && rr1 < H && cc1 >= 0 && cc1 < W) w1[q] = (int)d[rr1 * W + cc1];
+            if (rr1 >= 0 && rr1 < H && cc1 >= 0 && cc1 < W) w1[q] = (int)d[rr1 * W + cc1];
         }
     }
+    // Rows are processed U at a time, phase by phase: a row's chain is ~8 dependent LDS round trips, so one row
+    // at a time leaves the wave waiting; two interleaved rows share every wait.
+    constexpr int U = 2;
+    static_assert(RPW % U == 0, "RPW must be a multiple of U");
 #pragma unroll
-    for (int q = 0; q < kPerWave; q++) {
-        const int a = a_begin + wave + 4 * q;
-        if (a >= n_agents) break;                                       // wave-uniform
-        const AgentRec me = srec[a];
-        const int pr = me.pr, pc = me.pc;
-        const int v0 = w0[q], v1 = w1[q];
+    for (int q0 = 0; q0 < RPW; q0 += U) {
+        if (state[q0] < 0) break;                                       // wave-uniform: past the last agent
+        bool live[U];
+        if (KP == 1) bkt[lane] = make_uint4(0u, 0u, 0u, 0u);          // entries 16u + d: distance bucket d of row u
+        int mdm[U][KP], rank[U][KP];
+        uint4 *mine[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            live[u] = state[q0 + u] >= 0;
+            uint8_t *rw = row + u * (kRowImage / U);
+            const int v0 = w0[q0 + u], v1 = w1[q0 + u];
+            const uint32_t my0 = my0s[q0 + u];
+            reinterpret_cast<uint2 *>(rw)[lane] = make_uint2(0x42424242u, 0x42424242u);   // "!" (66), cpp:375-376,386-387
 
-        row32[lane] = 0x42424242u;                                      // whole row <- "!" (66), cpp:375-376,386-387
+            // --- window tokens (cpp:288-311 + encoder cpp:352-357) ---
+            int mid = __builtin_amdgcn_readlane(v0, kR * kWin + kR);    // centre cell, cpp:297
+            if (sizeof(DT) == 1 && mid == 255) mid = kUnreach;          // agent on a wall: same arithmetic as the 16-bit field
+            const int midp = mid - (kLimit + 1);
+            int x0 = min(max(v0 - midp, 0), 2 * kLimit + 2);            // -> v_med3_i32
+            int x1 = min(max(v1 - midp, 0), 2 * kLimit + 2);
+            x0 = (v0 == UNR) ? 2 * kLimit + 3 : x0;                     // cpp:308-309 (-80)
+            x1 = (v1 == UNR) ? 2 * kLimit + 3 : x1;
+            tok0_at[u * (kRowImage / U)] = lut[x0];
+            tok1_at[u * (kRowImage / U)] = lut[x1];
 
-        // --- neighbour candidates from the LDS-resident records ---
-        int cnt = 0;
-        for (int b0 = 0; b0 < n_agents; b0 += 64) {
-            const int b = b0 + lane;
-            bool in = false;
-            int md = 0;
-            if (b < n_agents) {
-                const int dr = srec[b].pr - pr, dc = srec[b].pc - pc;
-                in = (dr >= -kR && dr <= kR && dc >= -kR && dc <= kR);  // the 11x11 scan of cpp:492-495
-                md = abs(dr) + abs(dc);                                  // cpp:498-499
+            // --- neighbours: the 11x11 scan of cpp:492-495 on the LDS-resident positions ---
+            const uint32_t myb = my0 ^ 0x80008000u;
+            const us2 lo = __builtin_bit_cast(us2, myb) - (us2){kR, kR};
+#pragma unroll
+            for (int k = 0; k < KP; k++) {
+                const uint32_t bp = spos[lane + 64 * k];
+                const us2 t = __builtin_bit_cast(us2, bp) - lo;                              // (dr + 5, dc + 5) mod 2^16
+                const us2 mx = __builtin_elementwise_max(t, (us2){2 * kR, 2 * kR});
+                const bool in = __builtin_bit_cast(uint32_t, mx) == (uint32_t)(2 * kR) * 0x00010001u;
+                const int md = (int)__builtin_amdgcn_sad_u16(bp, myb, 0u);                    // |dr| + |dc|, cpp:498-499
+                mdm[u][k] = in ? md : 2 * kR + 1;                                             // 11 = not a neighbour
             }
-            const unsigned long long m = __ballot(in);
-            if (in) {
-                const int idx = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                if (idx < kMaxCand) cand[idx] = ((uint32_t)md << 16) | (uint32_t)b;
-            }
-            cnt += __popcll(m);
         }
-        if (cnt > kMaxCand) cnt = kMaxCand;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // candidate list written by some lanes, read by all
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // --- window tokens ---
-        const int mid = __shfl(v0, kR * kWin + kR);                     // centre cell = index 60, cpp:297
-        row[lane] = (uint8_t)window_token(v0, mid);
-        if (lane + 64 < kWin * kWin) row[lane + 64] = (uint8_t)window_token(v1, mid);
-
-        // --- rank candidates, first 13 emit their 10-token record (cpp:352-373, 506-512) ---
-        for (int c = lane; c < cnt; c += 64) {
-            const uint32_t key = cand[c];
-            int rank = 0;
-            for (int j = 0; j < cnt; j++) rank += (cand[j] < key) ? 1 : 0;
-            if (rank < kSlots) {
-                const AgentRec o = srec[key & 0xffffu];
-                uint8_t *q = row + kWin * kWin + 10 * rank;
-                q[0] = (uint8_t)(o.pr - pr + kLimit);
-                q[1] = (uint8_t)(o.pc - pc + kLimit);
-                q[2] = (uint8_t)(min(max(o.gr - pr, -kLimit), kLimit) + kLimit);
-                q[3] = (uint8_t)(min(max(o.gc - pc, -kLimit), kLimit) + kLimit);
-                q[4] = o.hist[0]; q[5] = o.hist[1]; q[6] = o.hist[2]; q[7] = o.hist[3]; q[8] = o.hist[4];
-                q[9] = o.next;
+        // --- rank = position in (Manhattan, id) order (cpp:500-506): lower buckets + lower ids of the own bucket ---
+        if (KP == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                mine[u] = bkt + u * 16 + mdm[u][0];
+                if (mdm[u][0] <= 2 * kR)    // divergent on purpose: same-address LDS atomics serialise, so only real neighbours issue one
+                    __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(mine[u]),
+                                          ((unsigned long long)bit_hi << 32) | bit_lo, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WAVEFRONT);                      // ds_or_b64, order-independent
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {   // lanes 16u .. 16u+11 prefix-sum the bucket populations of row u (DPP rows are 16 lanes wide)
+                const uint2 pop = *reinterpret_cast<const uint2 *>(bkt + (lane & 31));
+                const int c = __popc(pop.x) + __popc(pop.y);
+                int incl = dpp_shr_add<0x111>(c);
+                incl = dpp_shr_add<0x112>(incl);
+                incl = dpp_shr_add<0x114>(incl);
+                incl = dpp_shr_add<0x118>(incl);
+                reinterpret_cast<uint32_t *>(bkt + (lane & 31))[2] = (uint32_t)(incl - c);    // #candidates in lower buckets
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint4 e = *mine[u];
+                const int r = __popc(e.x & lt_lo) + __popc(e.y & lt_hi) + (int)e.z;
+                rank[u][0] = mdm[u][0] <= 2 * kR ? r : kNoRank;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int k = 0; k < KP; k++) rank[u][k] = kNoRank;
+                int placed = 0;
+#define MGPT_BUCKET(m_)                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < KP; k++)                                                                   \
+    {                                                                                                                \
+        const bool hit = mdm[u][k] == (m_);                                                                          \
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(hit);                                              \
+        const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)) + placed; \
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(rank[u][k]) : "v"(rank[u][k]), "v"(r), "s"(bm)); /* select, never a branch */ \
+        placed += __popcll(bm);                                                                                      \
+    }
+                MGPT_BUCKET(0) MGPT_BUCKET(1) MGPT_BUCKET(2) MGPT_BUCKET(3) MGPT_BUCKET(4)
+                if (placed < kSlots) {                                  // wave-uniform early exits: 13 are enough
+                    MGPT_BUCKET(5) MGPT_BUCKET(6)
+                    if (placed < kSlots) { MGPT_BUCKET(7) MGPT_BUCKET(8) MGPT_BUCKET(9) MGPT_BUCKET(10) }
+                }
+#undef MGPT_BUCKET
+            }
+        }
+        // --- the first 13 write their 10-token record (cpp:352-373, 506-512) ---
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const ss2 mys = __builtin_bit_cast(ss2, my0s[q0 + u]);
+            uint8_t *rw = row + u * (kRowImage / U);
+#pragma unroll
+            for (int k = 0; k < KP; k++) {
+                if (rank[u][k] >= kSlots) continue;     // divergent on purpose: <= 13 active lanes make conflict-free LDS stores
+                const uint4 o = srec[lane + 64 * k];
+                const ss2 rel = __builtin_bit_cast(ss2, o.x) - mys + (ss2){kLimit, kLimit};                // not clamped (within +-5)
+                ss2 rg = __builtin_bit_cast(ss2, o.y) - mys;
+                rg = __builtin_elementwise_min(__builtin_elementwise_max(rg, (ss2){-kLimit, -kLimit}), (ss2){kLimit, kLimit}) +
+                     (ss2){kLimit, kLimit};
+                const uint32_t qa = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, rg), __builtin_bit_cast(uint32_t, rel),
+                                                          0x06040200u);                                     // {rel.r, rel.c, goal.r, goal.c}
+                uint16_t *dst = reinterpret_cast<uint16_t *>(rw + 1 + kWin * kWin + 10 * rank[u][k]);         // 2-byte aligned
+                dst[0] = (uint16_t)qa; dst[1] = (uint16_t)(qa >> 16);
+                dst[2] = (uint16_t)o.z; dst[3] = (uint16_t)(o.z >> 16);                                      // history, oldest first
+                dst[4] = (uint16_t)o.w;                                                                      // newest action, greedy bits
             }
         }
         // all LDS traffic above is issued by this wave in program order; make it visible to its own reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t packed = row32[lane];
-        reinterpret_cast<uint32_t *>(tokens + ((size_t)inst * n_agents + a) * 256)[lane] = packed;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!live[u]) break;
+            const uint32_t *row32 = reinterpret_cast<const uint32_t *>(row + u * (kRowImage / U));
+            const uint32_t packed = __builtin_amdgcn_alignbyte(row32[lane + 1], row32[lane], 1);   // tokens 4*lane .. 4*lane+3
+            reinterpret_cast<uint32_t *>(tokens + (row0 + a_begin + wave + 4 * (q0 + u)) * 256)[lane] = packed;
+        }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+template <int KP, int RPW>
+__global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict__ recs, const uint16_t *__restrict__ dist,
+                                                     const uint8_t *__restrict__ dist8, const int *__restrict__ u8_ok,
+                                                     int n_agents, int H, int W, int chunks_per_inst,
+                                                     uint8_t *__restrict__ tokens)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (*u8_ok)                                                         // uniform
+        tokens_body<uint8_t, KP, RPW>(recs, dist8, n_agents, H, W, chunks_per_inst, tokens, smem);
+    else
+        tokens_body<uint16_t, KP, RPW>(recs, dist, n_agents, H, W, chunks_per_inst, tokens, smem);
 }
 
 }  // namespace
@@ -286,6 +442,8 @@ struct mgpt_tokenizer {
     int n_inst, n_agents, H, W, n_grids;
     uint8_t *grids = nullptr;
     uint16_t *dist = nullptr;
+    uint8_t *dist8 = nullptr;
+    int *u8_ok = nullptr;
     AgentRec *recs = nullptr;
     uint8_t *dirty = nullptr;
     bool have_grids = false, have_agents = false;
@@ -302,6 +460,7 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
                  MGPT_ERR_UNSUPPORTED,
                  "only the reference's InputParameters (20,13,5,256,5,5) are implemented (inference.py:15-29)");
     MGPT_REQUIRE(n_agents <= 2048, MGPT_ERR_UNSUPPORTED, "n_agents=%d > 2048", n_agents);
+    MGPT_REQUIRE(H <= 16384 && W <= 16384, MGPT_ERR_UNSUPPORTED, "H=%d W=%d beyond 16384", H, W);
     // distances are uint16 as in the reference (h:73); shortest paths must stay below 65534
     MGPT_REQUIRE((int64_t)H * W <= (1 << 22), MGPT_ERR_UNSUPPORTED, "H*W=%lld cells is beyond this build's limit (4M)",
                  (long long)H * W);
@@ -310,6 +469,8 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
     const size_t cells = (size_t)H * W, total = (size_t)n_inst * n_agents;
     hipError_t e = hipMalloc(&t->grids, (size_t)n_grids * cells);
     if (e == hipSuccess) e = hipMalloc(&t->dist, total * cells * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc(&t->dist8, total * cells);
+    if (e == hipSuccess) e = hipMalloc(&t->u8_ok, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&t->recs, total * sizeof(AgentRec));
     if (e == hipSuccess) e = hipMalloc(&t->dirty, total);
     if (e != hipSuccess) {
@@ -324,7 +485,8 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
 extern "C" int mgpt_tokenizer_destroy(mgpt_tokenizer *t)
 {
     if (!t) return MGPT_OK;
-    (void)hipFree(t->grids); (void)hipFree(t->dist); (void)hipFree(t->recs); (void)hipFree(t->dirty);
+    (void)hipFree(t->grids); (void)hipFree(t->dist); (void)hipFree(t->dist8); (void)hipFree(t->u8_ok);
+    (void)hipFree(t->recs); (void)hipFree(t->dirty);
     delete t;
     return MGPT_OK;
 }
@@ -345,10 +507,10 @@ static int launch_bfs(mgpt_tokenizer *t, const uint8_t *dirty, hipStream_t s)
     ProfScope ps(P_BFS, s);
     if (bytes <= 64 * 1024) {
         hipLaunchKernelGGL(bfs_kernel<true>, dim3(total), dim3(256), bytes, s, t->grids, t->n_grids, t->n_agents, t->H,
-                           t->W, t->recs, dirty, t->dist);
+                           t->W, t->recs, dirty, t->dist, t->dist8, t->u8_ok);
     } else {
         hipLaunchKernelGGL(bfs_kernel<false>, dim3(total), dim3(256), 0, s, t->grids, t->n_grids, t->n_agents, t->H,
-                           t->W, t->recs, dirty, t->dist);
+                           t->W, t->recs, dirty, t->dist, t->dist8, t->u8_ok);
     }
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
@@ -362,7 +524,8 @@ extern "C" int mgpt_tokenizer_create_agents(mgpt_tokenizer *t, const int16_t *d_
     const int total = t->n_inst * t->n_agents;
     {
         ProfScope ps(P_TOK_UPDATE, s);
-        hipLaunchKernelGGL(tok_create_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, d_pos, d_goal, total);
+        hipLaunchKernelGGL(tok_create_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, d_pos, d_goal, total,
+                           t->u8_ok);
         MGPT_LAUNCH_CHECK();
     }
     int rc = launch_bfs(t, nullptr, s);
@@ -404,11 +567,33 @@ extern "C" int mgpt_tokenizer_generate_observations(mgpt_tokenizer *t, uint8_t *
     MGPT_REQUIRE(t && d_tokens, MGPT_ERR_ARG, "NULL argument");
     MGPT_REQUIRE(t->have_agents, MGPT_ERR_STATE, "create_agents must precede generate_observations");
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = cdiv(t->n_agents, kAgentsPerBlock);
-    const size_t smem = (size_t)t->n_agents * 16 + 4 * kMaxCand * 4 + 4 * 256;
+    const int kp = cdiv(t->n_agents, 64);
+    const int kpp = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 8 ? 8 : kp <= 16 ? 16 : 32;
+    // rows per wavefront: 16 (more bytes in flight, records staged once per 64 rows) when the launch still fills the GPU
+    const bool big = (int64_t)t->n_inst * cdiv(t->n_agents, 64) >= 4096;
+    const int apb = big ? 64 : 16;
+    const int chunks = cdiv(t->n_agents, apb);
+    const size_t smem = kLutBytes + (size_t)apb * 16 + (size_t)t->n_agents * 16 + (size_t)kpp * 64 * 4 + 4 * kRowImage +
+                        (kpp == 1 ? 4 * kBktBytes : 0);
     ProfScope ps(P_TOKENS, s);
-    hipLaunchKernelGGL(tokens_kernel, dim3(t->n_inst * chunks), dim3(256), smem, s, t->recs, t->dist, t->n_agents, t->H,
-                       t->W, chunks, d_tokens);
+#define MGPT_TOKENS(KP_)                                                                                              \
+    do {                                                                                                              \
+        if (big)                                                                                                      \
+            hipLaunchKernelGGL((tokens_kernel<KP_, 16>), dim3(t->n_inst * chunks), dim3(256), smem, s, t->recs, t->dist, \
+                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens);                        \
+        else                                                                                                          \
+            hipLaunchKernelGGL((tokens_kernel<KP_, 4>), dim3(t->n_inst * chunks), dim3(256), smem, s, t->recs, t->dist, \
+                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens);                        \
+    } while (0)
+    switch (kpp) {
+    case 1: MGPT_TOKENS(1); break;
+    case 2: MGPT_TOKENS(2); break;
+    case 4: MGPT_TOKENS(4); break;
+    case 8: MGPT_TOKENS(8); break;
+    case 16: MGPT_TOKENS(16); break;
+    default: MGPT_TOKENS(32); break;
+    }
+#undef MGPT_TOKENS
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
