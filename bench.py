@@ -130,6 +130,47 @@ def cpu_baseline(map_name, n_agents, model, budget_s=12.0):
             "reference_tokenizer_us_per_agent": ref_tok}
 
 
+def tokenizer_large_launch(grid, s_ok, g_ok, n_agents, local_rank, target_rows=524288, reps=20):
+    """the tokenizer's HBM roofline is to be read on launches of >= 1e5 rows (cfg4/5-sized per-GPU shards), not on
+    cfg2's 16 384 rows.  Same map and agent count as the workload, instances replicated up to ~5e5 rows, HIP-event timing
+    of the tokens kernel over `reps` launches (inputs resident in HBM)."""
+    import torch
+    from mapf_gpt_amd import _lib
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    from mapf_gpt_amd.runner import make_instances
+    dev = f"cuda:{local_rank}"
+    n_inst = max(1, target_rows // n_agents)
+    base = min(n_inst, 256)
+    pos, goal = make_instances(grid, base, n_agents, 0, s_ok, g_ok)
+    k = (n_inst + base - 1) // base
+    pos = pos.repeat(k, 1, 1)[:n_inst].contiguous().to(dev)
+    goal = goal.repeat(k, 1, 1)[:n_inst].contiguous().to(dev)
+    tok = BatchedTokenizer(grid, n_inst, n_agents, device=dev)
+    tok.create_agents(pos, goal)
+    act = torch.zeros((n_inst, n_agents), dtype=torch.int32, device=dev)
+    out = torch.empty((n_inst * n_agents, 256), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        tok.update_agents(pos, goal, act, goals_may_change=False)
+        tok.generate_observations(out)
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    for _ in range(reps):
+        tok.update_agents(pos, goal, act, goals_may_change=False)
+        tok.generate_observations(out)
+    _lib.prof_enable(False)
+    p = _lib.prof_read()
+    rows = n_inst * n_agents
+    ms, n = p["tok_generate_observations"]
+    ach = TOKENIZER_BYTES_PER_ROW * rows / (ms / n * 1e-3) / 1e9
+    del tok, out
+    torch.cuda.empty_cache()
+    return {"kernel": "tok_generate_observations", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows,
+            "algorithmic_bytes_per_row": TOKENIZER_BYTES_PER_ROW,
+            "note": "694 B/row = SURVEY 8d (u16 window 242 + own record 14 + 13 neighbour records 182 + uint8 row 256); the kernel "
+                    "itself reads one-byte fields when every distance fits (573 B/row by its own layout)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +180,7 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("MGPT_BENCH_PRECISION", "f16x3"), choices=["f32", "f16x3", "bf16"])
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tokenizer-leg", action="store_true", help="skip the >=1e5-row tokenizer roofline launch")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event hooks")
     a = ap.parse_args()
 
@@ -257,7 +299,10 @@ def main():
                 ach = TOKENIZER_BYTES_PER_ROW * rows / (ms / n * 1e-3) / 1e9
                 out["roofline_tokenizer"] = {"kernel": "tok_generate_observations", "bound": "hbm", "achieved": ach,
                                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
-                                             "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows}
+                                             "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows,
+                                             "note": "the workload's own launch (latency-bound when rows_per_launch < 1e5)"}
+            if world == 1 and not a.no_tokenizer_leg:
+                out["roofline_tokenizer_large"] = tokenizer_large_launch(grid, s_ok, g_ok, n_agents, local_rank)
             out["kernel_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(map_name, n_agents, model)

@@ -177,15 +177,20 @@ __global__ __launch_bounds__(256) void tok_next_kernel(AgentRec *__restrict__ re
 //   * window token = LUT[med3(v - (mid-21), 0, 42)] (43 = unreachable);
 //   * neighbour test on packed 16-bit positions (v_pk_sub_u16 / v_pk_max_u16 / v_sad_u16);
 //   * neighbour order = (Manhattan distance, agent id) ascending, first 13 (cpp:496-506):
-//     rank = #candidates in lower distance buckets + #lower ids in the own bucket.
-//       KP == 1 (<= 64 agents, lane == agent id): every candidate ORs its lane bit into bucket[md] in LDS,
-//       16 lanes prefix-sum the bucket populations (DPP row scan), then each candidate reads its bucket once:
-//       rank = prefix + popcount(bucket mask below my lane).  ~15 VALU, no per-distance loop.
-//       KP > 1: one ballot per distance value and pass (stops once 13 are ranked) + mbcnt.
-//   * only the <= 13 ranked lanes write their agent's 10-token record (conflict-free LDS stores).
+//     rank = #candidates in lower distance buckets + #lower ids in the own bucket.  Candidate lanes are in id
+//     order (KP == 1: lane == agent id; KP > 1: the passes' neighbours are compacted into <= 64 lanes by
+//     ballot + mbcnt).  Every candidate ORs its lane bit into bucket[md] in LDS, 16 lanes prefix-sum the bucket
+//     populations (DPP row scan), then each candidate reads its bucket once:
+//     rank = prefix + popcount(bucket mask below my lane).  ~15 VALU, no per-distance loop.
+//     More than 64 neighbours in one window (possible with > 64 agents in an open room): exact slow path that
+//     walks the distance buckets over all passes;
+//   * only the <= 13 ranked lanes write their agent's 10-token record (conflict-free LDS stores);
+//   * a row's chain is ~8 dependent LDS round trips, so a wave works on 4 rows at once, phase by phase.
 // KP = ceil(n_agents / 64) candidate passes per row.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRowImage = 1024;     // bytes per wave: two 512-B row images (token t at byte t+1; bytes >= 264 are dump space)
+constexpr int kRowsInterleaved = 4; // rows a wave works on at once (U)
+constexpr int kRowBytes = 512;      // one row image: token t at byte t+1; bytes >= 264 are dump space
+constexpr int kRowImage = kRowsInterleaved * kRowBytes;   // per wave
 constexpr int kDumpTok = 320;       // where lanes without a second window cell put their byte (inside the 512-B half image, never read)
 constexpr int kBktBytes = 1024;     // per wave: 64 x 16 B {mask lo, mask hi, prefix, -}; entries 0..10 = distances, 11 = "not a neighbour"
 constexpr int kNoRank = 64;
@@ -200,6 +205,23 @@ __device__ __forceinline__ int dpp_shr_add(int x)      // x + (x of the lane CTR
     return x + __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
 }
 
+// one neighbour record = 10 tokens at row bytes 122 + 10*rank (cpp:352-373): rel pos (not clamped, within +-5),
+// rel goal clamped to +-20, five history tokens oldest first, greedy-direction bits
+__device__ __forceinline__ void emit_record(uint8_t *rw, int rank, uint4 o, uint32_t my0)
+{
+    const ss2 mys = __builtin_bit_cast(ss2, my0);
+    const ss2 rel = __builtin_bit_cast(ss2, o.x) - mys + (ss2){kLimit, kLimit};
+    ss2 rg = __builtin_bit_cast(ss2, o.y) - mys;
+    rg = __builtin_elementwise_min(__builtin_elementwise_max(rg, (ss2){-kLimit, -kLimit}), (ss2){kLimit, kLimit}) +
+         (ss2){kLimit, kLimit};
+    const uint32_t qa = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, rg), __builtin_bit_cast(uint32_t, rel),
+                                              0x06040200u);                                   // {rel.r, rel.c, goal.r, goal.c}
+    uint16_t *dst = reinterpret_cast<uint16_t *>(rw + 1 + kWin * kWin + 10 * rank);           // 2-byte aligned
+    dst[0] = (uint16_t)qa; dst[1] = (uint16_t)(qa >> 16);
+    dst[2] = (uint16_t)o.z; dst[3] = (uint16_t)(o.z >> 16);
+    dst[4] = (uint16_t)o.w;
+}
+
 template <class DT, int KP, int RPW>
 __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, const DT *__restrict__ dist, int n_agents,
                                             int H, int W, int chunks_per_inst, uint8_t *__restrict__ tokens, char *smem)
@@ -211,7 +233,8 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
     uint4 *srec = reinterpret_cast<uint4 *>(smem + kLutBytes + APB * 16);                  // [n_agents]
     uint32_t *spos = reinterpret_cast<uint32_t *>(smem + kLutBytes + APB * 16 + (size_t)n_agents * 16);   // [KP*64] biased (r,c)
     uint8_t *srow = reinterpret_cast<uint8_t *>(spos + KP * 64);                           // [4][kRowImage]
-    uint8_t *sbkt = srow + 4 * kRowImage;                                                  // [4][kBktBytes] (KP == 1)
+    uint8_t *sbkt = srow + 4 * kRowImage;                                                  // [4][kBktBytes]
+    uint32_t *scand = reinterpret_cast<uint32_t *>(sbkt + 4 * kBktBytes);                  // [4][U*64] compacted neighbours (KP > 1)
 
     const int inst = blockIdx.x / chunks_per_inst;
     const int chunk = blockIdx.x - inst * chunks_per_inst;
@@ -249,6 +272,7 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
 
     uint8_t *row = srow + wave * kRowImage;
     uint4 *bkt = reinterpret_cast<uint4 *>(sbkt + wave * kBktBytes);
+    uint32_t *cand = scand + wave * (kRowsInterleaved * 64);
     const int cells = H * W;
     const int i0 = lane / kWin, j0 = lane - i0 * kWin;                  // window cell of this lane: index lane ...
     const bool has1 = lane < kWin * kWin - 64;
@@ -285,20 +309,22 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
         }
     }
     // Rows are processed U at a time, phase by phase: a row's chain is ~8 dependent LDS round trips, so one row
-    // at a time leaves the wave waiting; two interleaved rows share every wait.
-    constexpr int U = 2;
+    // at a time leaves the wave waiting; U interleaved rows share every wait.
+    constexpr int U = kRowsInterleaved;
     static_assert(RPW % U == 0, "RPW must be a multiple of U");
 #pragma unroll
     for (int q0 = 0; q0 < RPW; q0 += U) {
         if (state[q0] < 0) break;                                       // wave-uniform: past the last agent
         bool live[U];
-        if (KP == 1) bkt[lane] = make_uint4(0u, 0u, 0u, 0u);          // entries 16u + d: distance bucket d of row u
-        int mdm[U][KP], rank[U][KP];
+        bkt[lane] = make_uint4(0u, 0u, 0u, 0u);                         // entries 16u + d: distance bucket d of row u
+        int mdm[U];            // candidate of this lane for row u: Manhattan distance (11 = none) ...
+        int cid[U];            // ... and agent id
+        int ncand[U];          // KP > 1: number of neighbours found (wave-uniform)
         uint4 *mine[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             live[u] = state[q0 + u] >= 0;
-            uint8_t *rw = row + u * (kRowImage / U);
+            uint8_t *rw = row + u * kRowBytes;
             const int v0 = w0[q0 + u], v1 = w1[q0 + u];
             const uint32_t my0 = my0s[q0 + u];
             reinterpret_cast<uint2 *>(rw)[lane] = make_uint2(0x42424242u, 0x42424242u);   // "!" (66), cpp:375-376,386-387
@@ -311,12 +337,13 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
             int x1 = min(max(v1 - midp, 0), 2 * kLimit + 2);
             x0 = (v0 == UNR) ? 2 * kLimit + 3 : x0;                     // cpp:308-309 (-80)
             x1 = (v1 == UNR) ? 2 * kLimit + 3 : x1;
-            tok0_at[u * (kRowImage / U)] = lut[x0];
-            tok1_at[u * (kRowImage / U)] = lut[x1];
+            tok0_at[u * kRowBytes] = lut[x0];
+            tok1_at[u * kRowBytes] = lut[x1];
 
             // --- neighbours: the 11x11 scan of cpp:492-495 on the LDS-resident positions ---
             const uint32_t myb = my0 ^ 0x80008000u;
             const us2 lo = __builtin_bit_cast(us2, myb) - (us2){kR, kR};
+            ncand[u] = 0;
 #pragma unroll
             for (int k = 0; k < KP; k++) {
                 const uint32_t bp = spos[lane + 64 * k];
@@ -324,85 +351,89 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
                 const us2 mx = __builtin_elementwise_max(t, (us2){2 * kR, 2 * kR});
                 const bool in = __builtin_bit_cast(uint32_t, mx) == (uint32_t)(2 * kR) * 0x00010001u;
                 const int md = (int)__builtin_amdgcn_sad_u16(bp, myb, 0u);                    // |dr| + |dc|, cpp:498-499
-                mdm[u][k] = in ? md : 2 * kR + 1;                                             // 11 = not a neighbour
-            }
-        }
-        // --- rank = position in (Manhattan, id) order (cpp:500-506): lower buckets + lower ids of the own bucket ---
-        if (KP == 1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                mine[u] = bkt + u * 16 + mdm[u][0];
-                if (mdm[u][0] <= 2 * kR)    // divergent on purpose: same-address LDS atomics serialise, so only real neighbours issue one
-                    __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(mine[u]),
-                                          ((unsigned long long)bit_hi << 32) | bit_lo, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_WAVEFRONT);                      // ds_or_b64, order-independent
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            {   // lanes 16u .. 16u+11 prefix-sum the bucket populations of row u (DPP rows are 16 lanes wide)
-                const uint2 pop = *reinterpret_cast<const uint2 *>(bkt + (lane & 31));
-                const int c = __popc(pop.x) + __popc(pop.y);
-                int incl = dpp_shr_add<0x111>(c);
-                incl = dpp_shr_add<0x112>(incl);
-                incl = dpp_shr_add<0x114>(incl);
-                incl = dpp_shr_add<0x118>(incl);
-                reinterpret_cast<uint32_t *>(bkt + (lane & 31))[2] = (uint32_t)(incl - c);    // #candidates in lower buckets
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint4 e = *mine[u];
-                const int r = __popc(e.x & lt_lo) + __popc(e.y & lt_hi) + (int)e.z;
-                rank[u][0] = mdm[u][0] <= 2 * kR ? r : kNoRank;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-#pragma unroll
-                for (int k = 0; k < KP; k++) rank[u][k] = kNoRank;
-                int placed = 0;
-#define MGPT_BUCKET(m_)                                                                                              \
-    _Pragma("unroll") for (int k = 0; k < KP; k++)                                                                   \
-    {                                                                                                                \
-        const bool hit = mdm[u][k] == (m_);                                                                          \
-        const unsigned long long bm = __builtin_amdgcn_ballot_w64(hit);                                              \
-        const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)) + placed; \
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(rank[u][k]) : "v"(rank[u][k]), "v"(r), "s"(bm)); /* select, never a branch */ \
-        placed += __popcll(bm);                                                                                      \
-    }
-                MGPT_BUCKET(0) MGPT_BUCKET(1) MGPT_BUCKET(2) MGPT_BUCKET(3) MGPT_BUCKET(4)
-                if (placed < kSlots) {                                  // wave-uniform early exits: 13 are enough
-                    MGPT_BUCKET(5) MGPT_BUCKET(6)
-                    if (placed < kSlots) { MGPT_BUCKET(7) MGPT_BUCKET(8) MGPT_BUCKET(9) MGPT_BUCKET(10) }
+                if (KP == 1) {                                                                // lane == agent id
+                    mdm[u] = in ? md : 2 * kR + 1;
+                    cid[u] = lane;
+                } else {                                                                      // compact the neighbours, id order kept
+                    const unsigned long long bm = __builtin_amdgcn_ballot_w64(in);
+                    const int at = ncand[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                    if (in && at < 64) cand[u * 64 + at] = ((uint32_t)md << 16) | (uint32_t)(lane + 64 * k);
+                    ncand[u] += __popcll(bm);
                 }
-#undef MGPT_BUCKET
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (KP > 1) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t key = cand[u * 64 + lane];
+                const bool have = lane < ncand[u] && ncand[u] <= 64;      // > 64 neighbours in one window: exact slow path below
+                mdm[u] = have ? (int)(key >> 16) : 2 * kR + 1;
+                cid[u] = (int)(key & 0xffffu);
+            }
+        }
+        // --- rank = position in (Manhattan, id) order (cpp:500-506) = #candidates in lower distance buckets +
+        //     #lower ids in the own bucket (candidate lanes are in id order) ---
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            mine[u] = bkt + u * 16 + mdm[u];
+            if (mdm[u] <= 2 * kR)       // divergent on purpose: same-address LDS atomics serialise, so only real neighbours issue one
+                __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(mine[u]), ((unsigned long long)bit_hi << 32) | bit_lo,
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);        // ds_or_b64, order-independent
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {   // lanes 16u .. 16u+11 prefix-sum the bucket populations of row u (DPP rows are 16 lanes wide)
+            const uint2 pop = *reinterpret_cast<const uint2 *>(bkt + (lane & (16 * U - 1)));
+            const int c = __popc(pop.x) + __popc(pop.y);
+            int incl = dpp_shr_add<0x111>(c);
+            incl = dpp_shr_add<0x112>(incl);
+            incl = dpp_shr_add<0x114>(incl);
+            incl = dpp_shr_add<0x118>(incl);
+            reinterpret_cast<uint32_t *>(bkt + (lane & (16 * U - 1)))[2] = (uint32_t)(incl - c);   // #candidates in lower buckets
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // --- the first 13 write their 10-token record (cpp:352-373, 506-512) ---
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const ss2 mys = __builtin_bit_cast(ss2, my0s[q0 + u]);
-            uint8_t *rw = row + u * (kRowImage / U);
+            const uint4 e = *mine[u];
+            const int r = __popc(e.x & lt_lo) + __popc(e.y & lt_hi) + (int)e.z;
+            const int rank = mdm[u] <= 2 * kR ? r : kNoRank;
+            if (rank < kSlots)          // divergent on purpose: <= 13 active lanes make conflict-free LDS stores
+                emit_record(row + u * kRowBytes, rank, srec[cid[u]], my0s[q0 + u]);
+        }
+        if (KP > 1) {
 #pragma unroll
-            for (int k = 0; k < KP; k++) {
-                if (rank[u][k] >= kSlots) continue;     // divergent on purpose: <= 13 active lanes make conflict-free LDS stores
-                const uint4 o = srec[lane + 64 * k];
-                const ss2 rel = __builtin_bit_cast(ss2, o.x) - mys + (ss2){kLimit, kLimit};                // not clamped (within +-5)
-                ss2 rg = __builtin_bit_cast(ss2, o.y) - mys;
-                rg = __builtin_elementwise_min(__builtin_elementwise_max(rg, (ss2){-kLimit, -kLimit}), (ss2){kLimit, kLimit}) +
-                     (ss2){kLimit, kLimit};
-                const uint32_t qa = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, rg), __builtin_bit_cast(uint32_t, rel),
-                                                          0x06040200u);                                     // {rel.r, rel.c, goal.r, goal.c}
-                uint16_t *dst = reinterpret_cast<uint16_t *>(rw + 1 + kWin * kWin + 10 * rank[u][k]);         // 2-byte aligned
-                dst[0] = (uint16_t)qa; dst[1] = (uint16_t)(qa >> 16);
-                dst[2] = (uint16_t)o.z; dst[3] = (uint16_t)(o.z >> 16);                                      // history, oldest first
-                dst[4] = (uint16_t)o.w;                                                                      // newest action, greedy bits
+            for (int u = 0; u < U; u++) {
+                if (ncand[u] <= 64) continue;                                   // wave-uniform
+                // Exact slow path (> 64 agents inside one 11x11 window, i.e. shared cells): walk the distance buckets over
+                // all passes, recomputing the tests; ranks are known as they are met.
+                const uint32_t my0 = my0s[q0 + u];
+                const uint32_t myb = my0 ^ 0x80008000u;
+                const us2 lo = __builtin_bit_cast(us2, myb) - (us2){kR, kR};
+                int placed = 0;
+#pragma unroll 1
+                for (int m = 0; m <= 2 * kR && placed < kSlots; m++) {
+#pragma unroll 1
+                    for (int k = 0; k < KP && placed < kSlots; k++) {
+                        const uint32_t bp = spos[lane + 64 * k];
+                        const us2 t = __builtin_bit_cast(us2, bp) - lo;
+                        const us2 mx = __builtin_elementwise_max(t, (us2){2 * kR, 2 * kR});
+                        const bool hit = __builtin_bit_cast(uint32_t, mx) == (uint32_t)(2 * kR) * 0x00010001u &&
+                                         (int)__builtin_amdgcn_sad_u16(bp, myb, 0u) == m;
+                        const unsigned long long bm = __builtin_amdgcn_ballot_w64(hit);
+                        const int rank = placed + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        if (hit && rank < kSlots) emit_record(row + u * kRowBytes, rank, srec[lane + 64 * k], my0);
+                        placed += __popcll(bm);
+                    }
+                }
             }
         }
         // all LDS traffic above is issued by this wave in program order; make it visible to its own reads
@@ -412,7 +443,7 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (!live[u]) break;
-            const uint32_t *row32 = reinterpret_cast<const uint32_t *>(row + u * (kRowImage / U));
+            const uint32_t *row32 = reinterpret_cast<const uint32_t *>(row + u * kRowBytes);
             const uint32_t packed = __builtin_amdgcn_alignbyte(row32[lane + 1], row32[lane], 1);   // tokens 4*lane .. 4*lane+3
             reinterpret_cast<uint32_t *>(tokens + (row0 + a_begin + wave + 4 * (q0 + u)) * 256)[lane] = packed;
         }
@@ -574,7 +605,7 @@ extern "C" int mgpt_tokenizer_generate_observations(mgpt_tokenizer *t, uint8_t *
     const int apb = big ? 64 : 16;
     const int chunks = cdiv(t->n_agents, apb);
     const size_t smem = kLutBytes + (size_t)apb * 16 + (size_t)t->n_agents * 16 + (size_t)kpp * 64 * 4 + 4 * kRowImage +
-                        (kpp == 1 ? 4 * kBktBytes : 0);
+                        4 * kBktBytes + (kpp == 1 ? 0 : 4 * kRowsInterleaved * 64 * 4);
     ProfScope ps(P_TOKENS, s);
 #define MGPT_TOKENS(KP_)                                                                                              \
     do {                                                                                                              \

@@ -144,3 +144,56 @@ def test_full_size_properties_cfg2():
         o.create_agents(pos[i].numpy(), goal[i].numpy())
         o.update_agents(pos[i].numpy(), goal[i].numpy(), np.full(n, -1, np.int32))
         assert np.array_equal(o.generate_observations(), t1[i])
+
+
+def _compare_with_oracle(grid, pos, goal, steps=3, seed=0):
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = pos.shape[0]
+    gen = orc.OracleGenerator(grid)
+    tok = BatchedTokenizer(grid, 1, n)
+    last = np.full((n,), -1, np.int32)
+    pos = pos.copy()
+    for t in range(steps):
+        dp, dg, da = _dev(pos[None], torch.int16), _dev(goal[None], torch.int16), _dev(last[None], torch.int32)
+        if t == 0:
+            tok.create_agents(dp, dg)
+            gen.create_agents(pos, goal)
+        tok.update_agents(dp, dg, da, goals_may_change=False)
+        gen.update_agents(pos, goal, last)
+        got = tok.generate_observations().cpu().numpy().reshape(n, 256)
+        assert np.array_equal(got, gen.generate_observations()), f"step {t}"
+        last = rng.integers(0, 5, (n,)).astype(np.int32)
+        pos, _ = orc.env_step(grid, pos, goal, last)
+    return tok
+
+
+@pytest.mark.parametrize("n_agents", [150, 190])
+def test_crowded_window_more_than_64_neighbours(n_agents):
+    """An open 14x14 room with 150/190 agents: windows near the middle hold > 64 agents, which takes the exact
+    slow path of the multi-pass (n_agents > 64) kernel; sparse rows of the same launch take the compacted path."""
+    grid = maps.pad(np.zeros((14, 14), np.uint8))
+    free = np.argwhere(grid == 0)
+    rng = np.random.Generator(np.random.PCG64(n_agents))
+    pos = free[rng.permutation(len(free))[:n_agents]].astype(np.int32)
+    goal = free[rng.permutation(len(free))[:n_agents]].astype(np.int32)
+    _compare_with_oracle(grid, pos, goal, steps=3, seed=n_agents)
+
+
+def test_long_corridor_needs_16bit_fields():
+    """A serpentine corridor: shortest paths far beyond 253 cells, so the one-byte fields are invalid and the
+    kernel must read the 16-bit ones (a saturated byte would change the window tokens)."""
+    h, w = 41, 40
+    g = np.zeros((h, w), np.uint8)
+    for r in range(1, h, 2):
+        g[r, :] = 1
+        g[r, (w - 1) if (r // 2) % 2 == 0 else 0] = 0
+    grid = maps.pad(g)
+    free = np.argwhere(grid == 0)
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 48
+    pos = free[rng.permutation(len(free))[:n]].astype(np.int32)
+    goal = free[rng.permutation(len(free))[:n]].astype(np.int32)
+    tok = _compare_with_oracle(grid, pos, goal, steps=3, seed=9)
+    d = tok.distance_fields()
+    assert ((d > 253) & (d < 65535)).any()
