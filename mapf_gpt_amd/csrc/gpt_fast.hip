@@ -44,6 +44,10 @@ struct ModeState {          // one precision mode
     std::vector<uint16_t *> proj_pk;
     // last-layer shortcut: new residual rows of token 255 only, [round_up(max_rows, 256)][C] fp32
     float *x_last = nullptr;
+    // PK GEMM path (C % 256 == 0: 6M, 85M): weights as MFMA-fragment streams, activations produced in the same layout
+    bool pk_gemm = false;
+    std::vector<uint16_t *> attn_pk2, proj_pk2, fc_pk2, proj2_pk2;   // [row tile][k-step][plane][lane][8]
+    uint16_t *apk = nullptr;                   // LayerNorm'ed rows in PK layout, [M/32][C/16][NP][512]
 };
 
 struct FastState {
@@ -108,7 +112,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             MGPT_LAUNCH_CHECK();
         }
         const int pkt = (int)(frags * NP * 1024 * (C == 256 ? 2 : 3));
-        if (C == 256) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
+        if (C == 256) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
         else if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
         else MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
     }
@@ -135,6 +139,33 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             }
         }
     }
+    m->pk_gemm = (C == 256 || C == 512 || C == 768 || C == 1024) && getenv("MGPT_NO_PK_GEMM") == nullptr;
+    if (m->pk_gemm) {
+        auto pack = [&](std::vector<uint16_t *> &dst, size_t off, size_t R, size_t K, float scale, int l) -> int {
+            MGPT_HIP(hipMalloc(&dst[l], R * K * NP * sizeof(uint16_t)));
+            ProfScope ps(P_PACK, nullptr);
+            hipLaunchKernelGGL((fastk::pack_pk_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)(R / 32) * (K / 16) * 64, 256)), dim3(256), 0,
+                               nullptr, g->params + off, dst[l], (int)R, (int)K, scale);
+            MGPT_LAUNCH_CHECK();
+            return MGPT_OK;
+        };
+        m->attn_pk2.assign(g->L, nullptr); m->proj_pk2.assign(g->L, nullptr); m->fc_pk2.assign(g->L, nullptr); m->proj2_pk2.assign(g->L, nullptr);
+        for (int l = 0; l < g->L; l++) {
+            const LayerOff &lo = g->layers[l];
+            if ((rc = pack(m->attn_pk2, lo.attn_w, 3 * C, C, 1.0f / m->attn[l].inv_scale, l)) != MGPT_OK) return rc;
+            if ((rc = pack(m->proj_pk2, lo.proj_w, C, C, 1.0f / m->proj[l].inv_scale, l)) != MGPT_OK) return rc;
+            if (!m->mlp_fused) {
+                if ((rc = pack(m->fc_pk2, lo.fc_w, 4 * C, C, 1.0f / m->fc[l].inv_scale, l)) != MGPT_OK) return rc;
+                if ((rc = pack(m->proj2_pk2, lo.proj2_w, C, 4 * C, 1.0f / m->proj2[l].inv_scale, l)) != MGPT_OK) return rc;
+            }
+        }
+        const int lds = (NP == 2 ? 4 : 6) * 16 * NP * 1024;
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipMalloc(&m->apk, (size_t)g->max_rows * kT * C * NP * sizeof(uint16_t)));
+    }
     {
         const size_t nl = (size_t)((g->max_rows + 255) / 256) * 256 * C;
         MGPT_HIP(hipMalloc(&m->x_last, nl * sizeof(float)));
@@ -145,8 +176,9 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
     for (int p = 0; p < NP; p++) {
         MGPT_HIP(hipMalloc(&m->qk[p], 2 * M * C * sizeof(uint16_t)));
         MGPT_HIP(hipMalloc(&m->vt[p], M * C * sizeof(uint16_t)));
-        MGPT_HIP(hipMalloc(&m->y[p], M * C * sizeof(uint16_t)));
-        MGPT_HIP(hipMalloc(&m->hbuf[p], 4 * M * C * sizeof(uint16_t)));
+        if (m->pk_gemm && p > 0) continue;                                   // PK buffers interleave the planes in [0]
+        MGPT_HIP(hipMalloc(&m->y[p], M * C * (m->pk_gemm ? NP : 1) * sizeof(uint16_t)));
+        if (!m->mlp_fused) MGPT_HIP(hipMalloc(&m->hbuf[p], 4 * M * C * (m->pk_gemm ? NP : 1) * sizeof(uint16_t)));
     }
     MGPT_HIP(hipDeviceSynchronize());
     m->built = true;
@@ -160,6 +192,8 @@ void free_mode(ModeState *m)
     for (auto *p : m->mlp_pk) (void)hipFree(p);
     for (auto *p : m->qkv_pk) (void)hipFree(p);
     for (auto *p : m->proj_pk) (void)hipFree(p);
+    for (auto *v : {&m->attn_pk2, &m->proj_pk2, &m->fc_pk2, &m->proj2_pk2}) for (auto *p : *v) (void)hipFree(p);
+    (void)hipFree(m->apk);
     (void)hipFree(m->stats);
     (void)hipFree(m->x_last);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
@@ -185,6 +219,34 @@ int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
         set_error("gemm16: N=%d unsupported for C=%d", a.N, C);
         return MGPT_ERR_UNSUPPORTED;
     }
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+template <class T, int NP, int EPI>
+int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
+{
+    constexpr int NST = (NP == 2) ? 4 : 6;
+    MGPT_REQUIRE(a.M % 256 == 0 && a.N % 256 == 0 && a.K % 32 == 0 && a.K >= 16 * NST, MGPT_ERR_UNSUPPORTED,
+                 "gemm_pk shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    a.n_tiles_n = a.N / 256;
+    if (EPI == fastk::EPI_RESID) a.stats_out = nullptr;               // rows span two waves: stats come from row_stats_kernel
+    hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(256),
+                       (size_t)NST * 16 * NP * 1024, s, a);
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+template <class T, int NP>
+int launch_ln_pack(const float *x, const float *gain, uint16_t *out, int64_t M, int C, hipStream_t s)
+{
+    ProfScope ps(P_LAYERNORM, s);
+    const dim3 grid((unsigned)(M / 32));
+    if (C == 256) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 4>), grid, dim3(256), 0, s, x, gain, out, C);
+    else if (C == 512) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 8>), grid, dim3(256), 0, s, x, gain, out, C);
+    else if (C == 768) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 12>), grid, dim3(256), 0, s, x, gain, out, C);
+    else if (C == 1024) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 16>), grid, dim3(256), 0, s, x, gain, out, C);
+    else { set_error("ln_pack: C=%d unsupported", C); return MGPT_ERR_UNSUPPORTED; }
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
@@ -266,6 +328,15 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                 hipLaunchKernelGGL((fastk::ln_qkv_kernel<T, NP, 2>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, m->qkv_pk[l],
                                    m->attn[l].inv_scale, m->qk[0], m->qk[1], m->vt[0], m->vt[1], g->nh, g->hs, (int64_t)(M * C));
             MGPT_LAUNCH_CHECK();
+        } else if (m->pk_gemm) {
+            if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln1, m->apk, M, C, s)) != MGPT_OK) return rc;
+            ProfScope ps(P_GEMM_QKV, s);
+            const size_t tile_halves = (size_t)(C / 16) * NP * 512;          // one 32-row tile of a PK matrix with K = C
+            a.a_hi = m->apk; a.w_hi = m->attn_pk2[l];
+            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_QK>(a, s)) != MGPT_OK) return rc;
+            a.w_hi = m->attn_pk2[l] + (size_t)(2 * C / 32) * tile_halves;    // rows 2C.. of c_attn.weight: V
+            a.N = C; a.o_hi = m->vt[0]; a.o_lo = m->vt[1];
+            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_VT>(a, s)) != MGPT_OK) return rc;
         } else {
             ProfScope ps(P_GEMM_QKV, s);
             if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_QK>(a, C, s)) != MGPT_OK) return rc;
@@ -278,9 +349,9 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             ProfScope ps(P_ATTN, s);
             const uint16_t *qh = m->qk[0], *ql = m->qk[1], *kh = m->qk[0] + M * C, *kl = (NP == 2) ? m->qk[1] + M * C : nullptr;
             if (g->hs == 32)
-                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e);
+                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0);
             else
-                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e);
+                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0);
             MGPT_LAUNCH_CHECK();
         }
         // ---- attention output projection + residual (+ stats of the new rows) ----
@@ -289,9 +360,12 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         a.x_out = g->x; a.stats_out = m->stats;
         if (!proj_fused) {
             ProfScope ps(P_GEMM_PROJ, s);
-            if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
+            if (m->pk_gemm) {
+                a.w_hi = m->proj_pk2[l];
+                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
+            } else if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
-        if (!fused_stats(C) && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
+        if (!fused_stats(C) && !m->pk_gemm && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
         float *mlp_x = last_short ? m->x_last : g->x;
         const int64_t mlp_M = last_short ? (int64_t)((rows + 255) / 256) * 256 : M;
         if (m->mlp_fused) {
@@ -309,8 +383,14 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     }
                 if (abl == 1) MGPT_ABL_LAUNCH(1) else if (abl == 2) MGPT_ABL_LAUNCH(2) else if (abl == 3) MGPT_ABL_LAUNCH(3) else MGPT_ABL_LAUNCH(4)
 #undef MGPT_ABL_LAUNCH
+            } else if (C == 256 && NP == 2 && abl != 0) {
+#define MGPT_ABL_LAUNCH(A_)                                                                                                         \
+    hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 8, A_, 4, 2, 1, 4>), dim3((unsigned)(mlp_M / 128)), dim3(256), lds, s, mlp_x, P + lo.ln2, \
+                       m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)mlp_M);
+                if (abl == 1) MGPT_ABL_LAUNCH(1) else if (abl == 2) MGPT_ABL_LAUNCH(2) else if (abl == 3) MGPT_ABL_LAUNCH(3) else MGPT_ABL_LAUNCH(4)
+#undef MGPT_ABL_LAUNCH
             } else if (C == 256)
-                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1>), dim3((unsigned)(mlp_M / 128)), dim3(256), lds, s, mlp_x, P + lo.ln2,
+                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1, 4>), dim3((unsigned)(mlp_M / 128)), dim3(256), lds, s, mlp_x, P + lo.ln2,
                                    m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)mlp_M);
             else if (C == 160)
                 hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
@@ -319,6 +399,23 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                 hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 2>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
                                    m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
             MGPT_LAUNCH_CHECK();
+            continue;
+        }
+        if (m->pk_gemm) {
+            // ---- LN2 -> PK planes; FC + GELU -> hidden PK planes; proj2 + residual ----
+            if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln2, m->apk, M, C, s)) != MGPT_OK) return rc;
+            a.a_hi = m->apk; a.K = C; a.N = 4 * C; a.w_hi = m->fc_pk2[l]; a.out_scale = m->fc[l].inv_scale;
+            a.o_hi = m->hbuf[0]; a.o_pk = 1;
+            {
+                ProfScope ps(P_GEMM_FC, s);
+                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_GELU>(a, s)) != MGPT_OK) return rc;
+            }
+            a.a_hi = m->hbuf[0]; a.K = 4 * C; a.N = C; a.w_hi = m->proj2_pk2[l]; a.out_scale = m->proj2[l].inv_scale;
+            a.x_out = g->x; a.stats_out = nullptr;
+            {
+                ProfScope ps(P_GEMM_PROJ2, s);
+                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
+            }
             continue;
         }
         // ---- LN2 + FC + GELU -> hidden planes ----

@@ -29,6 +29,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kT = 256;
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
 struct F16T {
     static __device__ __forceinline__ uint16_t cvt(float v) { _Float16 x = (_Float16)v; return __builtin_bit_cast(uint16_t, x); }
     static __device__ __forceinline__ float back(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
@@ -198,6 +201,7 @@ struct GemmArgs {
     uint16_t *o_hi, *o_lo;                                           // EPI_QK: q|k planes, EPI_VT: v^T planes, EPI_GELU: h planes
     int C, n_head, hs;
     int64_t plane;                                                   // EPI_QK: elements between the q and the k plane (= M*C)
+    int o_pk;                                                        // EPI_GELU: write the hidden planes in PK layout (o_hi = base)
 };
 
 // erf(x) ~= x P(x^2) / Q(x^2) on [-4, 4] (|erf| = 1 - 1.5e-8 beyond): max abs error 4.5e-7 in fp32 arithmetic
@@ -248,6 +252,111 @@ __device__ __forceinline__ float gelu_folded(float v)
     return fmaf(hv, e, hv);
 }
 
+
+// Packed ("PK") operand layout used by gemm_pk_kernel: a matrix X[R][K] as MFMA fragments
+//   [row tile R/32][k-step K/16][plane][lane = (row % 32) + 32 * ((k % 16) / 8)][8 halves = k % 8]
+// i.e. every (tile, k-step, plane) is the 1 KiB register image of one 32x16 operand: one direct global->LDS
+// instruction moves it, one conflict-free ds_read_b128 per lane loads it.
+__device__ __forceinline__ size_t pk_off(int64_t m, int k, int pl, int KS, int NP)
+{
+    return ((((size_t)(m >> 5) * KS + (k >> 4)) * NP + pl) << 9) + ((size_t)((m & 31) + ((k & 8) << 2)) << 3) + (k & 7);
+}
+
+// Epilogues shared by gemm16_kernel and gemm_pk_kernel.  acc[i][j] is the 32x32 tile (row tile wm*TM+i, column
+// tile wn*TN+j) of the block; swapped orientation (EPI != EPI_VT): lane = token, registers = output columns.
+template <class T, int NP, int EPI, int TM, int TN, int WN>
+__device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn,
+                                                int r, int h)
+{
+    const float os = p.out_scale;
+    if (EPI == EPI_VT) {
+        // natural: lane = output column n (-> head, d), registers = tokens; 4 consecutive tokens per register quad
+        // v^T planes [rows][n_head][hs][256]
+        const int64_t b = m0 >> 8;
+        const int tb = (int)(m0 & (kT - 1));
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + (wn * TN + j) * 32 + r;                         // column inside V (n_base handled by the W pointer)
+            const int head = n / p.hs, d = n - head * p.hs;
+            const int64_t rowbase = ((b * p.n_head + head) * p.hs + d) * kT;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int t = tb + (wm * TM + i) * 32 + 8 * gq + 4 * h;
+                    const float v[4] = {acc[i][j][4 * gq] * os, acc[i][j][4 * gq + 1] * os, acc[i][j][4 * gq + 2] * os,
+                                        acc[i][j][4 * gq + 3] * os};
+                    u32x2 hi, lo;
+                    split4<T, NP>(v, hi, lo);
+                    *reinterpret_cast<u32x2 *>(p.o_hi + rowbase + t) = hi;
+                    if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + rowbase + t) = lo;
+                }
+        }
+    } else {
+        // swapped: lane = token m, registers = 4 consecutive output columns per quad
+        float rsum[TM];
+#pragma unroll
+        for (int i = 0; i < TM; i++) rsum[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int64_t m = m0 + (wm * TM + i) * 32 + r;
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int n = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h;   // first of 4 consecutive columns
+                    float v[4] = {acc[i][j][4 * gq] * os, acc[i][j][4 * gq + 1] * os, acc[i][j][4 * gq + 2] * os,
+                                  acc[i][j][4 * gq + 3] * os};
+                    if (EPI == EPI_RESID) {
+                        f32x4 *dst = reinterpret_cast<f32x4 *>(p.x_out + m * p.N + n);
+                        f32x4 cur = *dst;
+                        cur[0] += v[0]; cur[1] += v[1]; cur[2] += v[2]; cur[3] += v[3];
+                        *dst = cur;
+                        acc[i][j][4 * gq] = cur[0]; acc[i][j][4 * gq + 1] = cur[1];          // keep the new row for the stats
+                        acc[i][j][4 * gq + 2] = cur[2]; acc[i][j][4 * gq + 3] = cur[3];
+                        rsum[i] += (cur[0] + cur[1]) + (cur[2] + cur[3]);
+                    } else if (EPI == EPI_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = gelu_folded(v[e]);
+                        u32x2 hi, lo;
+                        split4<T, NP>(v, hi, lo);
+                        if (p.o_pk) {                       // hidden planes feed gemm_pk_kernel next
+                            *reinterpret_cast<u32x2 *>(p.o_hi + pk_off(m, n, 0, p.N >> 4, NP)) = hi;
+                            if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_hi + pk_off(m, n, 1, p.N >> 4, NP)) = lo;
+                        } else {
+                            *reinterpret_cast<u32x2 *>(p.o_hi + m * p.N + n) = hi;
+                            if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + m * p.N + n) = lo;
+                        }
+                    } else {   // EPI_QK: q|k planes [which][rows][n_head][256][hs]
+                        const int which = n / p.C, cc = n - which * p.C;
+                        const int head = cc / p.hs, d = cc - head * p.hs;
+                        const int64_t bb = m >> 8;
+                        const int t = (int)(m & (kT - 1));
+                        const int64_t off = (int64_t)which * p.plane + ((bb * p.n_head + head) * kT + t) * p.hs + d;
+                        u32x2 hi, lo;
+                        split4<T, NP>(v, hi, lo);
+                        *reinterpret_cast<u32x2 *>(p.o_hi + off) = hi;
+                        if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + off) = lo;
+                    }
+                }
+        }
+        if (EPI == EPI_RESID && WN == 1 && p.stats_out != nullptr) {
+            // this wave holds complete rows (BN == N): LayerNorm statistics of the NEW residual rows for the next kernel
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                float s = rsum[i] + __shfl_xor(rsum[i], 32);
+                const float mean = s / (float)p.N;
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int g = 0; g < 16; g++) { const float d = acc[i][j][g] - mean; q += d * d; }
+                q += __shfl_xor(q, 32);
+                if (h == 0) p.stats_out[m0 + (wm * TM + i) * 32 + r] = make_float2(mean, rsqrtf(q / (float)p.N + 1e-5f));
+            }
+        }
+    }
+}
 
 template <class T, int NP, int BN, int WM, int WN, int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p)
@@ -380,89 +489,203 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p)
     }
 #undef MGPT_G16_LOAD
 
-    const float os = p.out_scale;
-    if (EPI == EPI_VT) {
-        // natural: lane = output column n (-> head, d), registers = tokens; 4 consecutive tokens per register quad
-        // v^T planes [rows][n_head][hs][256]
-        const int64_t b = m0 >> 8;
-        const int tb = (int)(m0 & (kT - 1));
+    gemm16_epilogue<T, NP, EPI, TM, TN, WN>(p, acc, m0, n0, wm, wn, r, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PK GEMM (C = 256, 768: 6M and 85M shapes): both operands pre-packed as MFMA fragments (pk_off above), so
+//   * one k-step of a 256 x 256 block tile = 8 + 8 fragments (x NP planes) that go HBM/L2 -> LDS by direct
+//     global->LDS loads, 1 KiB contiguous each, through a ring of NST stages with counted vmcnt + raw s_barrier;
+//   * a wave owns a 128 x 128 sub-tile (4 x 4 MFMA tiles, 256 accumulator registers): every fragment it reads from
+//     LDS feeds 4 MFMAs (x3 in the split-fp16 mode), i.e. 64 B/clk of LDS reads per CU at full matrix rate -- the
+//     128 x BN x 32 kernel above (2 x 2 tiles, two __syncthreads per 24 MFMAs) ran at 20 % of the MFMA peak;
+//   * one wave per SIMD (512 registers), so the schedule is explicit: the next k-step's fragments are requested
+//     before this k-step's MFMAs, and the 16 accumulators are visited round-robin (3 rounds in the split mode).
+// Weights are packed once at finalize (pack_pk_kernel); activations are produced in PK layout by ln_pack_kernel
+// (LayerNorm statistics + normalise + split in one pass over x), attn16_kernel (y) and the GELU epilogue (hidden planes).
+// ---------------------------------------------------------------------------------------------
+template <class T, int NP>
+__global__ __launch_bounds__(256) void pack_pk_kernel(const float *__restrict__ w, uint16_t *__restrict__ out, int R, int K,
+                                                      float scale)
+{
+    const int KS = K >> 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (row tile, k-step, lane)
+    if (gid >= (int64_t)(R >> 5) * KS * 64) return;
+    const int lane = (int)(gid & 63), ks = (int)((gid >> 6) % KS), rt = (int)((gid >> 6) / KS);
+    const float *src = w + (size_t)(rt * 32 + (lane & 31)) * K + ks * 16 + (lane >> 5) * 8;
+    float v0[4], v1[4];
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = n0 + (wn * TN + j) * 32 + r;                         // column inside V (n_base handled by the W pointer)
-            const int head = n / p.hs, d = n - head * p.hs;
-            const int64_t rowbase = ((b * p.n_head + head) * p.hs + d) * kT;
+    for (int e = 0; e < 4; e++) { v0[e] = src[e] * scale; v1[e] = src[4 + e] * scale; }
+    u32x2 h0, l0, h1, l1;
+    split4<T, NP>(v0, h0, l0);
+    split4<T, NP>(v1, h1, l1);
+    u32x4 hi, lo;
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+    uint16_t *dst = out + (((size_t)rt * KS + ks) * NP << 9) + lane * 8;
+    *reinterpret_cast<u32x4 *>(dst) = hi;
+    if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
+}
+
+// LayerNorm + split into PK operand planes, statistics computed here: a workgroup owns one 32-token tile, every lane
+// keeps its share of the row (C/8 floats) in registers between the mean, the centred variance (two-pass, as
+// model.py:19-20 / F.layer_norm) and the normalisation, so x is read exactly once; wave w writes the whole 1 KiB
+// fragments of k-steps w, w+4, ...
+template <class T, int NP, int KSW>                        // KSW = k-steps per wave = C / 64
+__global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ x, const float *__restrict__ gain,
+                                                      uint16_t *__restrict__ out, int C)
+{
+    __shared__ float red[2][8][32];
+    const int KS = C >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t rt = blockIdx.x, m = rt * 32 + r;
+    const float *xr = x + m * C + h * 8;
+    f32x4 va[KSW], vb[KSW];
+    float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int t = tb + (wm * TM + i) * 32 + 8 * gq + 4 * h;
-                    const float v[4] = {acc[i][j][4 * gq] * os, acc[i][j][4 * gq + 1] * os, acc[i][j][4 * gq + 2] * os,
-                                        acc[i][j][4 * gq + 3] * os};
-                    u32x2 hi, lo;
-                    split4<T, NP>(v, hi, lo);
-                    *reinterpret_cast<u32x2 *>(p.o_hi + rowbase + t) = hi;
-                    if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + rowbase + t) = lo;
-                }
-        }
-    } else {
-        // swapped: lane = token m, registers = 4 consecutive output columns per quad
-        float rsum[TM];
-#pragma unroll
-        for (int i = 0; i < TM; i++) rsum[i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int64_t m = m0 + (wm * TM + i) * 32 + r;
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int n = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h;   // first of 4 consecutive columns
-                    float v[4] = {acc[i][j][4 * gq] * os, acc[i][j][4 * gq + 1] * os, acc[i][j][4 * gq + 2] * os,
-                                  acc[i][j][4 * gq + 3] * os};
-                    if (EPI == EPI_RESID) {
-                        f32x4 *dst = reinterpret_cast<f32x4 *>(p.x_out + m * p.N + n);
-                        f32x4 cur = *dst;
-                        cur[0] += v[0]; cur[1] += v[1]; cur[2] += v[2]; cur[3] += v[3];
-                        *dst = cur;
-                        acc[i][j][4 * gq] = cur[0]; acc[i][j][4 * gq + 1] = cur[1];          // keep the new row for the stats
-                        acc[i][j][4 * gq + 2] = cur[2]; acc[i][j][4 * gq + 3] = cur[3];
-                        rsum[i] += (cur[0] + cur[1]) + (cur[2] + cur[3]);
-                    } else if (EPI == EPI_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = gelu_folded(v[e]);
-                        u32x2 hi, lo;
-                        split4<T, NP>(v, hi, lo);
-                        *reinterpret_cast<u32x2 *>(p.o_hi + m * p.N + n) = hi;
-                        if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + m * p.N + n) = lo;
-                    } else {   // EPI_QK: q|k planes [which][rows][n_head][256][hs]
-                        const int which = n / p.C, cc = n - which * p.C;
-                        const int head = cc / p.hs, d = cc - head * p.hs;
-                        const int64_t bb = m >> 8;
-                        const int t = (int)(m & (kT - 1));
-                        const int64_t off = (int64_t)which * p.plane + ((bb * p.n_head + head) * kT + t) * p.hs + d;
-                        u32x2 hi, lo;
-                        split4<T, NP>(v, hi, lo);
-                        *reinterpret_cast<u32x2 *>(p.o_hi + off) = hi;
-                        if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + off) = lo;
-                    }
-                }
-        }
-        if (EPI == EPI_RESID && WN == 1 && p.stats_out != nullptr) {
-            // this wave holds complete rows (BN == N): LayerNorm statistics of the NEW residual rows for the next kernel
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                float s = rsum[i] + __shfl_xor(rsum[i], 32);
-                const float mean = s / (float)p.N;
-                float q = 0.f;
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int g = 0; g < 16; g++) { const float d = acc[i][j][g] - mean; q += d * d; }
-                q += __shfl_xor(q, 32);
-                if (h == 0) p.stats_out[m0 + (wm * TM + i) * 32 + r] = make_float2(mean, rsqrtf(q / (float)p.N + 1e-5f));
-            }
-        }
+    for (int i = 0; i < KSW; i++) {
+        const int ks = wave + 4 * i;
+        va[i] = *reinterpret_cast<const f32x4 *>(xr + ks * 16);
+        vb[i] = *reinterpret_cast<const f32x4 *>(xr + ks * 16 + 4);
+        s += ((va[i][0] + va[i][1]) + (va[i][2] + va[i][3])) + ((vb[i][0] + vb[i][1]) + (vb[i][2] + vb[i][3]));
     }
+    red[0][wave * 2 + h][r] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) tot += red[0][k][r];
+    const float mean = tot / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < KSW; i++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float da = va[i][e] - mean, db = vb[i][e] - mean;
+            q += da * da + db * db;
+        }
+    red[1][wave * 2 + h][r] = q;
+    __syncthreads();
+    float qt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) qt += red[1][k][r];
+    const float rstd = rsqrtf(qt / (float)C + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < KSW; i++) {
+        const int ks = wave + 4 * i;
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gain + ks * 16 + h * 8), gb = *reinterpret_cast<const f32x4 *>(gain + ks * 16 + h * 8 + 4);
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v0[e] = (va[i][e] - mean) * rstd * ga[e]; v1[e] = (vb[i][e] - mean) * rstd * gb[e]; }
+        u32x2 h0, l0, h1, l1;
+        split4<T, NP>(v0, h0, l0);
+        split4<T, NP>(v1, h1, l1);
+        u32x4 hi, lo;
+        hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+        lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+        uint16_t *dst = out + (((size_t)rt * KS + ks) * NP << 9) + lane * 8;
+        *reinterpret_cast<u32x4 *>(dst) = hi;
+        if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
+    }
+}
+
+template <class T, int NP, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_pk_kernel(GemmArgs p)
+{
+    constexpr bool SWAP = (EPI != EPI_VT);
+    constexpr int NST = (NP == 2) ? 4 : 6;                 // ring depth, in k-steps
+    constexpr int STAGE = 16 * NP * 1024;                  // 8 A fragments + 8 B fragments, NP planes each
+    constexpr int PER_WAVE = 4 * NP;                       // direct-to-LDS loads a wave issues per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NST][STAGE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    // Block -> tile map, XCD-aware: hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own
+    // 4 MiB L2), so logical ids are made contiguous per XCD, and inside an XCD the ~32 concurrently running blocks form
+    // bands of 4 token tiles x all column tiles (token tile fastest): every A tile is fetched once into that L2 and hit
+    // by the other column tiles, every weight tile by the 4 token tiles.
+    const int nb = gridDim.x, ntn = p.n_tiles_n, mtn = nb / ntn;
+    int id = blockIdx.x;
+    if ((nb & 7) == 0) id = (id & 7) * (nb >> 3) + (id >> 3);
+    constexpr int GM = 4;
+    const int band = id / (GM * ntn);
+    const int gm = min(GM, mtn - band * GM);
+    const int rem = id - band * GM * ntn;
+    const int nt = rem / gm, mt = band * GM + (rem - nt * gm);
+    const int KS = p.K >> 4;
+    const unsigned char *abase = reinterpret_cast<const unsigned char *>(p.a_hi) + (size_t)mt * 8 * KS * NP * 1024 + lane * 16;
+    const unsigned char *bbase = reinterpret_cast<const unsigned char *>(p.w_hi) + (size_t)nt * 8 * KS * NP * 1024 + lane * 16;
+
+    auto issue = [&](int s_) {
+        unsigned char *dst = smem + (size_t)(s_ % NST) * STAGE;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; i++) {
+            const int c = wave + 4 * i;                    // piece = (fragment f, plane pl), c = f * NP + pl
+            const int f = c / NP, pl = c - f * NP;
+            const unsigned char *src = (f < 8) ? abase + ((size_t)(f * KS + s_) * NP + pl) * 1024
+                                               : bbase + ((size_t)((f - 8) * KS + s_) * NP + pl) * 1024;
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; s_++) issue(s_);        // K >= 16 * NST is checked by the launcher
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
+
+    u32x4 fa[2][4][NP], fb[2][4][NP];                      // [buffer][tile][plane]
+    auto fetch = [&](int s_, int buf) {
+        const unsigned char *st = smem + (size_t)(s_ % NST) * STAGE + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) {
+                fa[buf][i][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((wm * 4 + i) * NP + pl) * 1024);
+                fb[buf][i][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((8 + wn * 4 + i) * NP + pl) * 1024);
+            }
+    };
+    auto round = [&](int buf, int pa, int pb) {            // one MFMA on each of the 16 accumulators
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = SWAP ? T::mfma(fb[buf][j][pb], fa[buf][i][pa], acc[i][j]) : T::mfma(fa[buf][i][pa], fb[buf][j][pb], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step = [&](int s_, int buf) {
+        if (s_ + 1 < KS) {
+            // stage s+1 landed for everyone; everyone is done reading the slot that gets refilled below
+            if (s_ + NST - 2 < KS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s_ + NST - 1 < KS) issue(s_ + NST - 1);
+            fetch(s_ + 1, buf ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (NP == 2) {
+            // weight operand = B side when SWAP (fb), its lo plane first: lo.hi, hi.lo, hi.hi
+            round(buf, SWAP ? 0 : 1, SWAP ? 1 : 0);
+            round(buf, SWAP ? 1 : 0, SWAP ? 0 : 1);
+        }
+        round(buf, 0, 0);
+    };
+
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER_WAVE) : "memory");
+    __builtin_amdgcn_s_barrier();
+    fetch(0, 0);
+#pragma unroll 1
+    for (int s_ = 0; s_ < KS; s_ += 2) {
+        step(s_, 0);
+        step(s_ + 1, 1);
+    }
+    gemm16_epilogue<T, NP, EPI, 4, 4, 2>(p, acc, (int64_t)mt * 256, nt * 256, wm, wn, r, h);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -478,7 +701,7 @@ __global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict_
                                                      const uint16_t *__restrict__ k_hi, const uint16_t *__restrict__ k_lo,
                                                      const uint16_t *__restrict__ vt_hi, const uint16_t *__restrict__ vt_lo,
                                                      uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo, int n_head,
-                                                     float scale_log2e)
+                                                     float scale_log2e, int y_pk)
 {
     constexpr int KRS = (HS + 8) * 2;           // K row stride in bytes  (80 for HS = 32)
     constexpr int VRS = (kT + 8) * 2;           // V^T row stride in bytes (528)
@@ -588,8 +811,15 @@ __global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict_
                 const float v[4] = {o[dt][4 * gq] * inv, o[dt][4 * gq + 1] * inv, o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv};
                 u32x2 hi, lo;
                 split4<T, NP>(v, hi, lo);
-                *reinterpret_cast<u32x2 *>(y_hi + yrow + dt * 32 + 8 * gq + 4 * h) = hi;
-                if (NP == 2) *reinterpret_cast<u32x2 *>(y_lo + yrow + dt * 32 + 8 * gq + 4 * h) = lo;
+                if (y_pk) {                                 // y feeds gemm_pk_kernel: PK layout, y_hi = base
+                    const int64_t m = (int64_t)b * kT + qt * 32 + r;
+                    const int n = head * HS + dt * 32 + 8 * gq + 4 * h;
+                    *reinterpret_cast<u32x2 *>(y_hi + pk_off(m, n, 0, C >> 4, NP)) = hi;
+                    if (NP == 2) *reinterpret_cast<u32x2 *>(y_hi + pk_off(m, n, 1, C >> 4, NP)) = lo;
+                } else {
+                    *reinterpret_cast<u32x2 *>(y_hi + yrow + dt * 32 + 8 * gq + 4 * h) = hi;
+                    if (NP == 2) *reinterpret_cast<u32x2 *>(y_lo + yrow + dt * 32 + 8 * gq + 4 * h) = lo;
+                }
             }
     }
 }
@@ -650,13 +880,12 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
 }
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 // ABL: timing ablations for tools/ (results are WRONG unless ABL == 0): 1 no GELU, 2 no weight streaming,
 //      3 no c_proj MFMAs, 4 no c_fc MFMAs
-// C = 256 (6M) instantiates NW = 4, NBUF = 2, MINW = 1: the row block needs ~330 registers, i.e. one wave per SIMD.
-template <class T, int NP, int CT, int ABL = 0, int NW = 8, int NBUF = 3, int MINW = 2>
+// C = 256 (6M) instantiates NW = 4, NBUF = 2, MINW = 1, NCH = 4: the row block needs ~330 registers, i.e. one wave per SIMD;
+// with no partner wave to fill the matrix pipe, NCH = 4 independent accumulator chains (instead of 2) keep dependent MFMAs apart.
+template <class T, int NP, int CT, int ABL = 0, int NW = 8, int NBUF = 3, int MINW = 2, int NCH = 2>
 __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                             const uint16_t *__restrict__ wpk, float inv1, float inv2,
                                                             float2 *__restrict__ stats_out, int M)
@@ -744,40 +973,85 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
         // Two partial accumulators (even / odd k-steps) with their MFMA passes interleaved: a 32x32x16 MFMA
         // that reads the previous one's result as C waits for its full latency (~2x the issue interval), so a
         // single dependent chain runs the matrix pipe at half rate (measured: tools/abl_mlp.sh).
-        f32x16 hacc, hacc1;
+        f32x16 hch[NCH];
 #pragma unroll
-        for (int g = 0; g < 16; g++) { hacc[g] = 0.f; hacc1[g] = 0.f; }
+        for (int c = 0; c < NCH; c++)
 #pragma unroll
-        for (int ks = 0; ks < KS; ks += 2) {
-            u32x4 w0[2], w1[2];
+            for (int g = 0; g < 16; g++) hch[c][g] = 0.f;
+        if constexpr (MINW == 1) {
+            // One wave per SIMD: nothing else fills the matrix pipe, so the order is pinned by hand -- fragments of the
+            // next group of k-steps are requested before this group's MFMAs, and each round visits the NCH chains in turn
+            // (left to itself the scheduler serialises each chain: 9 dependent MFMAs back to back, measured 3.3x slower).
+            u32x4 wq[2][NCH][2];
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++) {
-                w0[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(ks * NP + pl) * 1024);
-                w1[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + 1) * NP + pl) * 1024);
-            }
-            if (ABL != 4) {
-                if (NP == 2) {
-                    hacc = T::mfma(w0[1], xn[ks][0], hacc);
-                    hacc1 = T::mfma(w1[1], xn[ks + 1][0], hacc1);
-                    hacc = T::mfma(w0[0], xn[ks][1], hacc);
-                    hacc1 = T::mfma(w1[0], xn[ks + 1][1], hacc1);
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) wq[0][c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(c * NP + pl) * 1024);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks += NCH) {
+                const int cur = (ks / NCH) & 1;
+                if (ks + NCH < KS) {
+#pragma unroll
+                    for (int c = 0; c < NCH; c++)
+#pragma unroll
+                        for (int pl = 0; pl < NP; pl++)
+                            wq[cur ^ 1][c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + NCH + c) * NP + pl) * 1024);
                 }
-                hacc = T::mfma(w0[0], xn[ks][0], hacc);
-                hacc1 = T::mfma(w1[0], xn[ks + 1][0], hacc1);
-            } else {
-                asm volatile("" :: "v"(w0[0]), "v"(w0[NP - 1]), "v"(w1[0]), "v"(w1[NP - 1]));
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL != 4) {
+                    if (NP == 2) {
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) hch[c] = T::mfma(wq[cur][c][1], xn[ks + c][0], hch[c]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) hch[c] = T::mfma(wq[cur][c][0], xn[ks + c][1], hch[c]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) hch[c] = T::mfma(wq[cur][c][0], xn[ks + c][0], hch[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) asm volatile("" :: "v"(wq[cur][c][0]), "v"(wq[cur][c][NP - 1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        // fragment reads run one pair of k-steps ahead of the MFMAs that consume them
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < KS; ks += 2) {
-            if (ks + 2 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NP == 2 ? 6 : 2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < KS; ks += NCH) {
+                u32x4 w[NCH][2];
 #pragma unroll
-        for (int g = 0; g < 16; g++) hacc[g] += hacc1[g];
+                for (int c = 0; c < NCH; c++)
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++)
+                        w[c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + c) * NP + pl) * 1024);
+                if (ABL != 4) {
+                    if (NP == 2) {
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) hch[c] = T::mfma(w[c][1], xn[ks + c][0], hch[c]);
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) hch[c] = T::mfma(w[c][0], xn[ks + c][1], hch[c]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) hch[c] = T::mfma(w[c][0], xn[ks + c][0], hch[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) asm volatile("" :: "v"(w[c][0]), "v"(w[c][NP - 1]));
+                }
+            }
+            // fragment reads run one group of k-steps ahead of the MFMAs that consume them
+            __builtin_amdgcn_sched_group_barrier(0x100, NCH * NP, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks += NCH) {
+                if (ks + NCH < KS) __builtin_amdgcn_sched_group_barrier(0x100, NCH * NP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NCH * (NP == 2 ? 3 : 1), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x16 hacc = hch[0];
+#pragma unroll
+        for (int c = 1; c < NCH; c++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) hacc[g] += hch[c][g];
         u32x4 hf[2][2];                                    // [kk][plane]: B operand of c_proj
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
@@ -795,36 +1069,74 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
         }
         // ---- c_proj: for each kk the CT output tiles are independent accumulators; interleave them pairwise ----
         constexpr int NG = 2 * CT;                         // (kk, j) groups, visited kk-major so neighbours differ in j
+        static_assert(NG % NCH == 0 && KS % NCH == 0, "chain count must divide the k-steps and the output groups");
+        if constexpr (MINW == 1) {
+            u32x4 wq[2][NCH][2];
 #pragma unroll
-        for (int gi = 0; gi < NG; gi += 2) {
-            const int kk0 = gi / CT, j0 = gi % CT;
-            const int kk1 = (gi + 1 < NG) ? (gi + 1) / CT : kk0, j1 = (gi + 1 < NG) ? (gi + 1) % CT : j0;
-            u32x4 w0[2], w1[2];
+            for (int c = 0; c < NCH; c++)
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++) {
-                w0[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((KS + 2 * j0 + kk0) * NP + pl) * 1024);
-                w1[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((KS + 2 * j1 + kk1) * NP + pl) * 1024);
-            }
-            if (ABL != 3) {
-                if (NP == 2) {
-                    acc[j0] = T::mfma(w0[1], hf[kk0][0], acc[j0]);
-                    if (gi + 1 < NG) acc[j1] = T::mfma(w1[1], hf[kk1][0], acc[j1]);
-                    acc[j0] = T::mfma(w0[0], hf[kk0][1], acc[j0]);
-                    if (gi + 1 < NG) acc[j1] = T::mfma(w1[0], hf[kk1][1], acc[j1]);
+                for (int pl = 0; pl < NP; pl++)
+                    wq[0][c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((KS + 2 * (c % CT) + c / CT) * NP + pl) * 1024);
+#pragma unroll
+            for (int gi = 0; gi < NG; gi += NCH) {
+                const int cur = (gi / NCH) & 1;
+                if (gi + NCH < NG) {
+#pragma unroll
+                    for (int c = 0; c < NCH; c++)
+#pragma unroll
+                        for (int pl = 0; pl < NP; pl++)
+                            wq[cur ^ 1][c][pl] = *reinterpret_cast<const u32x4 *>(
+                                pk + (size_t)((KS + 2 * ((gi + NCH + c) % CT) + (gi + NCH + c) / CT) * NP + pl) * 1024);
                 }
-                acc[j0] = T::mfma(w0[0], hf[kk0][0], acc[j0]);
-                if (gi + 1 < NG) acc[j1] = T::mfma(w1[0], hf[kk1][0], acc[j1]);
-            } else {
-                asm volatile("" :: "v"(w0[0]), "v"(w0[NP - 1]), "v"(w1[0]), "v"(w1[NP - 1]), "v"(hf[kk0][0]));
-            }
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL != 3) {
+                    if (NP == 2) {
 #pragma unroll
-        for (int gi = 0; gi < NG; gi += 2) {
-            if (gi + 2 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
-            __builtin_amdgcn_sched_group_barrier(0x008, NP == 2 ? 6 : 2, 1);
+                        for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(wq[cur][c][1], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(wq[cur][c][0], hf[(gi + c) / CT][1], acc[(gi + c) % CT]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(wq[cur][c][0], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) asm volatile("" :: "v"(wq[cur][c][0]), "v"(wq[cur][c][NP - 1]), "v"(hf[(gi + c) / CT][0]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int gi = 0; gi < NG; gi += NCH) {
+                u32x4 w[NCH][2];
+#pragma unroll
+                for (int c = 0; c < NCH; c++)
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++)
+                        w[c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((KS + 2 * ((gi + c) % CT) + (gi + c) / CT) * NP + pl) * 1024);
+                if (ABL != 3) {
+                    if (NP == 2) {
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(w[c][1], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(w[c][0], hf[(gi + c) / CT][1], acc[(gi + c) % CT]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(w[c][0], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) asm volatile("" :: "v"(w[c][0]), "v"(w[c][NP - 1]), "v"(hf[(gi + c) / CT][0]));
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, NCH * NP, 1);
+#pragma unroll
+            for (int gi = 0; gi < NG; gi += NCH) {
+                if (gi + NCH < NG) __builtin_amdgcn_sched_group_barrier(0x100, NCH * NP, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, NCH * (NP == 2 ? 3 : 1), 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         // packet t+1 must have landed before anyone reads it; the pieces of packet t+2 issued at the top of this
         // iteration (the newest PER_WAVE of this wave) may stay in flight across the barrier.
         // (raw s_barrier: __syncthreads() would drain every outstanding LDS-DMA, cdna guide section 5)
