@@ -127,6 +127,13 @@ int mgpt_env_copy_state(mgpt_env *env, int16_t *d_pos_out, int16_t *d_goal_out, 
  * (the keys the reference's result tables use: eval_configs/05-puzzles/05-puzzles.yaml:49-58). */
 int mgpt_env_metrics(mgpt_env *env, float *d_metrics, void *stream);
 
+/* Lifelong mode (POGEMA on_target="restart", experiment_setup/create_env.py:28-32): d_goal_queue is int16
+ * [n_inst][n_agents][queue_len][2] (padded coords); an agent that ends a step on its goal takes the next entry of its
+ * queue (wrapping) and the arrival is counted; episodes then end by truncation only.  NULL / 0 switches back to
+ * on_target="nothing".  Call before mgpt_env_reset.  d_reached_out: int32 [n_inst][n_agents] arrivals so far. */
+int mgpt_env_set_lifelong(mgpt_env *env, const int16_t *d_goal_queue, int queue_len, void *stream);
+int mgpt_env_lifelong_counts(mgpt_env *env, int32_t *d_reached_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Policy forward: replaces GPT.forward / GPT.act (mapf_gpt/model.py:167-189, 244-260).
  * ------------------------------------------------------------------------------------------ */

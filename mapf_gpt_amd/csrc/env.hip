@@ -13,6 +13,10 @@
 //        (a waiting agent claims its own cell).
 //   on_target = "nothing": agents stay on the grid; terminated when all stand on their goals,
 //   truncated after max_episode_steps.
+//   on_target = "restart" (lifelong, create_env.py:28-32): an agent that ends a step on its goal takes the next
+//   goal of its own pre-generated queue (mgpt_env_set_lifelong; the queue wraps) and the arrival is counted;
+//   the episode only ends by truncation.  The tokenizer sees the goal change through update_agents
+//   (observation_generator.cpp:464-477: a new cost-to-go field for that agent).
 //
 // One workgroup per instance, one thread per agent; the per-agent current/target cell ids live in
 // LDS and every conflict test is an O(n_agents) LDS scan (n_agents <= 1024), so no per-cell scratch
@@ -40,9 +44,11 @@ __global__ void env_reset_kernel(int16_t *__restrict__ pos, int16_t *__restrict_
 
 __global__ __launch_bounds__(1024) void env_step_kernel(const uint8_t *__restrict__ grids, int n_grids, int n_agents,
                                                         int H, int W, int max_steps, int16_t *__restrict__ pos,
-                                                        const int16_t *__restrict__ goal,
+                                                        int16_t *__restrict__ goal,
                                                         const int32_t *__restrict__ actions, int32_t *__restrict__ arrive,
-                                                        int32_t *__restrict__ tcount, uint8_t *__restrict__ done)
+                                                        int32_t *__restrict__ tcount, uint8_t *__restrict__ done,
+                                                        const int16_t *__restrict__ goal_queue, int queue_len,
+                                                        int32_t *__restrict__ qnext, int32_t *__restrict__ reached)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *cur = reinterpret_cast<int *>(smem);
@@ -95,14 +101,25 @@ __global__ __launch_bounds__(1024) void env_step_kernel(const uint8_t *__restric
         pos[2 * g] = (int16_t)nr; pos[2 * g + 1] = (int16_t)nc;
         const int gr = goal[2 * g], gc = goal[2 * g + 1];
         on = (nr == gr && nc == gc) ? 1 : 0;
-        const bool was_on = (pr == gr && pc == gc);
-        if (on && !was_on) arrive[g] = t_new;         // time of the (latest) arrival
-        if (!on) arrive[g] = -1;
+        if (goal_queue != nullptr) {                  // lifelong: count the arrival, take the next queued goal
+            if (on) {
+                reached[g] += 1;
+                const int q = qnext[g];
+                const int16_t *nx = goal_queue + ((size_t)g * queue_len + q) * 2;
+                goal[2 * g] = nx[0]; goal[2 * g + 1] = nx[1];
+                qnext[g] = (q + 1 == queue_len) ? 0 : q + 1;
+            }
+            on = 0;
+        } else {
+            const bool was_on = (pr == gr && pc == gc);
+            if (on && !was_on) arrive[g] = t_new;     // time of the (latest) arrival
+            if (!on) arrive[g] = -1;
+        }
     }
     const int n_on = __syncthreads_count(on);
     if (a == 0) {
         tcount[inst] = t_new;
-        if (n_on == n_agents) done[inst] = 1;
+        if (goal_queue == nullptr && n_on == n_agents) done[inst] = 1;
         else if (t_new >= max_steps) done[inst] = 2;
     }
 }
@@ -140,6 +157,9 @@ struct mgpt_env {
     int16_t *pos = nullptr, *goal = nullptr;
     int32_t *arrive = nullptr, *tcount = nullptr;
     uint8_t *done = nullptr;
+    int16_t *goal_queue = nullptr;      // lifelong: [n_inst][n_agents][queue_len][2], else NULL
+    int32_t *qnext = nullptr, *reached = nullptr;
+    int queue_len = 0;
     bool have_grids = false, have_reset = false;
 };
 
@@ -172,6 +192,7 @@ extern "C" int mgpt_env_destroy(mgpt_env *e)
     if (!e) return MGPT_OK;
     (void)hipFree(e->grids); (void)hipFree(e->pos); (void)hipFree(e->goal);
     (void)hipFree(e->arrive); (void)hipFree(e->tcount); (void)hipFree(e->done);
+    (void)hipFree(e->goal_queue); (void)hipFree(e->qnext); (void)hipFree(e->reached);
     delete e;
     return MGPT_OK;
 }
@@ -194,7 +215,39 @@ extern "C" int mgpt_env_reset(mgpt_env *e, const int16_t *d_pos, const int16_t *
     hipLaunchKernelGGL(env_reset_kernel, dim3(cdiv(total > e->n_inst ? total : e->n_inst, 256)), dim3(256), 0, s, e->pos,
                        e->goal, d_pos, d_goal, e->arrive, e->tcount, e->done, e->n_inst, e->n_agents);
     MGPT_LAUNCH_CHECK();
+    if (e->goal_queue != nullptr) {
+        const size_t total_b = (size_t)total * sizeof(int32_t);
+        MGPT_HIP(hipMemsetAsync(e->qnext, 0, total_b, s));
+        MGPT_HIP(hipMemsetAsync(e->reached, 0, total_b, s));
+    }
     e->have_reset = true;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_env_set_lifelong(mgpt_env *e, const int16_t *d_goal_queue, int queue_len, void *stream)
+{
+    MGPT_REQUIRE(e, MGPT_ERR_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipFree(e->goal_queue); (void)hipFree(e->qnext); (void)hipFree(e->reached);
+    e->goal_queue = nullptr; e->qnext = nullptr; e->reached = nullptr; e->queue_len = 0;
+    if (d_goal_queue == nullptr || queue_len <= 0) return MGPT_OK;          // back to on_target = "nothing"
+    const size_t total = (size_t)e->n_inst * e->n_agents;
+    MGPT_HIP(hipMalloc(&e->goal_queue, total * queue_len * 2 * sizeof(int16_t)));
+    MGPT_HIP(hipMalloc(&e->qnext, total * sizeof(int32_t)));
+    MGPT_HIP(hipMalloc(&e->reached, total * sizeof(int32_t)));
+    MGPT_HIP(hipMemcpyAsync(e->goal_queue, d_goal_queue, total * queue_len * 2 * sizeof(int16_t), hipMemcpyDeviceToDevice, s));
+    MGPT_HIP(hipMemsetAsync(e->qnext, 0, total * sizeof(int32_t), s));
+    MGPT_HIP(hipMemsetAsync(e->reached, 0, total * sizeof(int32_t), s));
+    e->queue_len = queue_len;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_env_lifelong_counts(mgpt_env *e, int32_t *d_reached_out, void *stream)
+{
+    MGPT_REQUIRE(e && d_reached_out, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(e->reached != nullptr, MGPT_ERR_STATE, "mgpt_env_set_lifelong must precede lifelong_counts");
+    MGPT_HIP(hipMemcpyAsync(d_reached_out, e->reached, (size_t)e->n_inst * e->n_agents * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                            (hipStream_t)stream));
     return MGPT_OK;
 }
 
@@ -207,7 +260,7 @@ extern "C" int mgpt_env_step(mgpt_env *e, const int32_t *d_actions, void *stream
     ProfScope ps(P_ENV_STEP, s);
     hipLaunchKernelGGL(env_step_kernel, dim3(e->n_inst), dim3(threads), (size_t)e->n_agents * 2 * sizeof(int), s, e->grids,
                        e->n_grids, e->n_agents, e->H, e->W, e->max_steps, e->pos, e->goal, d_actions, e->arrive,
-                       e->tcount, e->done);
+                       e->tcount, e->done, e->goal_queue, e->queue_len, e->qnext, e->reached);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }

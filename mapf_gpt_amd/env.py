@@ -37,6 +37,7 @@ class BatchedEnv:
         self.pos = torch.empty(shp, dtype=torch.int16, device=self.device)
         self.goal = torch.empty(shp, dtype=torch.int16, device=self.device)
         self.done = torch.zeros((self.n_inst,), dtype=torch.uint8, device=self.device)
+        self.lifelong = False
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -55,6 +56,25 @@ class BatchedEnv:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().mgpt_env_reset(self._h, _lib.ptr(pos), _lib.ptr(goal), _lib.stream_ptr()))
         self.sync_state()
+
+    def set_lifelong(self, goal_queue):
+        """on_target="restart": goal_queue int16 [n_inst, n_agents, Q, 2] (None -> back to "nothing").  Call before reset()."""
+        with torch.cuda.device(self.device):
+            if goal_queue is None:
+                _lib.check(_lib.lib().mgpt_env_set_lifelong(self._h, None, 0, _lib.stream_ptr()))
+                self.lifelong = False
+                return
+            q = goal_queue.to(self.device, torch.int16).contiguous()
+            assert q.dim() == 4 and tuple(q.shape[:2]) == (self.n_inst, self.n_agents) and q.shape[3] == 2
+            _lib.check(_lib.lib().mgpt_env_set_lifelong(self._h, _lib.ptr(q), int(q.shape[2]), _lib.stream_ptr()))
+            self.lifelong = True
+
+    def goals_reached(self):
+        """int32 [n_inst, n_agents]: arrivals so far (lifelong mode)."""
+        out = torch.empty((self.n_inst, self.n_agents), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_env_lifelong_counts(self._h, _lib.ptr(out), _lib.stream_ptr()))
+        return out
 
     def step(self, actions):
         assert actions.dtype == torch.int32 and actions.is_cuda and actions.numel() == self.n_inst * self.n_agents

@@ -13,7 +13,8 @@ With `torch.distributed` initialised the instances of a group are sharded over t
 metric records are gathered once (runner.gather_metrics).
 
 Result records keep the toolbox's shape: {"metrics": {...}, "env_grid_search": {...}, "algorithm": name}.
-Metric keys: CSR, ISR, SoC, makespan, ep_length (env spec: DESIGN.md section 4) and `runtime`
+Metric keys: CSR, ISR, SoC, makespan, ep_length (env spec: DESIGN.md section 4; `avg_throughput` for
+on_target="restart" runs) and `runtime`
 (seconds; the group's wall time divided by its instances -- a batched run has no per-episode clock).
 Placement is this repo's seeded generator, not POGEMA's (absent offline): numbers are comparable to
 the paper's only in distribution, not seed for seed.
@@ -29,6 +30,7 @@ import numpy as np
 from . import maps as _maps
 
 METRIC_KEYS = ("CSR", "ISR", "SoC", "makespan", "ep_length")
+LIFELONG_QUEUE = 64          # goals pre-generated per agent in on_target="restart" runs (the queue wraps)
 
 
 # ---- config handling (pure python, testable without a GPU) -------------------------------------
@@ -102,7 +104,8 @@ def tabular_view(results, view_cfg, print_fn=print):
     for r in results:
         key = tuple((k, v) for k, v in r["env_grid_search"].items() if k not in drop) + (("algorithm", r["algorithm"]),)
         rows.setdefault(key, []).append(r["metrics"])
-    cols = [k for k in list(METRIC_KEYS) + ["runtime"] if k not in drop]
+    present = set().union(*[set(r["metrics"]) for r in results]) if results else set()
+    cols = [k for k in list(METRIC_KEYS) + ["avg_throughput", "runtime"] if k not in drop and k in present]
     table = []
     for key, ms in rows.items():
         rec = OrderedDict(key)
@@ -144,8 +147,8 @@ def evaluation(evaluation_config, eval_dir=None, registry=None, precision=None, 
             algo_cfg["precision"] = precision
         algo, cfg = _build_algorithm(algo_cfg, max_rows_per_batch)
         for (n_agents, max_steps, on_target), idxs in groups.items():
-            if on_target != "nothing":
-                raise NotImplementedError(f"on_target={on_target!r}: only 'nothing' (every eval config of the reference) is built")
+            if on_target not in ("nothing", "restart"):
+                raise NotImplementedError(f"on_target={on_target!r}: 'nothing' and 'restart' (lifelong) are built")
             parsed = [registry.get(runs[i][0]["map_name"]) for i in idxs]
             frames = dict(zip(idxs, common_frame(parsed)))
             per_batch = max(1, max_rows_per_batch // n_agents)
@@ -165,14 +168,27 @@ def evaluation(evaluation_config, eval_dir=None, registry=None, precision=None, 
                     run = BatchedRunner(grids, len(mine), n_agents, algo.net, max_episode_steps=max_steps,
                                         seed=int(cfg.seed or 0), do_sample=True, precision=cfg.precision, device=cfg.device,
                                         row_offset=lo * n_agents)
-                    run.reset(torch.from_numpy(pos), torch.from_numpy(goal))
+                    queue = None
+                    if on_target == "restart":          # lifelong: a seeded queue of further goals per agent (wraps)
+                        queue = np.empty((len(mine), n_agents, LIFELONG_QUEUE, 2), np.int16)
+                        for k, i in enumerate(mine):
+                            g, s_ok, g_ok = frames[i]
+                            cells = np.argwhere(_maps.largest_component(g == 0) & g_ok)
+                            rng = np.random.Generator(np.random.PCG64([int(runs[i][0].get("seed", 0)), 0x4C4C]))
+                            queue[k] = cells[rng.integers(0, len(cells), (n_agents, LIFELONG_QUEUE))]
+                        queue = torch.from_numpy(queue)
+                    run.reset(torch.from_numpy(pos), torch.from_numpy(goal), goal_queue=queue)
                     run.run(max_steps)
                     local = run.metrics().to(torch.float32)
+                    if queue is not None:               # ISR column carries the throughput (arrivals per step) in lifelong runs
+                        local[:, 1] = run.env.goals_reached().sum(1).to(torch.float32) / float(max_steps)
                     torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 allm = gather_metrics(local, len(chunk), rank, world).cpu().numpy()
                 for k, i in enumerate(chunk):
                     m = {key: float(allm[k, j]) for j, key in enumerate(METRIC_KEYS)}
+                    if on_target == "restart":
+                        m = {"avg_throughput": m["ISR"], "ep_length": m["ep_length"]}
                     m["runtime"] = dt / max(1, len(chunk))
                     results.append({"metrics": m, "env_grid_search": runs[i][1], "algorithm": algo_name})
         del algo

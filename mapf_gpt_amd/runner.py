@@ -72,7 +72,11 @@ class BatchedRunner:
         self.t = 0
         self._pos_ptr, self._goal_ptr, _ = self.env.state_ptrs()
 
-    def reset(self, pos, goal):
+    def reset(self, pos, goal, goal_queue=None):
+        """goal_queue int16 [n_inst, n_agents, Q, 2]: lifelong mode (on_target="restart"), the tokenizer then re-checks
+        goals every step (observation_generator.cpp:464-477)."""
+        if goal_queue is not None or self.env.lifelong:
+            self.env.set_lifelong(goal_queue)
         self.env.reset(pos, goal)
         self.tok.create_agents(self.env.pos, self.env.goal)
         self.actions.fill_(-1)                                   # inference.py:140
@@ -82,7 +86,8 @@ class BatchedRunner:
         L = _lib.lib()
         s = _lib.stream_ptr()
         with torch.cuda.device(self.device):
-            _lib.check(L.mgpt_tokenizer_update_agents(self.tok._h, self._pos_ptr, self._goal_ptr, _lib.ptr(self.actions), 0, s))
+            _lib.check(L.mgpt_tokenizer_update_agents(self.tok._h, self._pos_ptr, self._goal_ptr, _lib.ptr(self.actions),
+                                                      1 if self.env.lifelong else 0, s))
             _lib.check(L.mgpt_tokenizer_generate_observations(self.tok._h, _lib.ptr(self.tokens), s))
         self.net.act_tokens(self.tokens, do_sample=self.do_sample, seed=self.seed + self.row_offset * 0x9E3779B1,
                             step=self.t, precision=self.precision, out=self.actions.view(-1))

@@ -45,3 +45,18 @@ def test_batch_composition_does_not_change_an_episode():
     m1 = [both[1]["metrics"][k] for k in ("CSR", "ISR", "SoC", "makespan", "ep_length")]
     assert both[1]["env_grid_search"]["map_name"] == "validation-random-seed-000"
     assert m0 == m1
+
+
+def test_lifelong_config_reports_throughput():
+    from mapf_gpt_amd import evaluation as ev
+    cfg = {"environment": {"name": "Environment", "on_target": "restart", "max_episode_steps": 32, "num_agents": 8,
+                           "seed": {"grid_search": [0, 1]}, "map_name": "validation-random-seed-000"},
+           "algorithms": {"A": {"name": "MAPF-GPT", "path_to_weights": "synthetic:tiny", "precision": "f16x3"}},
+           "results_views": {"T": {"type": "tabular", "drop_keys": ["seed"], "print_results": True}}}
+    lines = []
+    res = ev.evaluation(cfg, print_fn=lines.append)
+    assert len(res) == 2
+    for r in res:
+        assert set(r["metrics"]) == {"avg_throughput", "ep_length", "runtime"}
+        assert r["metrics"]["ep_length"] == 32 and r["metrics"]["avg_throughput"] >= 0.0
+    assert "avg_throughput" in lines[1]

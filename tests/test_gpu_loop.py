@@ -95,3 +95,54 @@ def test_batched_runner_teacher_forced_vs_oracle():
         last = actions.copy()
     m = run.metrics().cpu().numpy()
     assert (m[:, 4] == 10).all()
+
+
+def test_lifelong_runner_against_host_restatement():
+    """on_target="restart": goals advance along each agent's queue when reached, arrivals are counted, episodes never
+    terminate early, and the tokenizer follows every goal change (teacher-forced: device actions replayed on the host
+    with the oracle's env step + generator)."""
+    from mapf_gpt_amd.model import build_model
+    from mapf_gpt_amd.runner import BatchedRunner
+    grid, s_ok, g_ok = maps.load_named("validation-random-seed-000")
+    n_inst, n, Q, T = 3, 20, 5, 48
+    rng = np.random.Generator(np.random.PCG64(11))
+    comp = maps.largest_component(grid == 0)
+    free = np.argwhere(comp)
+    pos = np.stack([maps.place_agents(grid, n, 100 + i, component=comp)[0] for i in range(n_inst)]).astype(np.int32)
+    queue = free[rng.integers(0, len(free), (n_inst, n, Q))].astype(np.int32)          # [inst, agent, Q, 2]
+    for i in range(n_inst):                                   # first goals 1-3 cells away so that arrivals do happen
+        for a in range(n):
+            d = np.abs(free - pos[i, a]).sum(1)
+            near = free[(d >= 1) & (d <= 3)]
+            queue[i, a, 0] = near[rng.integers(0, len(near))]
+    goal = queue[:, :, 0].copy()
+    net = build_model("tiny", seed=0, max_rows=n_inst * n, precision="f32")
+    run = BatchedRunner(grid, n_inst, n, net, max_episode_steps=T, seed=5, do_sample=True)
+    run.reset(torch.from_numpy(pos.astype(np.int16)), torch.from_numpy(goal.astype(np.int16)),
+              goal_queue=torch.from_numpy(np.roll(queue, -1, axis=2).astype(np.int16)))   # next goals: entries 1, 2, ..., 0
+    nxt = np.roll(queue, -1, axis=2)
+    qn = np.zeros((n_inst, n), np.int64)
+    reached = np.zeros((n_inst, n), np.int64)
+    gens = [orc.OracleGenerator(grid) for _ in range(n_inst)]
+    for i in range(n_inst):
+        gens[i].create_agents(pos[i], goal[i])
+    last = np.full((n_inst, n), -1, np.int32)
+    for t in range(T):
+        run.step()
+        toks = run.tokens.cpu().numpy().reshape(n_inst, n, 256)
+        acts = run.actions.cpu().numpy()
+        for i in range(n_inst):
+            gens[i].update_agents(pos[i], goal[i], last[i])
+            assert np.array_equal(toks[i], gens[i].generate_observations()), f"tokens, step {t} instance {i}"
+            pos[i], _ = orc.env_step(grid, pos[i], goal[i], acts[i])
+            on = (pos[i] == goal[i]).all(1)
+            for a in np.nonzero(on)[0]:
+                reached[i, a] += 1
+                goal[i, a] = nxt[i, a, qn[i, a]]
+                qn[i, a] = (qn[i, a] + 1) % Q
+        last = acts.copy()
+        p_dev, g_dev, done = run.env.sync_state()
+        assert np.array_equal(p_dev.cpu().numpy(), pos) and np.array_equal(g_dev.cpu().numpy(), goal), f"state, step {t}"
+        assert (done.cpu().numpy() == (2 if t == T - 1 else 0)).all()
+    assert np.array_equal(run.env.goals_reached().cpu().numpy(), reached)
+    assert reached.sum() > 0
