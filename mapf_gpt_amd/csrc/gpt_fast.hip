@@ -272,7 +272,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     const int64_t M = (int64_t)rows * kT;
     const float *P = g->params;
     int rc;
-    {
+    // the first attention block can form x = wte[token] + wpe[position] itself (then no embedding kernel, no first read of x)
+    static const bool no_embed_fuse = getenv("MGPT_NO_EMBED_FUSE") != nullptr;
+    static const bool no_attn_block0 = getenv("MGPT_NO_ATTN_BLOCK") != nullptr, no_proj_fuse0 = getenv("MGPT_NO_PROJ_FUSE") != nullptr;
+    const bool embed_fused = m->qkv_fused && g->hs == 32 && m->mlp_fused && g->L > 1 && !no_embed_fuse && !no_attn_block0 && !no_proj_fuse0;
+    if (!embed_fused) {
         ProfScope ps(P_EMBED, s);
         const dim3 grid((unsigned)cdiv64(M, 4));
         if (C <= 256) hipLaunchKernelGGL((fastk::embed_stats_kernel<1>), grid, dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, m->stats, M, C);
@@ -302,20 +306,21 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             // ---- LN1 + QKV + attention (+ out-projection + residual) in one kernel: q, k, v (, y) stay on chip ----
             ProfScope ps(P_ATTN, s);
             const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 4;   // K, V^T planes + 4 weight packet slots
-#define MGPT_ATTN_BLOCK(CT_, PROJ_, LAST_)                                                                                       \
+#define MGPT_ATTN_BLOCK(CT_, PROJ_, LAST_, EMB_)                                                                                 \
     {                                                                                                                            \
         static bool once = false;                                                                                                \
         if (!once) {                                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, CT_, PROJ_, LAST_>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, CT_, PROJ_, LAST_, EMB_>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
             once = true;                                                                                                         \
         }                                                                                                                        \
-        hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, PROJ_, LAST_>), dim3((unsigned)rows), dim3(512), lds, s, g->x,  \
-                           P + lo.ln1, m->qkv_pk[l], m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e, m->proj_pk[l],   \
-                           m->proj[l].inv_scale, m->stats, m->x_last);                                                           \
+        hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, PROJ_, LAST_, EMB_>), dim3((unsigned)rows), dim3(512), lds, s,  \
+                           g->x, P + lo.ln1, m->qkv_pk[l], m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e,           \
+                           m->proj_pk[l], m->proj[l].inv_scale, m->stats, m->x_last, d_tokens, P + g->off_wte, P + g->off_wpe);  \
     }
-            if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, true) else if (proj_fused) MGPT_ATTN_BLOCK(5, true, false) else MGPT_ATTN_BLOCK(5, false, false) }
-            else { if (last_short) MGPT_ATTN_BLOCK(2, true, true) else if (proj_fused) MGPT_ATTN_BLOCK(2, true, false) else MGPT_ATTN_BLOCK(2, false, false) }
+            const bool emb = embed_fused && l == 0;
+            if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, true, false) else if (emb) MGPT_ATTN_BLOCK(5, true, false, true) else if (proj_fused) MGPT_ATTN_BLOCK(5, true, false, false) else MGPT_ATTN_BLOCK(5, false, false, false) }
+            else { if (last_short) MGPT_ATTN_BLOCK(2, true, true, false) else if (emb) MGPT_ATTN_BLOCK(2, true, false, true) else if (proj_fused) MGPT_ATTN_BLOCK(2, true, false, false) else MGPT_ATTN_BLOCK(2, false, false, false) }
 #undef MGPT_ATTN_BLOCK
             MGPT_LAUNCH_CHECK();
         } else if (m->qkv_fused) {

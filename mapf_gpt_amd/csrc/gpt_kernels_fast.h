@@ -1399,14 +1399,19 @@ __global__ __launch_bounds__(256) void pack_cols_perm_kernel(const float *__rest
 // LAST (needs PROJ): last layer -- only position 255 feeds ln_f and the head (model.py:186), so only K and V are
 // needed for all tokens; q, the attention, c_proj and the residual run for the wave that owns token 255 only, and
 // the new row of token 255 goes to the compact buffer x_last[row][C] (the MLP and the head then run on that).
-template <class T, int NP, int CT, bool PROJ, bool LAST = false>
+// EMBED (first layer): the residual row is not read from x but formed here as wte[token] + wpe[position]
+// (model.py:171-175), which removes the embedding kernel's write and this kernel's first read of x.
+template <class T, int NP, int CT, bool PROJ, bool LAST = false, bool EMBED = false>
 __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                              const uint16_t *__restrict__ wpk, float inv_scale,
                                                              uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo,
                                                              int n_head, float scale_log2e,
                                                              const uint16_t *__restrict__ ppk, float inv_scale_p,
-                                                             float2 *__restrict__ stats_out, float *__restrict__ x_last)
+                                                             float2 *__restrict__ stats_out, float *__restrict__ x_last,
+                                                             const uint8_t *__restrict__ tokens, const float *__restrict__ wte,
+                                                             const float *__restrict__ wpe)
 {
+    static_assert(!EMBED || (PROJ && !LAST), "EMBED is the first layer of a model with more than one layer");
     static_assert(!LAST || PROJ, "LAST implies PROJ");
     constexpr int C = CT * 32, KS = C / 16, NW = 8, HS = 32;
     constexpr int F = KS * NP, PKT = F * 1024, PER_WAVE = (F + NW - 1) / NW;
@@ -1420,6 +1425,8 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
     const int64_t b = blockIdx.x;
     const int tok0 = wave * 32;
     float *xrow = x + (b * kT + tok0 + r) * C;
+    const float *erow = EMBED ? wte + (size_t)tokens[b * kT + tok0 + r] * C : nullptr;   // token embedding row of this lane's token
+    const float *prow = EMBED ? wpe + (size_t)(tok0 + r) * C : nullptr;                   // position embedding row
     const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(wpk);
     const unsigned char *psrc = reinterpret_cast<const unsigned char *>(ppk);
     static_assert(2 * CT * NP == F, "c_proj slice packet has the same size as a c_attn tile packet");
@@ -1453,7 +1460,9 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
         for (int j = 0; j < CT; j++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+                const int off = 32 * j + 8 * gq + 4 * h;
+                const f32x4 v = EMBED ? *reinterpret_cast<const f32x4 *>(erow + off) + *reinterpret_cast<const f32x4 *>(prow + off)
+                                      : *reinterpret_cast<const f32x4 *>(xrow + off);
                 xv[j][4 * gq] = v[0]; xv[j][4 * gq + 1] = v[1]; xv[j][4 * gq + 2] = v[2]; xv[j][4 * gq + 3] = v[3];
                 s += (v[0] + v[1]) + (v[2] + v[3]);
             }
@@ -1656,7 +1665,9 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
         for (int j = 0; j < CT; j++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
-                f32x4 cur = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+                const int off = 32 * j + 8 * gq + 4 * h;
+                f32x4 cur = EMBED ? *reinterpret_cast<const f32x4 *>(erow + off) + *reinterpret_cast<const f32x4 *>(prow + off)
+                                  : *reinterpret_cast<const f32x4 *>(xrow + off);
 #pragma unroll
                 for (int e = 0; e < 4; e++) { cur[e] += pacc[j][4 * gq + e] * inv_scale_p; pacc[j][4 * gq + e] = cur[e]; }
                 if (keep) *reinterpret_cast<f32x4 *>(orow + 32 * j + 8 * gq + 4 * h) = cur;
