@@ -16,7 +16,7 @@ cat $OUT/bench.log >> $OUT/summary.txt; tail -5 $OUT/bench.err >> $OUT/summary.t
 if [ "$1" != "quick" ]; then
   echo "== rocprofv3 kernel trace ==" | tee -a $OUT/summary.txt
   R=$PWD
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-prof > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-prof --no-tokenizer-leg > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
   python tools/rocpd_summary.py $OUT/prof/bench_results.db $OUT/kernel_stats.txt | cut -c1-210 | head -24 >> $OUT/summary.txt
 fi
 cat $OUT/summary.txt
