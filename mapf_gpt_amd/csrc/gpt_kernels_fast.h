@@ -901,6 +901,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
     float *xrow = x + m * C;
 
     // ---- stream helper: packet t -> LDS buffer (t & 1); every wave moves FRAGS*NP/4 fragment-planes of 1 KiB ----
+    auto issue_part = [&](int t, int i0, int i1) {         // pieces i0 .. i1-1 of this wave's share of packet t
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)t * PKT;
+        unsigned char *dst = smem + (size_t)(t % NBUF) * PKT;
+#pragma unroll
+        for (int i = i0; i < i1; i++) {
+            const int c = min(wave + NW * i, FRAGS * NP - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)c * 1024 + lane * 16),
+                                             (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
+        }
+    };
     auto issue = [&](int t) {
         const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)t * PKT;
         unsigned char *dst = smem + (size_t)(t % NBUF) * PKT;
@@ -967,7 +977,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
 #pragma unroll 1
     for (int t = 0; t < NT; t++) {
         // refill the buffer that was read during tile t-1 (all waves are past the barrier that ended it)
-        if (ABL != 2 && t + NBUF - 1 < NT) issue(t + NBUF - 1);
+        // (one wave per SIMD: the refill is spread over the c_fc MFMA rounds below.  s_memtime stamps showed the 16 back-to-back
+        //  1 KiB loads holding the wave at the issue stage for ~1500 of ~7600 cycles per tile; spreading them moved the stall
+        //  into the rounds without shortening the tile -- an in-order wave with no partner on its SIMD serialises matrix issue,
+        //  GELU, LDS waits and this refill, which is the real cost of the one-wave-per-SIMD shape)
+        if (MINW != 1 && ABL != 2 && t + NBUF - 1 < NT) issue(t + NBUF - 1);
+        const bool refill = MINW == 1 && ABL != 2 && t + NBUF - 1 < NT;
         const unsigned char *pk = smem + (size_t)(ABL == 2 ? 0 : (t % NBUF)) * PKT + lane * 16;
         // ---- hidden tile: c_fc output for (token r, hidden 32 t + (g&3) + 8 (g>>2) + 4 h) ----
         // Two partial accumulators (even / odd k-steps) with their MFMA passes interleaved: a 32x32x16 MFMA
@@ -979,37 +994,46 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
 #pragma unroll
             for (int g = 0; g < 16; g++) hch[c][g] = 0.f;
         if constexpr (MINW == 1) {
-            // One wave per SIMD: nothing else fills the matrix pipe, so the order is pinned by hand -- fragments of the
-            // next group of k-steps are requested before this group's MFMAs, and each round visits the NCH chains in turn
-            // (left to itself the scheduler serialises each chain: 9 dependent MFMAs back to back, measured 3.3x slower).
-            u32x4 wq[2][NCH][2];
+            // One wave per SIMD: nothing else fills the matrix pipe, so the order is pinned by hand -- fragments are
+            // requested two groups of k-steps ahead of the MFMAs that use them, each round visits the NCH chains in turn
+            // (left to itself the scheduler serialises each chain), and the packet refill rides between the rounds.
+            constexpr int NGF = KS / NCH;
+            constexpr int PPG = (PER_WAVE + 2 * NGF - 1) / (2 * NGF);              // refill pieces per slot (2 slots per group)
+            u32x4 wq[3][NCH][2];
+            auto ld = [&](int g_, int buf) {
 #pragma unroll
-            for (int c = 0; c < NCH; c++)
+                for (int c = 0; c < NCH; c++)
 #pragma unroll
-                for (int pl = 0; pl < NP; pl++) wq[0][c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(c * NP + pl) * 1024);
+                    for (int pl = 0; pl < NP; pl++)
+                        wq[buf][c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((g_ * NCH + c) * NP + pl) * 1024);
+            };
+            ld(0, 0);
+            if (NGF > 1) ld(1, 1);
 #pragma unroll
-            for (int ks = 0; ks < KS; ks += NCH) {
-                const int cur = (ks / NCH) & 1;
-                if (ks + NCH < KS) {
-#pragma unroll
-                    for (int c = 0; c < NCH; c++)
-#pragma unroll
-                        for (int pl = 0; pl < NP; pl++)
-                            wq[cur ^ 1][c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + NCH + c) * NP + pl) * 1024);
-                }
+            for (int g_ = 0; g_ < NGF; g_++) {
+                const int cur = g_ % 3, ks = g_ * NCH;
+                if (g_ + 2 < NGF) ld(g_ + 2, (g_ + 2) % 3);
                 __builtin_amdgcn_sched_barrier(0);
                 if (ABL != 4) {
                     if (NP == 2) {
 #pragma unroll
                         for (int c = 0; c < NCH; c++) hch[c] = T::mfma(wq[cur][c][1], xn[ks + c][0], hch[c]);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (refill) issue_part(t + NBUF - 1, min((2 * g_) * PPG, PER_WAVE), min((2 * g_ + 1) * PPG, PER_WAVE));
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int c = 0; c < NCH; c++) hch[c] = T::mfma(wq[cur][c][0], xn[ks + c][1], hch[c]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (refill) issue_part(t + NBUF - 1, min((2 * g_ + 1) * PPG, PER_WAVE), min((2 * g_ + 2) * PPG, PER_WAVE));
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (refill) {
+                        issue_part(t + NBUF - 1, min((2 * g_) * PPG, PER_WAVE), min((2 * g_ + 2) * PPG, PER_WAVE));
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int c = 0; c < NCH; c++) hch[c] = T::mfma(wq[cur][c][0], xn[ks + c][0], hch[c]);
                 } else {
+                    if (refill) issue_part(t + NBUF - 1, min((2 * g_) * PPG, PER_WAVE), min((2 * g_ + 2) * PPG, PER_WAVE));
 #pragma unroll
                     for (int c = 0; c < NCH; c++) asm volatile("" :: "v"(wq[cur][c][0]), "v"(wq[cur][c][NP - 1]));
                 }
@@ -1071,23 +1095,22 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
         constexpr int NG = 2 * CT;                         // (kk, j) groups, visited kk-major so neighbours differ in j
         static_assert(NG % NCH == 0 && KS % NCH == 0, "chain count must divide the k-steps and the output groups");
         if constexpr (MINW == 1) {
-            u32x4 wq[2][NCH][2];
+            constexpr int NGP = NG / NCH;
+            u32x4 wq[3][NCH][2];
+            auto ld = [&](int g_, int buf) {
 #pragma unroll
-            for (int c = 0; c < NCH; c++)
+                for (int c = 0; c < NCH; c++)
 #pragma unroll
-                for (int pl = 0; pl < NP; pl++)
-                    wq[0][c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((KS + 2 * (c % CT) + c / CT) * NP + pl) * 1024);
+                    for (int pl = 0; pl < NP; pl++)
+                        wq[buf][c][pl] = *reinterpret_cast<const u32x4 *>(
+                            pk + (size_t)((KS + 2 * ((g_ * NCH + c) % CT) + (g_ * NCH + c) / CT) * NP + pl) * 1024);
+            };
+            ld(0, 0);
+            if (NGP > 1) ld(1, 1);
 #pragma unroll
-            for (int gi = 0; gi < NG; gi += NCH) {
-                const int cur = (gi / NCH) & 1;
-                if (gi + NCH < NG) {
-#pragma unroll
-                    for (int c = 0; c < NCH; c++)
-#pragma unroll
-                        for (int pl = 0; pl < NP; pl++)
-                            wq[cur ^ 1][c][pl] = *reinterpret_cast<const u32x4 *>(
-                                pk + (size_t)((KS + 2 * ((gi + NCH + c) % CT) + (gi + NCH + c) / CT) * NP + pl) * 1024);
-                }
+            for (int g_ = 0; g_ < NGP; g_++) {
+                const int cur = g_ % 3, gi = g_ * NCH;
+                if (g_ + 2 < NGP) ld(g_ + 2, (g_ + 2) % 3);
                 __builtin_amdgcn_sched_barrier(0);
                 if (ABL != 3) {
                     if (NP == 2) {
