@@ -112,7 +112,11 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             MGPT_LAUNCH_CHECK();
         }
         const int pkt = (int)(frags * NP * 1024 * (C == 256 ? 2 : 3));
-        if (C == 256) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
+        if (C == 256) {
+            MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
+            MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_pair_kernel<T, NP, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         pkt + 8 * 2048 + 8 * 32 * 4 + 64));
+        }
         else if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
         else MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
     }
@@ -378,6 +382,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             ProfScope ps(P_MLP_FUSED, s);
             const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * (C == 256 ? 2 : 3);
             static const int abl = getenv("MGPT_MLP_ABL") ? atoi(getenv("MGPT_MLP_ABL")) : 0;   // timing experiments only
+            static const bool no_pair = getenv("MGPT_NO_MLP_PAIR") != nullptr;            // A/B: one-wave-per-SIMD kernel instead
             if (C == 160 && NP == 2 && abl != 0) {
 #define MGPT_ABL_LAUNCH(A_)                                                                                                         \
     {                                                                                                                               \
@@ -394,6 +399,14 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                        m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)mlp_M);
                 if (abl == 1) MGPT_ABL_LAUNCH(1) else if (abl == 2) MGPT_ABL_LAUNCH(2) else if (abl == 3) MGPT_ABL_LAUNCH(3) else MGPT_ABL_LAUNCH(4)
 #undef MGPT_ABL_LAUNCH
+            } else if (C == 256 && !no_pair) {
+                hipLaunchKernelGGL((fastk::mlp_pair_kernel<T, NP, 8>), dim3((unsigned)(mlp_M / 128)), dim3(512),
+                                   lds + 8 * 2048 + 8 * 32 * 4 + 64, s, mlp_x, P + lo.ln2, m->mlp_pk[l], m->fc[l].inv_scale,
+                                   m->proj2[l].inv_scale);
+                if (!m->pk_gemm && l + 1 < g->L) {                       // the pair kernel leaves no LayerNorm statistics behind
+                    MGPT_LAUNCH_CHECK();
+                    if ((rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
+                }
             } else if (C == 256)
                 hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1, 4>), dim3((unsigned)(mlp_M / 128)), dim3(256), lds, s, mlp_x, P + lo.ln2,
                                    m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)mlp_M);

@@ -1196,6 +1196,228 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused MLP block for wide rows (C = 256, the 6M shape): mlp_fused_kernel's dataflow with every 32-token tile shared by
+// a PAIR of waves, so that each wave fits 256 registers and two waves live on every SIMD (the one-wave-per-SIMD
+// instance of mlp_fused_kernel serialises matrix issue, GELU, LDS waits and the weight refill: ~7600 cycles per hidden
+// tile against 3072 cycles of MFMA work, measured with s_memtime).
+//   wave `half` of a pair holds x[:, 128 half .. +128] as operand planes (64 registers) and the output accumulators
+//   for columns 128 half .. +128 (64 registers);
+//   c_fc:   partial pre-activations over its half of K (8 k-steps); the halves are exchanged through LDS so that each
+//           wave owns the full sum for 16 of the tile's 32 hidden units (register octet `half`, i.e. k-step `half` of
+//           the c_proj slice), applies GELU and splits them;
+//   c_proj: the two octets of split hidden values are exchanged, each wave accumulates its 4 output tiles.
+// Three workgroup barriers per hidden tile (partial sums visible / hidden planes visible / ring hand-over).
+// Weight packets, ring and packing are mlp_fused_kernel's (pack_mlp_kernel); NBUF = 2.
+// ---------------------------------------------------------------------------------------------
+template <class T, int NP, int CT>
+__global__ __launch_bounds__(512, 2) void mlp_pair_kernel(float *__restrict__ x, const float *__restrict__ gain,
+                                                          const uint16_t *__restrict__ wpk, float inv1, float inv2)
+{
+    static_assert(CT % 2 == 0, "the row is split in two halves of whole 32-column tiles");
+    constexpr int C = CT * 32, KS = C / 16, NT = 4 * CT, NW = 8, HT = CT / 2, HK = KS / 2;
+    constexpr int FRAGS = KS + 2 * CT;
+    constexpr int PKT = FRAGS * NP * 1024;
+    constexpr int PER_WAVE = (FRAGS * NP + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][PKT] ring, then exchange areas
+    // exchange area R[8 waves][2 KiB]: wave w publishes its 8 fp32 partial sums per lane in R[w]; after reading R[mate] it
+    // reuses THAT region (which only it reads) for its hidden octet planes, which the mate then finds in its own R[mate's w]
+    unsigned char *xch = smem + 2 * PKT;
+    float *xstat = reinterpret_cast<float *>(xch + NW * 2048);             // [8 waves][32]: LayerNorm partials
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int half = wave & 1, mate = wave ^ 1;
+    const int64_t m = (int64_t)blockIdx.x * (NW / 2 * 32) + (wave >> 1) * 32 + r;
+    float *xrow = x + m * C + half * (C / 2);                              // this wave's half of the row
+
+    auto issue = [&](int t) {
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)t * PKT;
+        unsigned char *dst = smem + (size_t)(t & 1) * PKT;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; i++) {
+            const int c = min(wave + NW * i, FRAGS * NP - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)c * 1024 + lane * 16),
+                                             (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+
+    // ---- half row -> registers, LayerNorm with the pair's partial sums exchanged through LDS ----
+    f32x16 acc[HT];                                        // x now, output accumulators later
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < HT; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+            acc[j][4 * gq] = v[0]; acc[j][4 * gq + 1] = v[1]; acc[j][4 * gq + 2] = v[2]; acc[j][4 * gq + 3] = v[3];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    s += __shfl_xor(s, 32);
+    if (h == 0) xstat[wave * 32 + r] = s;
+    __syncthreads();
+    const float mean = (s + xstat[mate * 32 + r]) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < HT; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) { const float d = acc[j][g] - mean; q += d * d; }
+    q += __shfl_xor(q, 32);
+    __syncthreads();                                       // everyone has read the sums
+    if (h == 0) xstat[wave * 32 + r] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((q + xstat[mate * 32 + r]) / (float)C + 1e-5f);
+    u32x4 xn[HK][2];                                       // B operand of c_fc for k-steps HK*half .. +HK
+#pragma unroll
+    for (int ks = 0; ks < HK; ks++) {
+        const int j = ks >> 1, g0 = 8 * (ks & 1);
+        const float *gp = gain + half * (C / 2) + 32 * j + 8 * (g0 >> 2) + 4 * h;
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gp), gb = *reinterpret_cast<const f32x4 *>(gp + 8);
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v0[e] = (acc[j][g0 + e] - mean) * rstd * ga[e];
+            v1[e] = (acc[j][g0 + 4 + e] - mean) * rstd * gb[e];
+        }
+        u32x2 h0, l0, h1, l1;
+        split4<T, NP>(v0, h0, l0);
+        split4<T, NP>(v1, h1, l1);
+        xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
+        xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
+    }
+#pragma unroll
+    for (int j = 0; j < HT; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) acc[j][g] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // packet 0 landed
+
+#pragma unroll 1
+    for (int t = 0; t < NT; t++) {
+        if (t + 1 < NT) issue(t + 1);                      // into the buffer read during tile t-1 (everyone is past its last barrier)
+        const unsigned char *pk = smem + (size_t)(t & 1) * PKT + lane * 16;
+        // ---- c_fc over this wave's half of K: two interleaved chains (even / odd k-steps) ----
+        f32x16 hch[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) hch[c][g] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < HK; ks += 2) {
+            u32x4 w[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    w[c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((HK * half + ks + c) * NP + pl) * 1024);
+            if (NP == 2) {
+                hch[0] = T::mfma(w[0][1], xn[ks][0], hch[0]);
+                hch[1] = T::mfma(w[1][1], xn[ks + 1][0], hch[1]);
+                hch[0] = T::mfma(w[0][0], xn[ks][1], hch[0]);
+                hch[1] = T::mfma(w[1][0], xn[ks + 1][1], hch[1]);
+            }
+            hch[0] = T::mfma(w[0][0], xn[ks][0], hch[0]);
+            hch[1] = T::mfma(w[1][0], xn[ks + 1][0], hch[1]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
+#pragma unroll
+        for (int ks = 0; ks < HK; ks += 2) {
+            if (ks + 2 < HK) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NP == 2 ? 6 : 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- exchange: the octet the mate owns goes to LDS, mine stays ----
+        float mine8[8];
+        {
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                o0[e] = hch[0][8 * (1 - half) + e] + hch[1][8 * (1 - half) + e];
+                o1[e] = hch[0][8 * (1 - half) + 4 + e] + hch[1][8 * (1 - half) + 4 + e];
+            }
+            *reinterpret_cast<f32x4 *>(xch + wave * 2048 + lane * 16) = o0;
+            *reinterpret_cast<f32x4 *>(xch + wave * 2048 + 1024 + lane * 16) = o1;
+#pragma unroll
+            for (int e = 0; e < 8; e++) mine8[e] = hch[0][8 * half + e] + hch[1][8 * half + e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // B1: partial sums visible
+        {
+            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(xch + mate * 2048 + lane * 16);
+            const f32x4 p1 = *reinterpret_cast<const f32x4 *>(xch + mate * 2048 + 1024 + lane * 16);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { mine8[e] += p0[e]; mine8[4 + e] += p1[e]; }
+        }
+        u32x4 hf[2][2];                                    // [k-step kk of the c_proj slice][plane]
+        {
+            float v0[4], v1[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v0[e] = gelu_folded(mine8[e] * inv1); v1[e] = gelu_folded(mine8[4 + e] * inv1); }
+            u32x2 h0, l0, h1, l1;
+            split4<T, NP>(v0, h0, l0);
+            split4<T, NP>(v1, h1, l1);
+            u32x4 a, b;
+            a[0] = h0[0]; a[1] = h0[1]; a[2] = h1[0]; a[3] = h1[1];
+            b[0] = l0[0]; b[1] = l0[1]; b[2] = l1[0]; b[3] = l1[1];
+            *reinterpret_cast<u32x4 *>(xch + mate * 2048 + lane * 16) = a;
+            if (NP == 2) *reinterpret_cast<u32x4 *>(xch + mate * 2048 + 1024 + lane * 16) = b;
+            if (half == 0) { hf[0][0] = a; hf[0][1] = b; } else { hf[1][0] = a; hf[1][1] = b; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // B2: hidden planes visible
+        {
+            const u32x4 a = *reinterpret_cast<const u32x4 *>(xch + wave * 2048 + lane * 16);
+            u32x4 b = a;
+            if (NP == 2) b = *reinterpret_cast<const u32x4 *>(xch + wave * 2048 + 1024 + lane * 16);
+            if (half == 0) { hf[1][0] = a; hf[1][1] = b; } else { hf[0][0] = a; hf[0][1] = b; }
+        }
+        // ---- c_proj for output tiles HT*half .. +HT: (kk, j) groups pairwise, neighbours differ in j ----
+        constexpr int NG = 2 * HT;
+#pragma unroll
+        for (int gi = 0; gi < NG; gi += 2) {
+            u32x4 w[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    w[c][pl] = *reinterpret_cast<const u32x4 *>(
+                        pk + (size_t)((KS + 2 * (HT * half + (gi + c) % HT) + (gi + c) / HT) * NP + pl) * 1024);
+            if (NP == 2) {
+                acc[gi % HT] = T::mfma(w[0][1], hf[gi / HT][0], acc[gi % HT]);
+                acc[(gi + 1) % HT] = T::mfma(w[1][1], hf[(gi + 1) / HT][0], acc[(gi + 1) % HT]);
+                acc[gi % HT] = T::mfma(w[0][0], hf[gi / HT][1], acc[gi % HT]);
+                acc[(gi + 1) % HT] = T::mfma(w[1][0], hf[(gi + 1) / HT][1], acc[(gi + 1) % HT]);
+            }
+            acc[gi % HT] = T::mfma(w[0][0], hf[gi / HT][0], acc[gi % HT]);
+            acc[(gi + 1) % HT] = T::mfma(w[1][0], hf[(gi + 1) / HT][0], acc[(gi + 1) % HT]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
+#pragma unroll
+        for (int gi = 0; gi < NG; gi += 2) {
+            if (gi + 2 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, NP == 2 ? 6 : 2, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of packet t+1 landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // B3: ... everyone's; packet t and the exchange areas are free
+    }
+
+    // ---- residual add and store for this wave's half of the columns ----
+#pragma unroll
+    for (int j = 0; j < HT; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+            f32x4 cur = *dst;
+#pragma unroll
+            for (int e = 0; e < 4; e++) cur[e] += acc[j][4 * gq + e] * inv2;
+            *dst = cur;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused LayerNorm + QKV projection in the register-resident style of mlp_fused_kernel: a workgroup = one row
 // (8 waves x 32 tokens), every wave normalises its 32 tokens once, keeps them as MFMA operand planes in registers
 // and walks all 3C/32 output tiles; weight fragments stream through an LDS ring by direct global->LDS loads.
