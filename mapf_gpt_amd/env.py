@@ -149,3 +149,66 @@ class GridEnv:
             m = self._env.metrics().cpu().numpy()[0]
             infos[0]["metrics"] = {k: float(v) for k, v in zip(METRIC_KEYS, m)}   # create_env.py:18-20
         return obs, rewards, terminated, truncated, infos
+
+
+class AECEnv:
+    """Agent-environment-cycle façade over GridEnv (the PettingZoo-style surface BASELINE.json's north star names; the
+    reference itself drives POGEMA through the parallel list API, create_env.py:14-15).  Agents act in turn; the underlying
+    env steps once every agent of the cycle has supplied its action (all moves of a MAPF step are simultaneous).
+
+        env = AECEnv(map_name=..., num_agents=...); env.reset(seed=0)
+        for agent in env.agent_iter():
+            obs, reward, terminated, truncated, info = env.last()
+            env.step(None if terminated or truncated else policy(obs))
+    """
+
+    def __init__(self, **grid_env_kwargs):
+        self._env = GridEnv(**grid_env_kwargs)
+        self.possible_agents = [f"agent_{i}" for i in range(self._env.num_agents)]
+        self.agents = []
+
+    def reset(self, seed=None, options=None):
+        self._obs, _ = self._env.reset(seed=seed)
+        n = self._env.num_agents
+        self.agents = list(self.possible_agents)
+        self.rewards = {a: 0.0 for a in self.agents}
+        self.terminations = {a: False for a in self.agents}
+        self.truncations = {a: False for a in self.agents}
+        self.infos = {a: {} for a in self.agents}
+        self._pending = [0] * n
+        self._cursor = 0
+        self.agent_selection = self.agents[0]
+
+    def observe(self, agent):
+        return self._obs[self.possible_agents.index(agent)]
+
+    def last(self):
+        a = self.agent_selection
+        return self.observe(a), self.rewards[a], self.terminations[a], self.truncations[a], self.infos[a]
+
+    def agent_iter(self, max_iter=2 ** 62):
+        it = 0
+        while self.agents and it < max_iter:
+            yield self.agent_selection
+            it += 1
+
+    def step(self, action):
+        a = self.agent_selection
+        i = self.possible_agents.index(a)
+        if self.terminations[a] or self.truncations[a]:
+            if action is not None:
+                raise ValueError("a finished agent must be stepped with None")
+            self.agents.remove(a)                                     # PettingZoo: dead agents leave on their None step
+            if self.agents:
+                self._cursor %= len(self.agents)
+                self.agent_selection = self.agents[self._cursor]
+            return
+        self._pending[i] = 0 if action is None else int(action)
+        self._cursor += 1
+        if self._cursor == len(self.agents):                          # cycle complete: one simultaneous env step
+            obs, rew, term, trunc, infos = self._env.step(self._pending)
+            self._obs = obs
+            for j, ag in enumerate(self.possible_agents):
+                self.rewards[ag], self.terminations[ag], self.truncations[ag], self.infos[ag] = rew[j], term[j], trunc[j], infos[j]
+            self._cursor = 0
+        self.agent_selection = self.agents[self._cursor]

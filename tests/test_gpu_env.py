@@ -63,3 +63,31 @@ def test_grid_env_list_api_shape():
         assert len(rew) == len(term) == len(trunc) == len(infos) == 8
     assert all(trunc) and set(infos[0]["metrics"]) == {"CSR", "ISR", "SoC", "makespan", "ep_length"}
     assert infos[0]["metrics"]["ep_length"] == 5
+
+
+def test_aec_facade_matches_parallel_api():
+    """Agents acting in turn through AECEnv give the same trajectory as one GridEnv.step per cycle."""
+    from mapf_gpt_amd.env import AECEnv, GridEnv
+    kw = dict(map_name="validation-random-seed-000", num_agents=6, seed=4, max_episode_steps=12)
+    ref = GridEnv(**kw)
+    obs_ref, _ = ref.reset()
+    aec = AECEnv(**kw)
+    aec.reset()
+    rng = np.random.Generator(np.random.PCG64(1))
+    plan = rng.integers(0, 5, (12, 6))
+    t, acted, steps_seen = 0, 0, 0
+    for agent in aec.agent_iter():
+        obs, reward, terminated, truncated, info = aec.last()
+        i = aec.possible_agents.index(agent)
+        if terminated or truncated:
+            aec.step(None)
+            continue
+        assert obs["global_xy"] == obs_ref[i]["global_xy"] and obs["global_target_xy"] == obs_ref[i]["global_target_xy"]
+        aec.step(int(plan[t, i]))
+        acted += 1
+        if acted == 6:
+            obs_ref, _, term, trunc, infos = ref.step(plan[t].tolist())
+            acted, t = 0, t + 1
+            steps_seen += 1
+    assert steps_seen == 12 and not aec.agents
+    assert "metrics" in aec.infos["agent_0"] and aec.infos["agent_0"]["metrics"]["ep_length"] == 12
