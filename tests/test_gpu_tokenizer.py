@@ -65,10 +65,11 @@ def test_batched_instances_share_one_map():
         assert np.array_equal(got[:, i], case["tokens"]), f"instance slot {i}"
 
 
-@pytest.mark.parametrize("n_inst,n_agents,h,w", [(7, 24, 20, 21), (3, 130, 40, 44), (2, 1, 8, 8), (4, 70, 90, 30)])
+@pytest.mark.parametrize("n_inst,n_agents,h,w", [(7, 24, 20, 21), (3, 130, 40, 44), (2, 1, 8, 8), (4, 70, 90, 30),
+                                                  (2, 300, 48, 50), (1, 700, 64, 60), (1, 1100, 80, 72)])
 def test_many_maps_vs_oracle(n_inst, n_agents, h, w):
-    """Distinct map per instance (n_grids == n_inst), ragged agent counts (1, 70, 130: not multiples of 16/64),
-    goal changes mid-way; checker = C oracle."""
+    """Distinct map per instance (n_grids == n_inst), ragged agent counts (1, 70, 130: not multiples of 16/64; 300, 700,
+    1100: 8, 16 and 32 candidate passes per row), goal changes mid-way; checker = C oracle."""
     from mapf_gpt_amd.observation_generator import BatchedTokenizer
     rng = np.random.Generator(np.random.PCG64(n_inst * 1000 + n_agents))
     grids = np.stack([maps.pad(maps.random_map(h, w, 0.12 + 0.03 * i, 50 + i)) for i in range(n_inst)])
