@@ -184,6 +184,22 @@ int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_actions, int
                         uint64_t seed, uint64_t step, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dataset-side bulk tokenizer: replaces dataset/tokenizer/generate_observations.py:8-92 with its two native modules
+ * (cost2go.cpp:33-88 precompute_cost2go / generate_cost2go_obs, encoder.cpp:88-127 Encoder::encode) -- every
+ * (agent, timestep) of a logged episode becomes one 256-token row.
+ *   create:   d_grid uint8 [H][W] PADDED map (non-zero = blocked); builds the all-pairs BFS table of the map
+ *             (= the reference's cost2go_data dict, cached per map_name at :47-54).  Synchronises `stream` once.
+ *   tokenize: d_paths int16 [n_agents][n_steps][2] = cells visited (padded coords, get_agent_paths :159-177; the goal of an
+ *             agent is its last cell); d_tokens uint8 [n_agents][n_steps][256], agent-major like the reference's append
+ *             order (:70-90).  Lifelong logs (per-step goals, :55-60) are not supported.  Relative goals beyond +-20 are
+ *             clamped (the reference's unordered_map::at throws there).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mgpt_dataset mgpt_dataset;
+int mgpt_dataset_create(mgpt_dataset **out, const uint8_t *d_grid, int H, int W, void *stream);
+int mgpt_dataset_destroy(mgpt_dataset *ds);
+int mgpt_dataset_tokenize(mgpt_dataset *ds, int n_agents, int n_steps, const int16_t *d_paths, uint8_t *d_tokens, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Kernel timing hooks (bench.py's live roofline): when enabled, the library brackets every kernel
  * class with hipEvents on the launch stream.  mgpt_prof_read synchronises the device.
  * ------------------------------------------------------------------------------------------ */

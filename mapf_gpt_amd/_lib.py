@@ -57,6 +57,9 @@ SYMBOLS = {
     "mgpt_env_metrics": (_i, [_vp, _vp, _vp]),
     "mgpt_env_set_lifelong": (_i, [_vp, _vp, _i, _vp]),
     "mgpt_env_lifelong_counts": (_i, [_vp, _vp, _vp]),
+    "mgpt_dataset_create": (_i, [_pp, _vp, _i, _i, _vp]),
+    "mgpt_dataset_destroy": (_i, [_vp]),
+    "mgpt_dataset_tokenize": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "mgpt_gpt_create": (_i, [_pp, _i, _i, _i, _i, _i]),
     "mgpt_gpt_destroy": (_i, [_vp]),
     "mgpt_gpt_set_param": (_i, [_vp, ctypes.c_char_p, _vp, _i64, _i]),

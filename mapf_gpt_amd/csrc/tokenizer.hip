@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void bfs_kernel(const uint8_t *__restrict__ gr
     const int cells = H * W;
     const uint8_t *grid = grids + (size_t)(inst % n_grids) * cells;
     uint16_t *out = dist_all + (size_t)ag * cells;
-    uint8_t *out8 = dist8_all + (size_t)ag * cells;
+    uint8_t *out8 = dist8_all != nullptr ? dist8_all + (size_t)ag * cells : nullptr;
     uint16_t *d = kLds ? reinterpret_cast<uint16_t *>(smem) : out;
     const AgentRec r = recs[ag];
     const int tid = threadIdx.x;
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) void bfs_kernel(const uint8_t *__restrict__ gr
         if (v == kFreeUnset) v = kUnreach;
         out[i] = (uint16_t)v;
         too_long |= (v != kUnreach && v > kMaxU8Dist);
-        out8[i] = (uint8_t)(v == kUnreach ? 255 : min(v, 254));
+        if (dist8_all != nullptr) out8[i] = (uint8_t)(v == kUnreach ? 255 : min(v, 254));
     }
-    if (too_long) *u8_ok = 0;     // benign race: every writer stores 0
+    if (too_long && u8_ok != nullptr) *u8_ok = 0;     // benign race: every writer stores 0
 }
 
 // greedy-direction bits, cpp:412-430: order u(-1,0) d(+1,0) l(0,-1) r(0,+1); bit = neighbour strictly closer
@@ -464,6 +464,148 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
         tokens_body<uint16_t, KP, RPW>(recs, dist, n_agents, H, W, chunks_per_inst, tokens, smem);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dataset-side bulk tokenizer (dataset/tokenizer/generate_observations.py + cost2go.cpp + encoder.cpp): every
+// (agent, timestep) of a logged episode becomes a row.  Against the inference path above:
+//   * neighbours are ordered by the BFS distance from the OBSERVER'S cell to theirs, then id, unreachable ones dropped
+//     (generate_observations.py:121-141) -> an all-pairs table D[cell][cell] per map (cost2go.cpp:33-42 keeps the same
+//     thing as a map of matrices), built once by bfs_kernel with every cell as a source; an agent's goal field is the
+//     row D[goal cell], so no per-agent BFS is needed;
+//   * history = executed moves read off the path, 'n' before the episode starts, one 'w' at its last step (:206-228);
+//   * goal = the path's last cell (:199).
+// Rows are (timestep, agent): one "instance" per timestep, so the records of a timestep are contiguous.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ds_sources_kernel(AgentRec *__restrict__ recs, int cells, int W)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cells) return;
+    AgentRec r = {};
+    r.gr = (int16_t)(c / W); r.gc = (int16_t)(c - (c / W) * W);
+    recs[c] = r;
+}
+
+// paths int16 [n_agents][n_steps][2] -> recs [n_steps][n_agents]
+__global__ __launch_bounds__(256) void ds_records_kernel(const int16_t *__restrict__ paths, int n_agents, int n_steps, int H, int W,
+                                                         const uint16_t *__restrict__ allpairs, AgentRec *__restrict__ recs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_agents * n_steps) return;
+    const int t = i / n_agents, a = i - t * n_agents;
+    const int16_t *p = paths + (size_t)a * n_steps * 2;
+    AgentRec r;
+    r.pr = p[2 * t]; r.pc = p[2 * t + 1];
+    r.gr = p[2 * (n_steps - 1)]; r.gc = p[2 * (n_steps - 1) + 1];                  // generate_observations.py:199
+#pragma unroll
+    for (int s = 0; s < 5; s++) {                                                   // slot s <-> move index i = t - 4 + s
+        const int m = t - 4 + s;
+        int tok = TOK_N;                                                            // before the episode: 'n' (:207)
+        if (m >= 1) {
+            if (m <= min(t, n_steps - 2)) {
+                const int dr = p[2 * m] - p[2 * (m - 1)], dc = p[2 * m + 1] - p[2 * (m - 1) + 1];
+                tok = dr < 0 ? TOK_N + 2 : dr > 0 ? TOK_N + 3 : dc < 0 ? TOK_N + 4 : dc > 0 ? TOK_N + 5 : TOK_N + 1;   // u d l r w (:11-17)
+            } else {
+                tok = TOK_N + 1;                                                    // the 'w' pad of the last step (:225-228)
+            }
+        }
+        r.hist[s] = (uint8_t)tok;
+    }
+    const int cells = H * W;
+    const bool gok = r.gr >= 0 && r.gr < H && r.gc >= 0 && r.gc < W;
+    r.next = (uint8_t)(gok ? next_action_token(allpairs + (size_t)(r.gr * W + r.gc) * cells, H, W, r.pr, r.pc) : TOK_BITS0);   // :230-243
+    r.pad[0] = r.pad[1] = 0;
+    recs[i] = r;
+}
+
+constexpr int kDsAgentsPerBlock = 16;
+constexpr int kDsMaxCand = 128;
+
+// window value -> token (cost2go.cpp:72-85 + encoder.cpp:52-73): unreachable -> -80, else clamp(v - mid) to +-20 / +-40
+__device__ __forceinline__ int window_token(int v, int mid)
+{
+    if (v == kUnreach) return TOK_UNREACH;
+    const int w = v - mid;
+    return w > kLimit ? TOK_POS : (w < -kLimit ? TOK_NEG : w + kLimit);
+}
+
+__global__ __launch_bounds__(256) void ds_tokens_kernel(const AgentRec *__restrict__ recs, const uint16_t *__restrict__ allpairs,
+                                                        int n_agents, int n_steps, int H, int W, int chunks_per_step,
+                                                        uint8_t *__restrict__ tokens)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *srec = reinterpret_cast<uint4 *>(smem);                                        // [n_agents]
+    uint32_t *scand = reinterpret_cast<uint32_t *>(smem + (size_t)n_agents * 16);         // [4][kDsMaxCand]
+    uint8_t *srow = reinterpret_cast<uint8_t *>(scand + 4 * kDsMaxCand);                  // [4][272], token t at byte t + 1
+    const int t = blockIdx.x / chunks_per_step, chunk = blockIdx.x - t * chunks_per_step;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint4 *grec = reinterpret_cast<const uint4 *>(recs) + (size_t)t * n_agents;
+    for (int i = tid; i < n_agents; i += 256) srec[i] = grec[i];
+    __syncthreads();
+    uint32_t *cand = scand + wave * kDsMaxCand;
+    uint8_t *row = srow + wave * 272;
+    const int cells = H * W;
+    for (int q = 0; q < kDsAgentsPerBlock / 4; q++) {
+        const int a = chunk * kDsAgentsPerBlock + wave + 4 * q;
+        if (a >= n_agents) break;                                                         // wave-uniform
+        const uint4 me = srec[a];
+        const int pr = (int16_t)(me.x & 0xffffu), pc = (int16_t)(me.x >> 16);
+        const int gr = (int16_t)(me.y & 0xffffu), gc = (int16_t)(me.y >> 16);
+        const bool gok = gr >= 0 && gr < H && gc >= 0 && gc < W;
+        const uint16_t *dg = allpairs + (size_t)(gok ? gr * W + gc : 0) * cells;          // distance-to-goal field = a table row
+        const uint16_t *dm = allpairs + (size_t)(pr * W + pc) * cells;                    // distances from my own cell
+        if (lane < 34) reinterpret_cast<uint2 *>(row)[lane] = make_uint2(0x42424242u, 0x42424242u);
+        // --- window (cost2go.cpp:44-88) ---
+        int v[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int cell = lane + 64 * u, i = cell / kWin, j = cell - i * kWin;
+            const int rr = pr - kR + i, cc = pc - kR + j;
+            v[u] = (gok && cell < kWin * kWin && rr >= 0 && rr < H && cc >= 0 && cc < W) ? (int)dg[rr * W + cc] : kUnreach;
+        }
+        const int mid = __shfl(v[0], kR * kWin + kR);
+        // --- neighbours in the window, reachable from my cell, keyed (BFS distance, id) (:121-141) ---
+        int cnt = 0;
+        for (int b0 = 0; b0 < n_agents; b0 += 64) {
+            const int b = b0 + lane;
+            bool in = false;
+            uint32_t key = 0;
+            if (b < n_agents) {
+                const uint32_t bp = srec[b].x;
+                const int br = (int16_t)(bp & 0xffffu), bc = (int16_t)(bp >> 16);
+                if (abs(br - pr) <= kR && abs(bc - pc) <= kR && br >= 0 && br < H && bc >= 0 && bc < W) {
+                    const int d = dm[br * W + bc];
+                    in = d != kUnreach;
+                    key = ((uint32_t)d << 11) | (uint32_t)b;
+                }
+            }
+            const unsigned long long bm = __ballot(in);
+            if (in) {
+                const int at = cnt + __popcll(bm & ((1ull << lane) - 1ull));
+                if (at < kDsMaxCand) cand[at] = key;
+            }
+            cnt += __popcll(bm);
+        }
+        cnt = min(cnt, kDsMaxCand);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        row[1 + lane] = (uint8_t)window_token(v[0], mid);
+        if (lane + 64 < kWin * kWin) row[65 + lane] = (uint8_t)window_token(v[1], mid);
+        for (int c = lane; c < cnt; c += 64) {
+            const uint32_t key = cand[c];
+            int rank = 0;
+            for (int j = 0; j < cnt; j++) rank += (cand[j] < key) ? 1 : 0;
+            if (rank < kSlots) emit_record(row, rank, srec[key & 0x7ffu], me.x);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t *row32 = reinterpret_cast<const uint32_t *>(row);
+        const uint32_t packed = __builtin_amdgcn_alignbyte(row32[lane + 1], row32[lane], 1);
+        reinterpret_cast<uint32_t *>(tokens + ((size_t)a * n_steps + t) * 256)[lane] = packed;      // [agent][timestep][256]
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -649,3 +791,86 @@ extern "C" int mgpt_tokenizer_copy_state(mgpt_tokenizer *t, uint16_t *d_dist_out
                                 (hipStream_t)stream));
     return MGPT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Dataset-side bulk tokenizer: C ABI
+// ---------------------------------------------------------------------------------------------
+struct mgpt_dataset {
+    int H, W;
+    uint16_t *allpairs = nullptr;       // [H*W][H*W]
+    AgentRec *recs = nullptr;           // scratch, grows
+    size_t recs_cap = 0;
+};
+
+extern "C" int mgpt_dataset_create(mgpt_dataset **out, const uint8_t *d_grid, int H, int W, void *stream)
+{
+    MGPT_REQUIRE(out && d_grid, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(H > 0 && W > 0 && (int64_t)H * W <= 8192, MGPT_ERR_UNSUPPORTED,
+                 "H*W=%lld: the all-pairs table is built for maps up to 8192 padded cells", (long long)H * W);
+    hipStream_t s = (hipStream_t)stream;
+    mgpt_dataset *d = new mgpt_dataset();
+    d->H = H; d->W = W;
+    const int cells = H * W;
+    AgentRec *src = nullptr;
+    hipError_t e = hipMalloc(&d->allpairs, (size_t)cells * cells * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc(&src, (size_t)cells * sizeof(AgentRec));
+    if (e != hipSuccess) {
+        set_error("hipMalloc failed in mgpt_dataset_create: %s", hipGetErrorString(e));
+        (void)hipFree(src); (void)hipFree(d->allpairs); delete d;
+        return MGPT_ERR_HIP;
+    }
+    hipLaunchKernelGGL(ds_sources_kernel, dim3(cdiv(cells, 256)), dim3(256), 0, s, src, cells, W);
+    {   // one BFS field per source cell (cost2go.cpp:33-42); blocked sources are never looked up
+        ProfScope ps(P_BFS, s);
+        const size_t bytes = (size_t)cells * sizeof(uint16_t);
+        hipLaunchKernelGGL(bfs_kernel<true>, dim3(cells), dim3(256), bytes, s, d_grid, 1, cells, H, W, src, (const uint8_t *)nullptr,
+                           d->allpairs, (uint8_t *)nullptr, (int *)nullptr);
+    }
+    hipError_t le = hipGetLastError();
+    hipError_t se = hipStreamSynchronize(s);              // `src` is freed below
+    (void)hipFree(src);
+    if (le != hipSuccess || se != hipSuccess) {
+        set_error("mgpt_dataset_create: %s", hipGetErrorString(le != hipSuccess ? le : se));
+        (void)hipFree(d->allpairs); delete d;
+        return MGPT_ERR_HIP;
+    }
+    *out = d;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_dataset_destroy(mgpt_dataset *d)
+{
+    if (!d) return MGPT_OK;
+    (void)hipFree(d->allpairs); (void)hipFree(d->recs);
+    delete d;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_dataset_tokenize(mgpt_dataset *d, int n_agents, int n_steps, const int16_t *d_paths, uint8_t *d_tokens, void *stream)
+{
+    MGPT_REQUIRE(d && d_paths && d_tokens, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(n_agents > 0 && n_agents <= 2048 && n_steps > 0, MGPT_ERR_ARG, "n_agents=%d n_steps=%d", n_agents, n_steps);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)n_agents * n_steps;
+    if (total > d->recs_cap) {
+        MGPT_HIP(hipStreamSynchronize(s));
+        (void)hipFree(d->recs);
+        d->recs = nullptr; d->recs_cap = 0;
+        MGPT_HIP(hipMalloc(&d->recs, total * sizeof(AgentRec)));
+        d->recs_cap = total;
+    }
+    {
+        ProfScope ps(P_TOK_UPDATE, s);
+        hipLaunchKernelGGL(ds_records_kernel, dim3(cdiv((int)total, 256)), dim3(256), 0, s, d_paths, n_agents, n_steps, d->H, d->W,
+                           d->allpairs, d->recs);
+        MGPT_LAUNCH_CHECK();
+    }
+    const int chunks = cdiv(n_agents, kDsAgentsPerBlock);
+    const size_t smem = (size_t)n_agents * 16 + 4 * kDsMaxCand * 4 + 4 * 272;
+    ProfScope ps(P_TOKENS, s);
+    hipLaunchKernelGGL(ds_tokens_kernel, dim3(n_steps * chunks), dim3(256), smem, s, d->recs, d->allpairs, n_agents, n_steps, d->H,
+                       d->W, chunks, d_tokens);
+    MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
