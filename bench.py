@@ -164,8 +164,15 @@ def tokenizer_large_launch(grid, s_ok, g_ok, n_agents, local_rank, target_rows=5
     ach = TOKENIZER_BYTES_PER_ROW * rows / (ms / n * 1e-3) / 1e9
     del tok, out
     torch.cuda.empty_cache()
+    traffic = None                  # HBM bytes per launch from the committed PMC passes of exactly this launch shape
+    tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tf):
+        t = json.load(open(tf)).get(f"tok_generate_observations_{rows}_rows")
+        if t:
+            traffic = {"hbm_bytes_per_launch": t["fetch_corrected_x2"] + t["write"], "fetch_raw": t["fetch_raw"], "write": t["write"],
+                       "source": "profiles/r01_hbm_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 gfx950 correction)"}
     return {"kernel": "tok_generate_observations", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows,
+            "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows,
             "algorithmic_bytes_per_row": TOKENIZER_BYTES_PER_ROW,
             "note": "694 B/row = SURVEY 8d (u16 window 242 + own record 14 + 13 neighbour records 182 + uint8 row 256); the kernel "
                     "itself reads one-byte fields when every distance fits (573 B/row by its own layout)"}
