@@ -55,9 +55,19 @@ struct BF16T {
 };
 
 // hi/lo split of 4 consecutive values -> two 8-byte packets
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <class T, int NP>
 __device__ __forceinline__ void split4(const float v[4], u32x2 &hi, u32x2 &lo)
 {
+    if constexpr (NP == 1 && std::is_same<T, BF16T>::value) {
+        // single bf16 plane: the hardware's packed round-to-nearest-even conversion (same rounding as BF16T::cvt)
+        hi[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2));
+        hi[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2));
+        lo[0] = 0u; lo[1] = 0u;
+        return;
+    }
     uint16_t a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -252,6 +262,31 @@ __device__ __forceinline__ float gelu_folded(float v)
     return fmaf(hv, e, hv);
 }
 
+// gelu_folded on two values with packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32): the same operations in the same order,
+// so the same results.  Pays in the one-wave-per-SIMD GEMM epilogue, where an instruction costs ~5 cycles whatever it does
+// (tools/probe_pk.hip); the register-tight fused kernels keep the scalar form (its constants are inline literals).
+__device__ __forceinline__ f32x2 gelu_folded2(f32x2 v)
+{
+    const f32x2 u = {__builtin_amdgcn_fmed3f(v[0], -5.6568542f, 5.6568542f), __builtin_amdgcn_fmed3f(v[1], -5.6568542f, 5.6568542f)};
+    const f32x2 z = u * u;
+    f32x2 p = (f32x2)(-3.011990121e-12f);
+    p = __builtin_elementwise_fma(p, z, (f32x2)(6.122398825e-10f));
+    p = __builtin_elementwise_fma(p, z, (f32x2)(-9.285302079e-08f));
+    p = __builtin_elementwise_fma(p, z, (f32x2)(-5.031512342e-06f));
+    p = __builtin_elementwise_fma(p, z, (f32x2)(-1.299292147e-04f));
+    p = __builtin_elementwise_fma(p, z, (f32x2)(-1.044608780e-03f));
+    p = __builtin_elementwise_fma(p, z, (f32x2)(-1.138161432e-02f));
+    p *= u;
+    f32x2 q = (f32x2)(-9.103794904e-07f);
+    q = __builtin_elementwise_fma(q, z, (f32x2)(-2.667175691e-05f));
+    q = __builtin_elementwise_fma(q, z, (f32x2)(-4.207067436e-04f));
+    q = __builtin_elementwise_fma(q, z, (f32x2)(-3.686664584e-03f));
+    q = __builtin_elementwise_fma(q, z, (f32x2)(-1.426473905e-02f));
+    const f32x2 e = p * (f32x2){__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+    const f32x2 hv = 0.5f * v;
+    return __builtin_elementwise_fma(hv, e, hv);
+}
+
 
 // Packed ("PK") operand layout used by gemm_pk_kernel: a matrix X[R][K] as MFMA fragments
 //   [row tile R/32][k-step K/16][plane][lane = (row % 32) + 32 * ((k % 16) / 8)][8 halves = k % 8]
@@ -316,8 +351,13 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
                         acc[i][j][4 * gq + 2] = cur[2]; acc[i][j][4 * gq + 3] = cur[3];
                         rsum[i] += (cur[0] + cur[1]) + (cur[2] + cur[3]);
                     } else if (EPI == EPI_GELU) {
+                        if (TM * TN >= 16) {                 // one-wave-per-SIMD kernel: packed math
+                            const f32x2 g0 = gelu_folded2((f32x2){v[0], v[1]}), g1 = gelu_folded2((f32x2){v[2], v[3]});
+                            v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = gelu_folded(v[e]);
+                            for (int e = 0; e < 4; e++) v[e] = gelu_folded(v[e]);
+                        }
                         u32x2 hi, lo;
                         split4<T, NP>(v, hi, lo);
                         if (p.o_pk) {                       // hidden planes feed gemm_pk_kernel next
