@@ -164,10 +164,14 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             }
         }
         const int lds = (NP == 2 ? 4 : 6) * 16 * NP * 1024;
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipMalloc(&m->apk, (size_t)g->max_rows * kT * C * NP * sizeof(uint16_t)));
     }
     {
@@ -235,8 +239,13 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
                  "gemm_pk shape M=%d N=%d K=%d", a.M, a.N, a.K);
     a.n_tiles_n = a.N / 256;
     if (EPI == fastk::EPI_RESID) a.stats_out = nullptr;               // rows span two waves: stats come from row_stats_kernel
-    hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(256),
-                       (size_t)NST * 16 * NP * 1024, s, a);
+    static const bool four = getenv("MGPT_PK_4WAVES") != nullptr;        // A/B: one wave per SIMD with 128 x 128 wave tiles
+    if (four)
+        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 4>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(256),
+                           (size_t)NST * 16 * NP * 1024, s, a);
+    else
+        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
+                           (size_t)NST * 16 * NP * 1024, s, a);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }

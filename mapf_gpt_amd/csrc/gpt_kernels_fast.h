@@ -629,13 +629,18 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
     }
 }
 
-template <class T, int NP, int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_pk_kernel(GemmArgs p)
+// NWV = 4: one wave per SIMD, 128 x 128 per wave (512 registers).  NWV = 8: two waves per SIMD, 64 x 128 per wave (256
+// registers): 1.5x the LDS reads per MFMA, but the second wave on the SIMD covers the issue time of the ds_reads, the
+// refill loads and the epilogue's VALU work, all of which otherwise ADD to the MFMA time (tools/probe_mfma_lds*.hip:
+// 460 -> 373 ns per block k-step in bf16, against 311 ns for the MFMAs alone).
+template <class T, int NP, int EPI, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
 {
+    constexpr int TM = (NWV == 4) ? 4 : 2, TN = 4;         // MFMA tiles per wave; waves are (NWV / 2) x 2
     constexpr bool SWAP = (EPI != EPI_VT);
     constexpr int NST = (NP == 2) ? 4 : 6;                 // ring depth, in k-steps
     constexpr int STAGE = 16 * NP * 1024;                  // 8 A fragments + 8 B fragments, NP planes each
-    constexpr int PER_WAVE = 4 * NP;                       // direct-to-LDS loads a wave issues per stage
+    constexpr int PER_WAVE = 16 * NP / NWV;                // direct-to-LDS loads a wave issues per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NST][STAGE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -661,7 +666,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pk_kernel(GemmArgs p)
         unsigned char *dst = smem + (size_t)(s_ % NST) * STAGE;
 #pragma unroll
         for (int i = 0; i < PER_WAVE; i++) {
-            const int c = wave + 4 * i;                    // piece = (fragment f, plane pl), c = f * NP + pl
+            const int c = wave + NWV * i;                  // piece = (fragment f, plane pl), c = f * NP + pl
             const int f = c / NP, pl = c - f * NP;
             const unsigned char *src = (f < 8) ? abase + ((size_t)(f * KS + s_) * NP + pl) * 1024
                                                : bbase + ((size_t)((f - 8) * KS + s_) * NP + pl) * 1024;
@@ -671,30 +676,30 @@ __global__ __launch_bounds__(256, 1) void gemm_pk_kernel(GemmArgs p)
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; s_++) issue(s_);        // K >= 16 * NST is checked by the launcher
 
-    f32x16 acc[4][4];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
 
-    u32x4 fa[2][4][NP], fb[2][4][NP];                      // [buffer][tile][plane]
+    u32x4 fa[2][TM][NP], fb[2][TN][NP];                    // [buffer][tile][plane]
     auto fetch = [&](int s_, int buf) {
         const unsigned char *st = smem + (size_t)(s_ % NST) * STAGE + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int pl = 0; pl < NP; pl++) {
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++) {
-                fa[buf][i][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((wm * 4 + i) * NP + pl) * 1024);
-                fb[buf][i][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((8 + wn * 4 + i) * NP + pl) * 1024);
-            }
+            for (int i = 0; i < TM; i++) fa[buf][i][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((wm * TM + i) * NP + pl) * 1024);
+#pragma unroll
+            for (int j = 0; j < TN; j++) fb[buf][j][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((8 + wn * TN + j) * NP + pl) * 1024);
+        }
     };
-    auto round = [&](int buf, int pa, int pb) {            // one MFMA on each of the 16 accumulators
+    auto round = [&](int buf, int pa, int pb) {            // one MFMA on each of the TM x TN accumulators
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < TN; j++)
                 acc[i][j] = SWAP ? T::mfma(fb[buf][j][pb], fa[buf][i][pa], acc[i][j]) : T::mfma(fa[buf][i][pa], fb[buf][j][pb], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -725,7 +730,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pk_kernel(GemmArgs p)
         step(s_, 0);
         step(s_ + 1, 1);
     }
-    gemm16_epilogue<T, NP, EPI, 4, 4, 2>(p, acc, (int64_t)mt * 256, nt * 256, wm, wn, r, h);
+    gemm16_epilogue<T, NP, EPI, TM, TN, 2>(p, acc, (int64_t)mt * 256, nt * 256, wm, wn, r, h);
 }
 
 // ---------------------------------------------------------------------------------------------
