@@ -350,7 +350,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln1, m->apk, M, C, s)) != MGPT_OK) return rc;
             ProfScope ps(P_GEMM_QKV, s);
             const size_t tile_halves = (size_t)(C / 16) * NP * 512;          // one 32-row tile of a PK matrix with K = C
-            a.a_hi = m->apk; a.w_hi = m->attn_pk2[l];
+            a.a_hi = m->apk; a.w_hi = m->attn_pk2[l]; a.chunk_major = 1;
             if ((rc = launch_gemm_pk<T, NP, fastk::EPI_QK>(a, s)) != MGPT_OK) return rc;
             a.w_hi = m->attn_pk2[l] + (size_t)(2 * C / 32) * tile_halves;    // rows 2C.. of c_attn.weight: V
             a.N = C; a.o_hi = m->vt[0]; a.o_lo = m->vt[1];
@@ -367,9 +367,9 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             ProfScope ps(P_ATTN, s);
             const uint16_t *qh = m->qk[0], *ql = m->qk[1], *kh = m->qk[0] + M * C, *kl = (NP == 2) ? m->qk[1] + M * C : nullptr;
             if (g->hs == 32)
-                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0);
+                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
             else
-                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0);
+                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
             MGPT_LAUNCH_CHECK();
         }
         // ---- attention output projection + residual (+ stats of the new rows) ----

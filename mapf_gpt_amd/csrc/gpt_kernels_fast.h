@@ -212,6 +212,7 @@ struct GemmArgs {
     int C, n_head, hs;
     int64_t plane;                                                   // EPI_QK: elements between the q and the k plane (= M*C)
     int o_pk;                                                        // EPI_GELU: write the hidden planes in PK layout (o_hi = base)
+    int chunk_major;                                                 // EPI_QK / EPI_VT: chunk-major q|k and v^T planes (below)
 };
 
 // erf(x) ~= x P(x^2) / Q(x^2) on [-4, 4] (|erf| = 1 - 1.5e-8 beyond): max abs error 4.5e-7 in fp32 arithmetic
@@ -323,8 +324,10 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
                                         acc[i][j][4 * gq + 3] * os};
                     u32x2 hi, lo;
                     split4<T, NP>(v, hi, lo);
-                    *reinterpret_cast<u32x2 *>(p.o_hi + rowbase + t) = hi;
-                    if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + rowbase + t) = lo;
+                    // chunk-major v^T planes [rows][n_head][256/8][hs][8 tokens]: the 32 lanes (d) of a store are 512 contiguous bytes
+                    const int64_t off = p.chunk_major ? (((b * p.n_head + head) * (kT / 8) + (t >> 3)) * p.hs + d) * 8 + (t & 7) : rowbase + t;
+                    *reinterpret_cast<u32x2 *>(p.o_hi + off) = hi;
+                    if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + off) = lo;
                 }
         }
     } else {
@@ -372,7 +375,11 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
                         const int head = cc / p.hs, d = cc - head * p.hs;
                         const int64_t bb = m >> 8;
                         const int t = (int)(m & (kT - 1));
-                        const int64_t off = (int64_t)which * p.plane + ((bb * p.n_head + head) * kT + t) * p.hs + d;
+                        // chunk-major q|k planes [which][rows][n_head][hs/8][256][8 d]: the 32 lanes (tokens) x 2 halves of a store
+                        // are 512 contiguous bytes instead of 32 pieces of 16 B
+                        const int64_t off = (int64_t)which * p.plane +
+                                            (p.chunk_major ? (((bb * p.n_head + head) * (p.hs >> 3) + (d >> 3)) * kT + t) * 8 + (d & 7)
+                                                           : ((bb * p.n_head + head) * kT + t) * p.hs + d);
                         u32x2 hi, lo;
                         split4<T, NP>(v, hi, lo);
                         *reinterpret_cast<u32x2 *>(p.o_hi + off) = hi;
@@ -746,7 +753,7 @@ __global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict_
                                                      const uint16_t *__restrict__ k_hi, const uint16_t *__restrict__ k_lo,
                                                      const uint16_t *__restrict__ vt_hi, const uint16_t *__restrict__ vt_lo,
                                                      uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo, int n_head,
-                                                     float scale_log2e, int y_pk)
+                                                     float scale_log2e, int y_pk, int chunk_major)
 {
     constexpr int KRS = (HS + 8) * 2;           // K row stride in bytes  (80 for HS = 32)
     constexpr int VRS = (kT + 8) * 2;           // V^T row stride in bytes (528)
@@ -764,6 +771,18 @@ __global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict_
     const int r = lane & 31, h = lane >> 5;
 
     // stage K [256][HS] and V^T [HS][256] planes (16-byte chunks)
+    if (chunk_major) {      // planes written by the packed GEMM: [hs/8][256][8] and [256/8][hs][8]; consecutive threads read consecutive 16 B
+        for (int idx = tid; idx < NP * kT * (HS / 8); idx += 256) {
+            const int pl = idx / (kT * (HS / 8)), rem = idx - pl * (kT * (HS / 8)), c = rem / kT, row = rem - c * kT;
+            const uint16_t *src = (pl == 0 ? k_hi : k_lo) + base + (size_t)rem * 8;
+            *reinterpret_cast<u32x4 *>(sK + (size_t)pl * kT * KRS + row * KRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
+        }
+        for (int idx = tid; idx < NP * HS * (kT / 8); idx += 256) {
+            const int pl = idx / (HS * (kT / 8)), rem = idx - pl * (HS * (kT / 8)), c = rem / HS, row = rem - c * HS;
+            const uint16_t *src = (pl == 0 ? vt_hi : vt_lo) + base + (size_t)rem * 8;
+            *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VRS + row * VRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
+        }
+    } else {
     for (int idx = tid; idx < NP * kT * (HS / 8); idx += 256) {
         const int pl = idx / (kT * (HS / 8)), rem = idx - pl * (kT * (HS / 8)), row = rem / (HS / 8), c = rem - row * (HS / 8);
         const uint16_t *src = (pl == 0 ? k_hi : k_lo) + base + (size_t)row * HS + c * 8;
@@ -773,6 +792,7 @@ __global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict_
         const int pl = idx / (HS * (kT / 8)), rem = idx - pl * (HS * (kT / 8)), row = rem / (kT / 8), c = rem - row * (kT / 8);
         const uint16_t *src = (pl == 0 ? vt_hi : vt_lo) + base + (size_t)row * kT + c * 8;
         *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VRS + row * VRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
+    }
     }
     __syncthreads();
 
@@ -785,7 +805,9 @@ __global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict_
         for (int ks = 0; ks < KS; ks++)
 #pragma unroll
             for (int pl = 0; pl < NP; pl++)
-                qf[ks][pl] = *reinterpret_cast<const u32x4 *>((pl == 0 ? q_hi : q_lo) + base + (size_t)(qt * 32 + r) * HS + ks * 16 + h * 8);
+                qf[ks][pl] = *reinterpret_cast<const u32x4 *>((pl == 0 ? q_hi : q_lo) + base +
+                                                             (chunk_major ? ((size_t)(ks * 2 + h) * kT + qt * 32 + r) * 8
+                                                                          : (size_t)(qt * 32 + r) * HS + ks * 16 + h * 8));
         f32x16 o[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; dt++)
