@@ -9,10 +9,12 @@
 // Kernels (all integer, bit-exact against the reference):
 //   bfs_kernel        one 256-thread workgroup per agent, monotone relaxation in LDS    (cpp:200-286)
 //   create/update     one thread per agent                                              (cpp:391-410, 432-485)
-//   tokens_kernel     one wavefront per agent row, 4 rows in flight per wavefront, the instance's agent
+//   tokens_kernel     one wavefront per agent row, 4 rows interleaved per wavefront, the instance's agent
 //                     records staged in LDS, window gathered straight from the agent's own distance field,
-//                     neighbours ranked by ballot-bucket counting, row assembled in LDS
+//                     neighbours ranked through a distance-bucket table in LDS, row assembled in LDS
 //                                                                                        (cpp:288-311, 487-528, 352-389)
+//   ds_* kernels      dataset-side bulk tokenizer (dataset/tokenizer/*): all-pairs BFS table per map, one row per
+//                     (agent, timestep) of a logged episode
 #include "common.h"
 
 using namespace mgpt;
