@@ -117,3 +117,40 @@ class ObservationGenerator:
             for g in gt_actions(rec["metrics"]["made_actions"]):
                 self.gt_actions.extend(g)
         return self.inputs, self.gt_actions
+
+
+class Encoder:
+    """Host-side vocabulary helper with the interface of the reference's python `Encoder` (dataset/tokenizer/tokenizer.py:30-185):
+    `encode(observation dict) -> list[int]` (positions and goals clamped to +-20, :55-60), `decode(ids) -> observation dict`.
+    Pure Python; useful for inspecting rows produced by the device tokenizers.  The mask_* ablations are not implemented."""
+
+    def __init__(self, cfg=None):
+        self.cfg = cfg or InputParameters()
+        lim = self.cfg.cost2go_value_limit
+        self.coord_range = list(range(-lim, lim + 1)) + [-lim * 4, -lim * 2, lim * 2]                 # :33-39
+        self.actions_range = ["n", "w", "u", "d", "l", "r"]
+        self.next_action_range = [format(i, "04b") for i in range(16)]
+        self.vocab = {tok: i for i, tok in enumerate(self.coord_range + self.actions_range + self.next_action_range + ["!"])}
+        self.inverse_vocab = {i: tok for tok, i in self.vocab.items()}
+
+    def encode(self, observation):
+        lim = self.cfg.cost2go_value_limit
+        clamp = lambda v: max(-lim, min(lim, v))
+        out = [self.vocab[int(v)] for v in np.asarray(observation["cost2go"]).flatten()]
+        for a in observation["agents"]:
+            out += [self.vocab[clamp(a["relative_pos"][0])], self.vocab[clamp(a["relative_pos"][1])],
+                    self.vocab[clamp(a["relative_goal"][0])], self.vocab[clamp(a["relative_goal"][1])]]
+            out += [self.vocab[x] for x in a["previous_actions"]] + [self.vocab[a["next_action"]]]
+        out += [self.vocab["!"]] * (self.cfg.context_size - len(out))
+        return out
+
+    def decode(self, idx):
+        idx = [int(i) & 0xff for i in np.asarray(idx).tolist()]
+        side = 2 * self.cfg.cost2go_radius + 1
+        per = 4 + self.cfg.num_previous_actions + 1
+        agents = []
+        for i in range(self.cfg.num_agents):
+            t = [self.inverse_vocab[j] for j in idx[side * side + i * per: side * side + (i + 1) * per]]
+            agents.append({"relative_pos": (t[0], t[1]), "relative_goal": (t[2], t[3]), "previous_actions": t[4:-1], "next_action": t[-1]})
+        cost2go = np.array([self.inverse_vocab[j] for j in idx[: side * side]], dtype=object).reshape(side, side)
+        return {"agents": agents, "cost2go": cost2go}

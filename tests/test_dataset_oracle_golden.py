@@ -34,3 +34,16 @@ def test_history_padding_rules():
     assert own[6].tolist() == [49, 47, 45, 48, 48]
     assert own[7].tolist() == [47, 45, 48, 48, 45]                     # last step: the newest slot is the 'w' pad
     assert gts.tolist() == [4, 4, 2, 0, 3, 3, 1, 5]                    # the appended step is "wait in goal"
+
+
+def test_host_encoder_round_trip_on_reference_rows():
+    """decode -> encode reproduces the reference's rows (empty slots decode to '!' records and are dropped again)."""
+    from mapf_gpt_amd.dataset_tokenizer import Encoder
+    enc = Encoder()
+    g = np.load(os.path.join(GOLDEN, "ds_random.npz"))
+    for row in g["inputs"][::17]:
+        obs = enc.decode(row)
+        assert obs["cost2go"][5, 5] == 0                                     # the observer's own cell
+        assert obs["agents"][0]["relative_pos"] == (0, 0)                    # slot 0 is the observer
+        obs["agents"] = [a for a in obs["agents"] if a["next_action"] != "!"]
+        assert enc.encode(obs) == [int(v) for v in row]
