@@ -33,6 +33,10 @@ WORKLOADS = {
     "cfg1": ("validation-random-seed-000", 32, 1, "2M", 128),
     "cfg2": ("validation-mazes-seed-000", 64, 256, "2M", 128),
     "cfg3": ("wfi_warehouse", 192, 64, "6M", 128),
+    # cfg4 = BASELINE configs[3]: 4096 instances over 8 GPUs = 512 per GPU; every instance has its own synthetic map, half
+    # Bernoulli "random" (obstacle density U[0.1, 0.3]) and half "maze" (wall density ~0.3), 40 x 40 cells so that 128 agents fit
+    # (the reference's 17-21-cell eval maps hold at most 64)
+    "cfg4": ("synthetic-random+maze-40x40", 128, 512, "6M", 128),
     "cfg5": ("Berlin_1_256_00", 256, 128, "85M", 256),
 }
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
@@ -219,11 +223,23 @@ def main():
         inst_per_gpu = a.instances
     n_total = inst_per_gpu * world
     lo, hi = shard_range(n_total, rank, world)
-    grid, s_ok, g_ok = maps.load_named(map_name)
     rows = (hi - lo) * n_agents
     chunk = min(rows, 4096 if model != "85M" else 1024)
     net = build_model(model, seed=0, max_rows=chunk, precision=a.precision, device=f"cuda:{local_rank}")
-    pos, goal = make_instances(grid, hi - lo, n_agents, first_seed=lo, start_ok=s_ok, goal_ok=g_ok)
+    if a.workload == "cfg4":                     # one map per instance, seeded by the global instance id
+        import numpy as np
+        gl, pl, gll = [], [], []
+        for i in range(lo, hi):
+            rng = np.random.Generator(np.random.PCG64([i, 4]))
+            obst = maps.random_map(40, 40, float(rng.uniform(0.1, 0.3)), 1000 + i) if i % 2 == 0 else maps.maze_map(40, 40, 1000 + i)
+            g = maps.pad(obst)
+            p_, g_ = maps.place_agents(g, n_agents, i)
+            gl.append(g); pl.append(p_); gll.append(g_)
+        grid, s_ok, g_ok = np.stack(gl), None, None
+        pos, goal = torch.from_numpy(np.stack(pl)), torch.from_numpy(np.stack(gll))
+    else:
+        grid, s_ok, g_ok = maps.load_named(map_name)
+        pos, goal = make_instances(grid, hi - lo, n_agents, first_seed=lo, start_ok=s_ok, goal_ok=g_ok)
     run = BatchedRunner(grid, hi - lo, n_agents, net, max_episode_steps=max_steps, seed=0, do_sample=True,
                         precision=a.precision, device=f"cuda:{local_rank}", row_offset=lo * n_agents)
     run.reset(pos, goal)
@@ -308,10 +324,10 @@ def main():
                                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
                                              "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows,
                                              "note": "the workload's own launch (latency-bound when rows_per_launch < 1e5)"}
-            if world == 1 and not a.no_tokenizer_leg:
+            if world == 1 and not a.no_tokenizer_leg and a.workload != "cfg4":
                 out["roofline_tokenizer_large"] = tokenizer_large_launch(grid, s_ok, g_ok, n_agents, local_rank)
             out["kernel_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload != "cfg4":
             out["cpu_baseline"] = cpu_baseline(map_name, n_agents, model)
         print(json.dumps(out), flush=True)
     if world > 1:
