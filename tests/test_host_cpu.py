@@ -80,3 +80,21 @@ def test_shard_range_partitions():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_flop_accounting_matches_survey():
+    """bench.py's per-row flops are SURVEY 8d's F_ref = L (24 C^2 T + 4 T^2 C) + 2 C V: 0.996 / 3.758 / 45.90 GFLOP."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from mapf_gpt_amd import weights
+    for name, gflop in (("2M", 0.996), ("6M", 3.758), ("85M", 45.90)):
+        total, per_layer = bench.flops_per_row(weights.model_args(name))
+        assert abs(total / 1e9 - gflop) < 0.005
+        a = weights.model_args(name)
+        fused = per_layer["gpt_gemm_qkv"] + per_layer["gpt_attention"] + per_layer["gpt_gemm_attn_proj"] + per_layer["gpt_mlp_fused"]
+        assert a["n_layer"] * fused + 2 * a["n_embd"] * 67 == total
+        assert per_layer["gpt_gemm_mlp_fc"] + per_layer["gpt_gemm_mlp_proj"] == per_layer["gpt_mlp_fused"]
+    assert set(bench.WORKLOADS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5"} and bench.TOKENIZER_BYTES_PER_ROW == 694
