@@ -137,3 +137,21 @@ def test_bf16_logits_close_to_reference(tag):
     err = np.abs(logits - g["logits"]).max()
     assert err <= 6e-2, f"{tag}: max |dlogit| = {err:.3e}"
     assert err > 1e-6          # it really is the reduced-precision path
+
+
+@pytest.mark.parametrize("shape,precision", [("2M", "f16x3"), ("6M", "f16x3"), ("6M", "bf16"), ("85M", "bf16"), ("85M", "f16x3")])
+def test_chunking_and_batch_position_do_not_change_a_row(shape, precision):
+    """Every 16-bit path (fused 2M kernels, pair MLP + packed GEMMs for 6M, packed GEMMs for 85M): ragged chunking
+    (max_rows 4, 7 rows -> chunks of 4 + 3) and the position of a row inside the batch leave its logits bit-identical."""
+    from mapf_gpt_amd.model import build_model
+    rng = np.random.Generator(np.random.PCG64(17))
+    tokens = torch.from_numpy(rng.integers(0, 67, (7, 256)).astype(np.uint8)).cuda()
+    small = build_model(shape, seed=1, max_rows=4, precision=precision)
+    big = build_model(shape, seed=1, max_rows=8, precision=precision)
+    a = small.logits_tokens(tokens).cpu().numpy()
+    b = big.logits_tokens(tokens).cpu().numpy()
+    assert np.array_equal(a, b)
+    perm = torch.tensor([6, 2, 5, 0, 3, 1, 4])
+    c = big.logits_tokens(tokens[perm].contiguous()).cpu().numpy()
+    assert np.array_equal(c, b[perm.numpy()])
+    assert np.isfinite(a).all()
