@@ -232,13 +232,20 @@ extern "C" int mgpt_env_set_lifelong(mgpt_env *e, const int16_t *d_goal_queue, i
     e->goal_queue = nullptr; e->qnext = nullptr; e->reached = nullptr; e->queue_len = 0;
     if (d_goal_queue == nullptr || queue_len <= 0) return MGPT_OK;          // back to on_target = "nothing"
     const size_t total = (size_t)e->n_inst * e->n_agents;
-    MGPT_HIP(hipMalloc(&e->goal_queue, total * queue_len * 2 * sizeof(int16_t)));
-    MGPT_HIP(hipMalloc(&e->qnext, total * sizeof(int32_t)));
-    MGPT_HIP(hipMalloc(&e->reached, total * sizeof(int32_t)));
-    MGPT_HIP(hipMemcpyAsync(e->goal_queue, d_goal_queue, total * queue_len * 2 * sizeof(int16_t), hipMemcpyDeviceToDevice, s));
-    MGPT_HIP(hipMemsetAsync(e->qnext, 0, total * sizeof(int32_t), s));
-    MGPT_HIP(hipMemsetAsync(e->reached, 0, total * sizeof(int32_t), s));
-    e->queue_len = queue_len;
+    int16_t *q = nullptr;
+    int32_t *qn = nullptr, *rc = nullptr;
+    hipError_t err = hipMalloc(&q, total * queue_len * 2 * sizeof(int16_t));
+    if (err == hipSuccess) err = hipMalloc(&qn, total * sizeof(int32_t));
+    if (err == hipSuccess) err = hipMalloc(&rc, total * sizeof(int32_t));
+    if (err == hipSuccess) err = hipMemcpyAsync(q, d_goal_queue, total * queue_len * 2 * sizeof(int16_t), hipMemcpyDeviceToDevice, s);
+    if (err == hipSuccess) err = hipMemsetAsync(qn, 0, total * sizeof(int32_t), s);
+    if (err == hipSuccess) err = hipMemsetAsync(rc, 0, total * sizeof(int32_t), s);
+    if (err != hipSuccess) {                                               // stay in on_target = "nothing" rather than half-configured
+        set_error("mgpt_env_set_lifelong: %s", hipGetErrorString(err));
+        (void)hipFree(q); (void)hipFree(qn); (void)hipFree(rc);
+        return MGPT_ERR_HIP;
+    }
+    e->goal_queue = q; e->qnext = qn; e->reached = rc; e->queue_len = queue_len;
     return MGPT_OK;
 }
 
