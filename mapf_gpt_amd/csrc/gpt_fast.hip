@@ -367,9 +367,9 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             ProfScope ps(P_ATTN, s);
             const uint16_t *qh = m->qk[0], *ql = m->qk[1], *kh = m->qk[0] + M * C, *kl = (NP == 2) ? m->qk[1] + M * C : nullptr;
             if (g->hs == 32)
-                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
+                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
             else
-                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(256), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
+                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
             MGPT_LAUNCH_CHECK();
         }
         // ---- attention output projection + residual (+ stats of the new rows) ----

@@ -748,8 +748,10 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
 // so that the 8 keys a lane holds for one PV MFMA are contiguous in V^T (one 16-byte LDS read).
 //   q, k planes [rows][n_head][256][HS]; v^T planes [rows][n_head][HS][256]; y planes [rows*256][C]
 // ---------------------------------------------------------------------------------------------
-template <class T, int NP, int HS>
-__global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict__ q_hi, const uint16_t *__restrict__ q_lo,
+// NW waves per (row, head) workgroup: 8 (one query tile each) keeps two waves on every SIMD even when K and V^T of the
+// head fill most of LDS (hs = 64 in the split mode: 141 KiB, one workgroup per CU).
+template <class T, int NP, int HS, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void attn16_kernel(const uint16_t *__restrict__ q_hi, const uint16_t *__restrict__ q_lo,
                                                      const uint16_t *__restrict__ k_hi, const uint16_t *__restrict__ k_lo,
                                                      const uint16_t *__restrict__ vt_hi, const uint16_t *__restrict__ vt_lo,
                                                      uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo, int n_head,
@@ -772,23 +774,23 @@ __global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict_
 
     // stage K [256][HS] and V^T [HS][256] planes (16-byte chunks)
     if (chunk_major) {      // planes written by the packed GEMM: [hs/8][256][8] and [256/8][hs][8]; consecutive threads read consecutive 16 B
-        for (int idx = tid; idx < NP * kT * (HS / 8); idx += 256) {
+        for (int idx = tid; idx < NP * kT * (HS / 8); idx += NW * 64) {
             const int pl = idx / (kT * (HS / 8)), rem = idx - pl * (kT * (HS / 8)), c = rem / kT, row = rem - c * kT;
             const uint16_t *src = (pl == 0 ? k_hi : k_lo) + base + (size_t)rem * 8;
             *reinterpret_cast<u32x4 *>(sK + (size_t)pl * kT * KRS + row * KRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
         }
-        for (int idx = tid; idx < NP * HS * (kT / 8); idx += 256) {
+        for (int idx = tid; idx < NP * HS * (kT / 8); idx += NW * 64) {
             const int pl = idx / (HS * (kT / 8)), rem = idx - pl * (HS * (kT / 8)), c = rem / HS, row = rem - c * HS;
             const uint16_t *src = (pl == 0 ? vt_hi : vt_lo) + base + (size_t)rem * 8;
             *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VRS + row * VRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
         }
     } else {
-    for (int idx = tid; idx < NP * kT * (HS / 8); idx += 256) {
+    for (int idx = tid; idx < NP * kT * (HS / 8); idx += NW * 64) {
         const int pl = idx / (kT * (HS / 8)), rem = idx - pl * (kT * (HS / 8)), row = rem / (HS / 8), c = rem - row * (HS / 8);
         const uint16_t *src = (pl == 0 ? k_hi : k_lo) + base + (size_t)row * HS + c * 8;
         *reinterpret_cast<u32x4 *>(sK + (size_t)pl * kT * KRS + row * KRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
     }
-    for (int idx = tid; idx < NP * HS * (kT / 8); idx += 256) {
+    for (int idx = tid; idx < NP * HS * (kT / 8); idx += NW * 64) {
         const int pl = idx / (HS * (kT / 8)), rem = idx - pl * (HS * (kT / 8)), row = rem / (kT / 8), c = rem - row * (kT / 8);
         const uint16_t *src = (pl == 0 ? vt_hi : vt_lo) + base + (size_t)row * kT + c * 8;
         *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VRS + row * VRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
@@ -799,7 +801,7 @@ __global__ __launch_bounds__(256) void attn16_kernel(const uint16_t *__restrict_
     // the S^T tile row this lane feeds as A-operand is key `kperm` of the tile (bits 2 and 3 of r swapped)
     const int kperm = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);
 
-    for (int qt = wave; qt < kT / 32; qt += 4) {
+    for (int qt = wave; qt < kT / 32; qt += NW) {
         u32x4 qf[KS][2];                                         // B operand: Q[query r][16 ks + 8 h ..]
 #pragma unroll
         for (int ks = 0; ks < KS; ks++)
