@@ -163,11 +163,13 @@ int mgpt_gpt_forward(mgpt_gpt *gpt, const uint8_t *d_tokens, int rows, float *d_
                      int precision, void *stream);
 
 /* = GPT.act (model.py:244-260): softmax over logits[:5]; do_sample != 0 draws from it with the
- * library's counter-based RNG keyed by (seed, step, row) -- torch.multinomial's stream is
- * device-specific and not reproduced -- else arg-max.  d_actions int32 [rows].
+ * library's counter-based RNG keyed by (seed, step, row0 + row) -- torch.multinomial's stream is
+ * device-specific and not reproduced -- else arg-max.  row0 = GLOBAL id of this call's first row, so
+ * that a shard of a larger job (instances split over GPUs) draws exactly what the unsharded job
+ * draws for the same rows.  d_actions int32 [rows].
  * d_logits may be NULL, else float32 [rows, 67] is also written. */
 int mgpt_gpt_act(mgpt_gpt *gpt, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits,
-                 int do_sample, uint64_t seed, uint64_t step, int precision, void *stream);
+                 int do_sample, uint64_t seed, uint64_t step, uint64_t row0, int precision, void *stream);
 
 /* test/debug: copy an fp32-path workspace buffer (valid after mgpt_gpt_forward with MGPT_PREC_F32):
  * which 0 = residual stream x [rows*256, C], 1 = last LayerNorm output, 2 = q|k|v planes
@@ -179,9 +181,9 @@ int mgpt_gpt_debug_copy(mgpt_gpt *gpt, int which, float *d_out, int64_t n_elem, 
  * 5/6 = attention output planes hi/lo; 7/8 = MLP hidden planes hi/lo (lo only for MGPT_PREC_F16X3). */
 int mgpt_gpt_debug_copy_raw(mgpt_gpt *gpt, int precision, int which, void *d_out, int64_t nbytes, void *stream);
 
-/* sampling alone (same RNG as mgpt_gpt_act), for callers that already hold logits */
+/* sampling alone (same RNG and key as mgpt_gpt_act), for callers that already hold logits */
 int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_actions, int do_sample,
-                        uint64_t seed, uint64_t step, void *stream);
+                        uint64_t seed, uint64_t step, uint64_t row0, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dataset-side bulk tokenizer: replaces dataset/tokenizer/generate_observations.py:8-92 with its two native modules

@@ -65,10 +65,10 @@ SYMBOLS = {
     "mgpt_gpt_set_param": (_i, [_vp, ctypes.c_char_p, _vp, _i64, _i]),
     "mgpt_gpt_finalize": (_i, [_vp]),
     "mgpt_gpt_forward": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
-    "mgpt_gpt_act": (_i, [_vp, _vp, _i, _vp, _vp, _i, _u64, _u64, _i, _vp]),
+    "mgpt_gpt_act": (_i, [_vp, _vp, _i, _vp, _vp, _i, _u64, _u64, _u64, _i, _vp]),
     "mgpt_gpt_debug_copy": (_i, [_vp, _i, _vp, _i64, _vp]),
     "mgpt_gpt_debug_copy_raw": (_i, [_vp, _i, _i, _vp, _i64, _vp]),
-    "mgpt_sample_actions": (_i, [_vp, _i, _vp, _i, _u64, _u64, _vp]),
+    "mgpt_sample_actions": (_i, [_vp, _i, _vp, _i, _u64, _u64, _u64, _vp]),
     "mgpt_prof_enable": (_i, [_i]),
     "mgpt_prof_reset": (_i, []),
     "mgpt_prof_read": (_i, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),

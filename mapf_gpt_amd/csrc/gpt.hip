@@ -299,24 +299,24 @@ extern "C" int mgpt_gpt_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, 
 }
 
 extern "C" int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_actions, int do_sample, uint64_t seed,
-                                   uint64_t step, void *stream)
+                                   uint64_t step, uint64_t row0, void *stream)
 {
     MGPT_REQUIRE(d_logits && d_actions && rows > 0, MGPT_ERR_ARG, "bad argument");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(P_SAMPLE, s);
-    hipLaunchKernelGGL(sample_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, d_logits, rows, d_actions, do_sample, seed, step, (uint64_t)0);
+    hipLaunchKernelGGL(sample_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, d_logits, rows, d_actions, do_sample, seed, step, row0);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
 
 extern "C" int mgpt_gpt_act(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits,
-                            int do_sample, uint64_t seed, uint64_t step, int precision, void *stream)
+                            int do_sample, uint64_t seed, uint64_t step, uint64_t row0, int precision, void *stream)
 {
     MGPT_REQUIRE(g && d_tokens && d_actions, MGPT_ERR_ARG, "NULL argument");
     MGPT_REQUIRE(rows > 0, MGPT_ERR_ARG, "rows=%d", rows);
     MGPT_REQUIRE(g->finalized, MGPT_ERR_STATE, "mgpt_gpt_finalize must precede act");
     hipStream_t s = (hipStream_t)stream;
-    // row index inside the RNG key is the GLOBAL row of this call, independent of workspace chunking
+    // row index inside the RNG key is the GLOBAL row (row0 + row of this call), independent of workspace chunking and sharding
     for (int r0 = 0; r0 < rows; r0 += g->max_rows) {
         const int n = std::min(g->max_rows, rows - r0);
         float *lg = d_logits ? d_logits + (size_t)r0 * kV : g->logits_tmp;
@@ -324,7 +324,7 @@ extern "C" int mgpt_gpt_act(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int3
         if (rc != MGPT_OK) return rc;
         ProfScope ps(P_SAMPLE, s);
         hipLaunchKernelGGL(sample_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, lg, n, d_actions + r0, do_sample,
-                           seed, step, (uint64_t)r0);
+                           seed, step, row0 + (uint64_t)r0);
         MGPT_LAUNCH_CHECK();
     }
     return MGPT_OK;

@@ -80,7 +80,7 @@ using namespace mgpt;
 
 extern "C" const char *mgpt_last_error(void) { return g_err; }
 
-extern "C" int mgpt_abi_version(void) { return 1000; }
+extern "C" int mgpt_abi_version(void) { return 1001; }
 
 extern "C" int mgpt_device_count(int *count)
 {

@@ -42,6 +42,7 @@ class GPT:
         self._h = None
         self._loaded = False
         self.training = False
+        self._act_calls = 0          # advances the library RNG between generator-less act() calls
 
     # ---- lifecycle -------------------------------------------------------------------------
     def _ensure(self):
@@ -115,9 +116,9 @@ class GPT:
                                                    _lib.stream_ptr()))
         return out
 
-    def act_tokens(self, tokens_u8, do_sample=True, seed=0, step=0, precision=None, out=None, logits_out=None):
+    def act_tokens(self, tokens_u8, do_sample=True, seed=0, step=0, precision=None, out=None, logits_out=None, row0=0):
         """Fused forward + 5-way masked softmax + sampling on the device (library RNG keyed by
-        (seed, step, row)) -> int32 [rows]."""
+        (seed, step, row0 + row); row0 = global id of the first row when the caller holds a shard) -> int32 [rows]."""
         assert self._loaded, "load_state_dict first"
         rows = tokens_u8.shape[0]
         if out is None:
@@ -125,7 +126,7 @@ class GPT:
         lp = _lib.ptr(logits_out) if logits_out is not None else None
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().mgpt_gpt_act(self._h, _lib.ptr(tokens_u8), rows, _lib.ptr(out), lp, 1 if do_sample else 0,
-                                               int(seed) & (2 ** 64 - 1), int(step), self._prec(precision), _lib.stream_ptr()))
+                                               int(seed) & (2 ** 64 - 1), int(step), int(row0), self._prec(precision), _lib.stream_ptr()))
         return out
 
     def forward(self, idx, targets=None):
@@ -140,14 +141,20 @@ class GPT:
     def act(self, idx, do_sample=True, generator=None):
         """= GPT.act (model.py:244-260).  With a torch `generator` the draw is torch.multinomial on the
         device from OUR logits (same masking/softmax as the reference); without one the library's fused
-        sampler runs.  Returns an int64 tensor [B] (0-d for B == 1, like the reference's .squeeze())."""
+        sampler runs, keyed by (seed drawn once from torch's global RNG, call counter, row) so that
+        successive calls draw fresh uniforms like the reference's advancing global RNG does.
+        Returns an int64 tensor [B] (0-d for B == 1, like the reference's .squeeze())."""
         tokens = self._tokens_u8(idx)
         if do_sample and generator is not None:
             logits = self.logits_tokens(tokens)
             probs = torch.softmax(logits[:, :5], dim=-1)                       # model.py:250-254
             nxt = torch.multinomial(probs, num_samples=1, generator=generator)  # model.py:257
             return nxt.squeeze()
-        return self.act_tokens(tokens, do_sample=do_sample).to(torch.int64).squeeze()
+        if do_sample and self._act_calls == 0:
+            self._act_seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # follows torch.manual_seed
+        step = self._act_calls
+        self._act_calls += 1
+        return self.act_tokens(tokens, do_sample=do_sample, seed=getattr(self, "_act_seed", 0), step=step).to(torch.int64).squeeze()
 
 
 def build_model(name_or_args, seed=0, scale=1.0, max_rows=2048, precision="f32", device="cuda", state_dict=None):

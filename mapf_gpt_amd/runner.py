@@ -66,7 +66,7 @@ class BatchedRunner:
         self.n_inst, self.n_agents = n_inst, n_agents
         self.rows = n_inst * n_agents
         self.seed, self.do_sample, self.precision = seed, do_sample, precision
-        self.row_offset = row_offset          # global row id of this shard's first row (keeps draws shard-independent)
+        self.row_offset = row_offset          # global row id of this shard's first row: the sampler keys draws by global row
         self.tokens = torch.empty((self.rows, 256), dtype=torch.uint8, device=self.device)
         self.actions = torch.full((n_inst, n_agents), -1, dtype=torch.int32, device=self.device)
         self.t = 0
@@ -89,8 +89,8 @@ class BatchedRunner:
             _lib.check(L.mgpt_tokenizer_update_agents(self.tok._h, self._pos_ptr, self._goal_ptr, _lib.ptr(self.actions),
                                                       1 if self.env.lifelong else 0, s))
             _lib.check(L.mgpt_tokenizer_generate_observations(self.tok._h, _lib.ptr(self.tokens), s))
-        self.net.act_tokens(self.tokens, do_sample=self.do_sample, seed=self.seed + self.row_offset * 0x9E3779B1,
-                            step=self.t, precision=self.precision, out=self.actions.view(-1))
+        self.net.act_tokens(self.tokens, do_sample=self.do_sample, seed=self.seed, step=self.t, precision=self.precision,
+                            out=self.actions.view(-1), row0=self.row_offset)
         with torch.cuda.device(self.device):
             _lib.check(L.mgpt_env_step(self.env._h, _lib.ptr(self.actions), s))
         self.t += 1

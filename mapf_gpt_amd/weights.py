@@ -67,11 +67,13 @@ def strip_prefix(state_dict, prefix="_orig_mod."):
     return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in state_dict.items()}
 
 
-def load_checkpoint(path, map_location="cpu"):
+def load_checkpoint(path, map_location="cpu", allow_pickle=False):
     """-> (model_args dict, state_dict of float32 numpy arrays).  Same dict layout the reference's
-    train.py:300-310 writes and inference.py:72-85 reads."""
+    train.py:300-310 writes and inference.py:72-85 reads.  The released files hold tensors and a plain
+    dict only, so the safe unpickler suffices; allow_pickle=True is an explicit opt-in for files that
+    carry other objects (unpickling can execute code -- only for checkpoints you trust)."""
     import torch
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    ckpt = torch.load(path, map_location=map_location, weights_only=not allow_pickle)
     sd = strip_prefix(ckpt["model"])
     args = model_args(ckpt["model_args"])
     out = {k: v.detach().to(torch.float32).cpu().numpy() for k, v in sd.items() if hasattr(v, "detach")}

@@ -1,0 +1,45 @@
+"""bench.py's own control flow on the GPU box: the one-JSON-line contract at N = 1 and the N > 1 path (two ranks sharing
+the one GPU over gloo -- the RCCL path differs only in the backend string and the device of the collective tensors)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_share_one_gpu():
+    env = dict(os.environ, MGPT_BENCH_BACKEND="gloo", MGPT_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "cfg4", "--instances", "6", "--precision", "f16x3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    rows = 2 * 6 * 128                                   # both ranks' instances x 128 agents
+    assert "12 total" in j["config"]["workload"] and f"{rows} rows/step" in j["config"]["workload"]
+    assert abs(j["value"] - rows * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
+    assert 0.0 <= j["config"]["mean_ISR_after_run"] <= 1.0
+    assert j["roofline"]["unit"] == "TFLOP/s" and 0 < j["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in j                       # rank 0 at N = 1 only
+
+
+def test_bench_single_rank_line():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--instances", "4",
+           "--no-cpu-baseline", "--no-tokenizer-leg", "--no-secondary"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 1 and j["config"]["workload"].startswith("cfg3: wfi_warehouse, 192 agents, MAPF-GPT-6M")
+    assert j["unit"] == "agent-steps/s" and j["dtype"] == "f16x3" and j["vs_baseline"] is None
+    assert j["roofline"]["bound"] == "mfma" and j["roofline_tokenizer"]["bound"] == "hbm"

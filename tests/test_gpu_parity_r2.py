@@ -1,0 +1,237 @@
+"""Round-2 parity additions (VERDICT r01 "close the parity holes"), all through the C ABI on the GPU:
+  (a) the 16-rows-per-wave tokens kernel (launches with >= 4096 instance-chunks) vs the C oracle;
+  (b) the cfg4 workload (per-instance random / maze maps, 128 agents) -> tokens vs oracle, 6M logits vs the fp64 port;
+  (c) the bf16 mode vs the reference's own bf16-autocast logits (2M, 6M, 85M);
+  (d) f32 and f16x3 on 256 real token rows per shape, x1 and x4 weights, vs the reference's fp32 / fp64 logits;
+  (e) released-checkpoint layout ({"model": {"_orig_mod....": tensor}, "model_args"}) through MAPFGPTInference;
+  (f) sharded sampling reproduces the unsharded draws (global row key).
+Goldens gptbig_*.npz come from the REAL mapf_gpt/model.py (tests/golden/make_golden_big.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mapf_gpt_amd import maps, weights
+from oracle import gpt_oracle
+from oracle import oracle as orc
+from tests.helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5            # BASELINE.json north_star: logits within 1e-5 of the reference PyTorch forward
+
+
+def _dev(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (a) tokens_kernel<KP, 16>: chosen by mgpt_tokenizer_generate_observations when n_inst * ceil(n_agents / 64) >= 4096
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_inst,n_agents,kind", [(4096, 64, "mazes000"), (2048, 128, "random40"), (1400, 192, "warehouse")])
+def test_large_launch_kernel_vs_oracle(n_inst, n_agents, kind):
+    """64-agents-per-block / 16-rows-per-wave instantiation (KP = 1, 2 and 4): 96 distinct base instances are checked row
+    for row against the C oracle over 3 steps (random intended actions, executed by the oracle env); all other instance
+    slots replicate a base instance and must equal it bit for bit."""
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    assert n_inst * ((n_agents + 63) // 64) >= 4096
+    if kind == "mazes000":
+        grid, s_ok, g_ok = maps.load_named("validation-mazes-seed-000")
+    elif kind == "warehouse":
+        grid, s_ok, g_ok = maps.load_named("wfi_warehouse")
+    else:
+        grid, s_ok, g_ok = maps.pad(maps.random_map(40, 40, 0.2, 77)), None, None
+    nb = 96
+    comp = maps.largest_component(grid == 0)
+    pg = [maps.place_agents(grid, n_agents, 1000 + i, s_ok, g_ok, component=comp) for i in range(nb)]
+    pos = np.stack([p for p, _ in pg]).astype(np.int32)
+    goal = np.stack([g for _, g in pg]).astype(np.int32)
+    rep = np.arange(n_inst) % nb
+    rng = np.random.Generator(np.random.PCG64(n_inst + n_agents))
+    gens = [orc.OracleGenerator(grid) for _ in range(nb)]
+    tok = BatchedTokenizer(grid, n_inst, n_agents)
+    last = np.full((nb, n_agents), -1, np.int32)
+    for t in range(3):
+        dp, dg, da = _dev(pos[rep], torch.int16), _dev(goal[rep], torch.int16), _dev(last[rep], torch.int32)
+        if t == 0:
+            tok.create_agents(dp, dg)
+            for i in range(nb):
+                gens[i].create_agents(pos[i], goal[i])
+        tok.update_agents(dp, dg, da, goals_may_change=False)
+        got = tok.generate_observations().cpu().numpy().reshape(n_inst, n_agents, 256)
+        for i in range(nb):
+            gens[i].update_agents(pos[i], goal[i], last[i])
+            assert np.array_equal(got[i], gens[i].generate_observations()), f"step {t} base instance {i}"
+        assert np.array_equal(got, got[rep]), f"step {t}: replicas differ from their base instance"
+        last = rng.integers(0, 5, (nb, n_agents)).astype(np.int32)
+        for i in range(nb):
+            pos[i], _ = orc.env_step(grid, pos[i], goal[i], last[i])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (b) cfg4: BASELINE.json configs[3] -- per-instance random / maze maps 40 x 40, 128 agents, MAPF-GPT-6M
+# ------------------------------------------------------------------------------------------------------------------
+def _cfg4_instances(lo, hi, n_agents=128):
+    import bench
+    return bench.cfg4_instances(lo, hi, n_agents)
+
+
+def test_cfg4_workload_tokens_and_6M_logits():
+    """12 instances of bench.py's cfg4 generator (6 Bernoulli maps, 6 mazes, each instance its own map): 8 steps of the
+    tokenizer vs the C oracle, then the 6M forward of those rows in f16x3 and f32 vs the fp64 torch port at 1e-5."""
+    from mapf_gpt_amd.model import build_model
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    n_inst, n = 12, 128
+    grids, pos_t, goal_t = _cfg4_instances(0, n_inst, n)
+    pos, goal = pos_t.numpy().astype(np.int32), goal_t.numpy().astype(np.int32)
+    assert len({g.tobytes() for g in grids}) == n_inst
+    gens = [orc.OracleGenerator(grids[i]) for i in range(n_inst)]
+    tok = BatchedTokenizer(grids, n_inst, n)
+    rng = np.random.Generator(np.random.PCG64(44))
+    last = np.full((n_inst, n), -1, np.int32)
+    keep_rows = []
+    for t in range(8):
+        dp, dg, da = _dev(pos, torch.int16), _dev(goal, torch.int16), _dev(last, torch.int32)
+        if t == 0:
+            tok.create_agents(dp, dg)
+            for i in range(n_inst):
+                gens[i].create_agents(pos[i], goal[i])
+        tok.update_agents(dp, dg, da, goals_may_change=False)
+        got = tok.generate_observations().cpu().numpy().reshape(n_inst, n, 256)
+        for i in range(n_inst):
+            gens[i].update_agents(pos[i], goal[i], last[i])
+            assert np.array_equal(got[i], gens[i].generate_observations()), f"step {t} instance {i}"
+        keep_rows.append(got[:, ::16].reshape(-1, 256))             # 8 rows per instance and step
+        last = rng.integers(0, 5, (n_inst, n)).astype(np.int32)
+        for i in range(n_inst):
+            pos[i], _ = orc.env_step(grids[i], pos[i], goal[i], last[i])
+    rows = np.concatenate(keep_rows)[::8][:96]                      # 96 rows spread over steps / instances / maps
+    sd, args = weights.synthetic_state_dict("6M", seed=0), weights.model_args("6M")
+    ref = gpt_oracle.forward_logits(sd, args, rows, dtype=torch.float64).numpy()
+    tokens = torch.from_numpy(np.ascontiguousarray(rows)).cuda()
+    for prec in ("f16x3", "f32"):
+        net = build_model("6M", seed=0, max_rows=64, precision=prec)
+        err = np.abs(net.logits_tokens(tokens).cpu().numpy() - ref).max()
+        assert err <= TOL, f"cfg4 rows, 6M {prec}: max |dlogit| = {err:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (c) + (d) 256 real rows per shape against the reference's own fp32 / fp64 / bf16-autocast logits
+# ------------------------------------------------------------------------------------------------------------------
+def _big(shape, scale):
+    return np.load(os.path.join(GOLDEN, f"gptbig_{shape}_s{scale}.npz"))
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("shape,scale", [("2M", 1), ("2M", 4), ("6M", 1), ("6M", 4), ("85M", 1), ("85M", 4)])
+def test_256_real_rows_within_1e5_of_reference(shape, scale, precision):
+    """The north star's bar on every released shape, x1 and x4 (trained-magnitude) weights, 256 real observation rows:
+    |ours - reference fp32 forward| <= 1e-5 and |ours - reference fp64| <= 1e-5.  The fp32 reference itself sits
+    e_ref = 7e-7 .. 4.4e-6 away from its own fp64 run on five of the six sets; on 85M x4 (|logit| up to 8.2) it is 3.6e-5
+    away, so no implementation can be within 1e-5 of both there: the bars become max(1e-5, e_ref) against fp64 (at least
+    as accurate as the reference's fp32) and max(1e-5, 2 e_ref) against the fp32 logits."""
+    from mapf_gpt_amd.model import build_model
+    g = _big(shape, scale)
+    net = build_model(shape, seed=0, scale=float(scale), max_rows=64 if shape == "85M" else 128, precision=precision)
+    logits = net.logits_tokens(torch.from_numpy(g["tokens"]).cuda()).cpu().numpy().astype(np.float64)
+    e_ref = np.abs(g["logits_f32"].astype(np.float64) - g["logits_f64"]).max()
+    e32 = np.abs(logits - g["logits_f32"]).max()
+    e64 = np.abs(logits - g["logits_f64"]).max()
+    print(f"{shape} x{scale} {precision}: vs fp32 ref {e32:.3e}, vs fp64 ref {e64:.3e}, ref fp32 vs fp64 {e_ref:.3e}, max|logit| {np.abs(g['logits_f64']).max():.2f}")
+    assert e64 <= max(TOL, e_ref) and e32 <= max(TOL, 2 * e_ref), \
+        f"{shape} x{scale} {precision}: vs fp32 ref {e32:.3e}, vs fp64 ref {e64:.3e} (reference fp32 vs fp64 {e_ref:.3e})"
+
+
+@pytest.mark.parametrize("shape,scale", [("2M", 1), ("2M", 4), ("6M", 1), ("6M", 4), ("85M", 1), ("85M", 4)])
+def test_bf16_mode_vs_reference_autocast(shape, scale):
+    """bf16 mode (single-pass bf16 MFMA, fp32 accumulate, fp32 residual stream / LayerNorm / softmax) against the
+    reference run under torch.autocast(bfloat16) (train.py:66-70).  Two bf16 pipelines round at different points, so the
+    stated tolerance is relative to the reference's own autocast error e_ref = max|autocast - fp64| on the same rows:
+        max|ours - fp64|      <= 1.5 * e_ref + 2e-3     (at least as accurate as the reference's regime)
+        max|ours - autocast|  <= 2.5 * e_ref + 2e-3     (the two land in the same error ball)"""
+    from mapf_gpt_amd.model import build_model
+    g = _big(shape, scale)
+    net = build_model(shape, seed=0, scale=float(scale), max_rows=64 if shape == "85M" else 128, precision="bf16")
+    logits = net.logits_tokens(torch.from_numpy(g["tokens"]).cuda()).cpu().numpy().astype(np.float64)
+    e_ref = np.abs(g["logits_bf16"] - g["logits_f64"]).max()
+    e_ours = np.abs(logits - g["logits_f64"]).max()
+    e_mut = np.abs(logits - g["logits_bf16"]).max()
+    assert e_ours <= 1.5 * e_ref + 2e-3, f"{shape} x{scale}: ours-fp64 {e_ours:.3e} vs reference autocast-fp64 {e_ref:.3e}"
+    assert e_mut <= 2.5 * e_ref + 2e-3, f"{shape} x{scale}: ours-autocast {e_mut:.3e} (reference autocast-fp64 {e_ref:.3e})"
+    assert e_ours > 1e-6, "this must be the reduced-precision path"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (e) released-checkpoint layout end to end (inference.py:33-44,72-85; train.py:300-310)
+# ------------------------------------------------------------------------------------------------------------------
+def test_checkpoint_roundtrip_through_adapter(tmp_path):
+    """torch.save({"model": {"_orig_mod.<key>": tensor}, "model_args": {...}, ...}) -- the dict train.py writes and
+    torch.compile prefixes -- loaded by MAPFGPTInference(path_to_weights=...) must give the same logits as the same
+    weights handed over directly, and the safe unpickler must suffice."""
+    from mapf_gpt_amd.inference import MAPFGPTInference, MAPFGPTInferenceConfig
+    from mapf_gpt_amd.model import build_model
+    args = weights.model_args("2M")
+    sd = weights.synthetic_state_dict("2M", seed=5)
+    ckpt = {"model": {"_orig_mod." + k: torch.from_numpy(v.copy()) for k, v in sd.items()},
+            "model_args": {k: args[k] for k in ("n_layer", "n_head", "n_embd", "block_size", "bias", "vocab_size", "dropout")},
+            "iter_num": 1000, "best_val_loss": 1.25, "config": {"dataset": "x", "batch_size": 32}}
+    path = tmp_path / "MAPF-GPT-2M-test.pt"
+    torch.save(ckpt, str(path))
+    a2, sd2 = weights.load_checkpoint(str(path))
+    assert a2["n_layer"] == 5 and a2["n_embd"] == 160 and set(sd2) == set(sd)
+    assert all(np.array_equal(sd2[k], sd[k]) for k in sd)
+    algo = MAPFGPTInference(MAPFGPTInferenceConfig(path_to_weights=str(path), batch_size=64, precision="f32"))
+    rows = np.load(os.path.join(GOLDEN, "gptbig_2M_s1.npz"))["tokens"][:24]
+    tokens = torch.from_numpy(rows).cuda()
+    direct = build_model("2M", state_dict=sd, max_rows=64).logits_tokens(tokens).cpu().numpy()
+    via = algo.net.logits_tokens(tokens).cpu().numpy()
+    assert np.array_equal(via, direct)
+    ref = gpt_oracle.forward_logits(sd, args, rows).numpy()
+    assert np.abs(via - ref).max() <= TOL
+    acts = algo.act_batch([rows[:12].astype(np.int64).tolist(), rows[12:].astype(np.int64).tolist()])   # pre-tokenised rows, inference.py:146
+    assert [len(a) for a in acts] == [12, 12] and all(0 <= x <= 4 for a in acts for x in a)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (f) shard-independent sampling: the RNG key is (seed, step, GLOBAL row)
+# ------------------------------------------------------------------------------------------------------------------
+def test_two_shards_reproduce_single_shard_actions():
+    """a 2-shard run (row0 = first global row of the shard) must draw exactly what the unsharded run draws,
+    step after step, through BatchedRunner (env + tokenizer + forward + device sampler)."""
+    from mapf_gpt_amd.model import build_model
+    from mapf_gpt_amd.runner import BatchedRunner, make_instances, shard_range
+    grid, s_ok, g_ok = maps.load_named("validation-random-seed-000")
+    n_inst, n = 6, 20
+    net = build_model("tiny", seed=0, max_rows=64)
+    pos, goal = make_instances(grid, n_inst, n, 0, s_ok, g_ok)
+    full = BatchedRunner(grid, n_inst, n, net, max_episode_steps=16, seed=3, do_sample=True)
+    full.reset(pos, goal)
+    shards = []
+    for r in range(2):
+        lo, hi = shard_range(n_inst, r, 2)
+        s = BatchedRunner(grid, hi - lo, n, net, max_episode_steps=16, seed=3, do_sample=True, row_offset=lo * n)
+        s.reset(pos[lo:hi], goal[lo:hi])
+        shards.append((lo, hi, s))
+    differs = False
+    for t in range(6):
+        full.step()
+        a_full = full.actions.cpu().numpy()
+        for lo, hi, s in shards:
+            s.step()
+            assert np.array_equal(s.actions.cpu().numpy(), a_full[lo:hi]), f"step {t} shard [{lo},{hi})"
+        differs |= bool((a_full[:3] != a_full[3:]).any())
+    assert differs                                   # the draws are not degenerate
+    m = torch.cat([s.metrics() for _, _, s in shards]).cpu().numpy()
+    assert np.array_equal(m, full.metrics().cpu().numpy())
+
+
+def test_generatorless_act_advances_between_calls():
+    """GPT.act(idx) without a torch generator must not reuse the same uniform at every call."""
+    from mapf_gpt_amd.model import build_model
+    net = build_model("tiny", seed=0, max_rows=256)
+    rows = np.load(os.path.join(GOLDEN, "gptbig_2M_s1.npz"))["tokens"][:200]
+    idx = torch.from_numpy(rows.astype(np.int64)).cuda()
+    torch.manual_seed(11)
+    draws = np.stack([net.act(idx).cpu().numpy() for _ in range(4)])
+    assert draws.min() >= 0 and draws.max() <= 4
+    assert all((draws[i] != draws[j]).any() for i in range(4) for j in range(i))
