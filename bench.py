@@ -59,7 +59,9 @@ def flops_per_row(model_args):
 def _cpu_worker(job):
     """One CPU-baseline process: its own instance of the workload, `threads` intra-op threads, runs steps until the
     budget is spent.  -> (agent_steps, seconds, split seconds)"""
-    map_name, n_agents, model, seed, threads, budget_s = job
+    map_name, n_agents, model, seed, threads, budget_s, cpus = job
+    if cpus and hasattr(os, "sched_setaffinity"):
+        os.sched_setaffinity(0, cpus)             # one process per block of cores: no migration, no shared cores
     torch.set_num_threads(threads)
     from mapf_gpt_amd import maps, weights
     from mapf_gpt_amd.runner import make_instances
@@ -96,18 +98,21 @@ def _cpu_worker(job):
     return n_agents * timed, t_tok + t_fwd + t_env, (t_tok, t_fwd, t_env), timed
 
 
-def cpu_baseline(map_name, n_agents, model, budget_s=12.0):
+def cpu_baseline(map_name, n_agents, model, budget_s=10.0):
     """Oracle (C env + tokenizer restatement, PyTorch-CPU fp32 forward = the ops the reference executes) timed on ALL
     host cores: a pool of processes (the reference's own CPU path is a `num_process` pool, inference.py:30-31,
     eval_configs/01-random/01-random.yaml:147-148), 16 intra-op threads each, one instance of the same workload per
-    process, bounded sample."""
+    process pinned to its own block of cores, bounded sample."""
     import multiprocessing as mp
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = min(16, ncpu)
     procs = max(1, ncpu // threads)
     from oracle import oracle as orc
     orc.build()                                   # once, before the pool forks the work out
-    jobs = [(map_name, n_agents, model, i, threads, budget_s) for i in range(procs)]
+    allc = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    jobs = [(map_name, n_agents, model, i, threads, budget_s, allc[i * threads:(i + 1) * threads]) for i in range(procs)]
+    os.environ["OMP_NUM_THREADS"] = str(threads)  # inherited by the pool: no oversubscribed OpenMP teams at import time
+    os.environ["MKL_NUM_THREADS"] = str(threads)
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(procs) as pool:

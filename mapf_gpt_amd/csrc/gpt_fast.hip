@@ -11,6 +11,7 @@
 #include "common.h"
 #include "gpt_ctx.h"
 #include "gpt_kernels_fast.h"
+#include "gpt_kernels_c256.h"
 
 using namespace mgpt;
 
@@ -27,6 +28,7 @@ struct PlaneSet {           // one weight matrix [N][K] as 16-bit planes
 struct ModeState {          // one precision mode
     bool built = false;
     int np = 0;             // planes per operand
+    int n_cu = 256;         // compute units of the model's device (grid of the persistent kernels)
     std::vector<PlaneSet> attn, proj, fc, proj2;
     // workspace (sized for max_rows)
     float2 *stats = nullptr;
@@ -37,6 +39,9 @@ struct ModeState {          // one precision mode
     // fused MLP (C = 64 / 160): per layer one packed stream [hidden tile][fragment][plane][lane][8]
     std::vector<uint16_t *> mlp_pk;
     bool mlp_fused = false;
+    // C = 256 (6M): mlp256_kernel's weight stream in consumption order, per layer [step][micro-step][plane][lane][8]
+    std::vector<uint16_t *> mlp256_pk;
+    float2 *gelu_lut = nullptr;                // mlp256_kernel's Phi table (kGeluLutN pairs)
     // register-resident LN+QKV (C = 64 / 160): per layer [tile][k-step][plane][lane][8] of c_attn.weight
     std::vector<uint16_t *> qkv_pk;
     bool qkv_fused = false;
@@ -79,6 +84,9 @@ float pick_scale(const float *h_w, size_t n, bool f16)
     return ldexpf(1.0f, e);
 }
 
+template <int NP>
+constexpr int kM256Lds = 6 * 8 * NP * 1024 + fastk::kGeluLutN * 8;      // mlp256_kernel: 6-slot weight ring + GELU table
+
 template <class T, int NP>
 int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
 {
@@ -86,6 +94,13 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
     std::vector<float> host(g->n_params);
     MGPT_HIP(hipMemcpy(host.data(), g->params, g->n_params * sizeof(float), hipMemcpyDeviceToHost));
     m->np = NP;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MGPT_HIP(hipGetDevice(&dev));
+        MGPT_HIP(hipGetDeviceProperties(&prop, dev));
+        m->n_cu = std::max(1, prop.multiProcessorCount);
+    }
     m->attn.resize(g->L); m->proj.resize(g->L); m->fc.resize(g->L); m->proj2.resize(g->L);
     int rc;
     for (int l = 0; l < g->L; l++) {
@@ -97,8 +112,33 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             if ((rc = pack_matrix<T, NP>(g->params + mt.off, mt.n, sc, mt.dst, nullptr)) != MGPT_OK) return rc;
         }
     }
-    m->mlp_fused = (C == 160 || C == 64 || C == 256) && getenv("MGPT_NO_FUSED_MLP") == nullptr;
-    if (m->mlp_fused) {
+    m->mlp_fused = (C == 160 || C == 64 || C == 256);
+    if (C == 256) {
+        const size_t n16 = (size_t)fastk::kM256Steps * 8 * NP * 512;
+        m->mlp256_pk.assign(g->L, nullptr);
+        for (int l = 0; l < g->L; l++) {
+            MGPT_HIP(hipMalloc(&m->mlp256_pk[l], n16 * sizeof(uint16_t)));
+            const LayerOff &lo = g->layers[l];
+            ProfScope ps(P_PACK, nullptr);
+            hipLaunchKernelGGL((fastk::pack_mlp256_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)fastk::kM256Steps * 8 * 64, 256)), dim3(256), 0,
+                               nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, m->mlp256_pk[l], 1.0f / m->fc[l].inv_scale,
+                               1.0f / m->proj2[l].inv_scale);
+            MGPT_LAUNCH_CHECK();
+        }
+        {   // Phi(v) = (1 + erf(v / sqrt 2)) / 2 on [-6, 6) in steps of 1/512, as (value, forward difference) pairs
+            std::vector<float2> lut(fastk::kGeluLutN);
+            auto phi = [](double v) { return 0.5 * (1.0 + erf(v * 0.70710678118654752440)); };
+            for (int i = 0; i < fastk::kGeluLutN; i++) {
+                const double v0 = (i - (double)fastk::kGeluLutBias) / fastk::kGeluLutScale, v1 = (i + 1 - (double)fastk::kGeluLutBias) / fastk::kGeluLutScale;
+                const float f0 = (float)phi(v0);
+                lut[i] = make_float2(f0, (float)(phi(v1) - (double)f0));
+            }
+            MGPT_HIP(hipMalloc(&m->gelu_lut, lut.size() * sizeof(float2)));
+            MGPT_HIP(hipMemcpy(m->gelu_lut, lut.data(), lut.size() * sizeof(float2), hipMemcpyHostToDevice));
+        }
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kM256Lds<NP>));
+    } else if (m->mlp_fused) {
         const size_t frags = C / 16 + 2 * (C / 32), nt = 4 * C / 32;
         const size_t n16 = nt * frags * NP * 512;
         m->mlp_pk.assign(g->L, nullptr);
@@ -111,16 +151,11 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                1.0f / m->fc[l].inv_scale, 1.0f / m->proj2[l].inv_scale);
             MGPT_LAUNCH_CHECK();
         }
-        const int pkt = (int)(frags * NP * 1024 * (C == 256 ? 2 : 3));
-        if (C == 256) {
-            MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
-            MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_pair_kernel<T, NP, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         pkt + 8 * 2048 + 8 * 32 * 4 + 64));
-        }
-        else if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
+        const int pkt = (int)(frags * NP * 1024 * 3);
+        if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
         else MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
     }
-    m->qkv_fused = (C == 160 || C == 64) && getenv("MGPT_NO_FUSED_QKV") == nullptr;
+    m->qkv_fused = (C == 160 || C == 64);
     if (m->qkv_fused) {
         const size_t ks = C / 16, ntile = 3 * C / 32;
         m->qkv_pk.assign(g->L, nullptr);
@@ -141,9 +176,17 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                    nullptr, g->params + g->layers[l].proj_w, m->proj_pk[l], g->nh, (int)C, (int)C, 1.0f / m->proj[l].inv_scale);
                 MGPT_LAUNCH_CHECK();
             }
+            // attn_block_kernel's dynamic LDS limit is a per-device function attribute: set it for this model's device
+            const int lds = (int)((size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 4);
+#define MGPT_ATTN_LDS(CT_, LAST_, EMB_)                                                                                      \
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, CT_, true, LAST_, EMB_>), \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+            if (C == 160) { MGPT_ATTN_LDS(5, false, false); MGPT_ATTN_LDS(5, true, false); MGPT_ATTN_LDS(5, false, true); }
+            else { MGPT_ATTN_LDS(2, false, false); MGPT_ATTN_LDS(2, true, false); MGPT_ATTN_LDS(2, false, true); }
+#undef MGPT_ATTN_LDS
         }
     }
-    m->pk_gemm = (C == 256 || C == 512 || C == 768 || C == 1024) && getenv("MGPT_NO_PK_GEMM") == nullptr;
+    m->pk_gemm = (C == 256 || C == 512 || C == 768 || C == 1024);
     if (m->pk_gemm) {
         auto pack = [&](std::vector<uint16_t *> &dst, size_t off, size_t R, size_t K, float scale, int l) -> int {
             MGPT_HIP(hipMalloc(&dst[l], R * K * NP * sizeof(uint16_t)));
@@ -164,13 +207,9 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             }
         }
         const int lds = (NP == 2 ? 4 : 6) * 16 * NP * 1024;
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipMalloc(&m->apk, (size_t)g->max_rows * kT * C * NP * sizeof(uint16_t)));
     }
@@ -198,6 +237,8 @@ void free_mode(ModeState *m)
     auto fr = [](std::vector<PlaneSet> &v) { for (auto &p : v) { (void)hipFree(p.hi); (void)hipFree(p.lo); } v.clear(); };
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
     for (auto *p : m->mlp_pk) (void)hipFree(p);
+    for (auto *p : m->mlp256_pk) (void)hipFree(p);
+    (void)hipFree(m->gelu_lut);
     for (auto *p : m->qkv_pk) (void)hipFree(p);
     for (auto *p : m->proj_pk) (void)hipFree(p);
     for (auto *v : {&m->attn_pk2, &m->proj_pk2, &m->fc_pk2, &m->proj2_pk2}) for (auto *p : *v) (void)hipFree(p);
@@ -239,13 +280,8 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
                  "gemm_pk shape M=%d N=%d K=%d", a.M, a.N, a.K);
     a.n_tiles_n = a.N / 256;
     if (EPI == fastk::EPI_RESID) a.stats_out = nullptr;               // rows span two waves: stats come from row_stats_kernel
-    static const bool four = getenv("MGPT_PK_4WAVES") != nullptr;        // A/B: one wave per SIMD with 128 x 128 wave tiles
-    if (four)
-        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 4>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(256),
-                           (size_t)NST * 16 * NP * 1024, s, a);
-    else
-        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
-                           (size_t)NST * 16 * NP * 1024, s, a);
+    hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
+                       (size_t)NST * 16 * NP * 1024, s, a);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
@@ -285,10 +321,10 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     const int64_t M = (int64_t)rows * kT;
     const float *P = g->params;
     int rc;
-    // the first attention block can form x = wte[token] + wpe[position] itself (then no embedding kernel, no first read of x)
-    static const bool no_embed_fuse = getenv("MGPT_NO_EMBED_FUSE") != nullptr;
-    static const bool no_attn_block0 = getenv("MGPT_NO_ATTN_BLOCK") != nullptr, no_proj_fuse0 = getenv("MGPT_NO_PROJ_FUSE") != nullptr;
-    const bool embed_fused = m->qkv_fused && g->hs == 32 && m->mlp_fused && g->L > 1 && !no_embed_fuse && !no_attn_block0 && !no_proj_fuse0;
+    // register-resident path (C = 64, 160; head size 32): a layer is attn_block_kernel + mlp_fused_kernel
+    const bool attn_block = m->qkv_fused && g->hs == 32 && m->mlp_fused;
+    // the first attention block forms x = wte[token] + wpe[position] itself (no embedding kernel, no first read of x)
+    const bool embed_fused = attn_block && g->L > 1;
     if (!embed_fused) {
         ProfScope ps(P_EMBED, s);
         const dim3 grid((unsigned)cdiv64(M, 4));
@@ -304,47 +340,23 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         const LayerOff &lo = g->layers[l];
         fastk::GemmArgs a = {};
         a.M = (int)M; a.C = C; a.n_head = g->nh; a.hs = g->hs; a.plane = M * C;
-        // ---- LN1 + QK projection -> q|k planes ----
         a.x = g->x; a.stats = m->stats; a.gain = P + lo.ln1; a.K = C;
         a.w_hi = m->attn[l].hi; a.w_lo = m->attn[l].lo; a.out_scale = m->attn[l].inv_scale;
         a.N = 2 * C; a.o_hi = m->qk[0]; a.o_lo = m->qk[1];
-        static const bool no_attn_block = getenv("MGPT_NO_ATTN_BLOCK") != nullptr;
-        const bool attn_block = m->qkv_fused && g->hs == 32 && !no_attn_block;
-        static const bool no_proj_fuse = getenv("MGPT_NO_PROJ_FUSE") != nullptr;
-        const bool proj_fused = attn_block && !no_proj_fuse;
         // last layer: only token 255 is needed downstream (model.py:186) -> compact buffer, MLP and head on `rows` tokens
-        static const bool no_last = getenv("MGPT_NO_LAST_SHORTCUT") != nullptr;
-        const bool last_short = proj_fused && m->mlp_fused && l == g->L - 1 && !no_last;
+        const bool last_short = attn_block && l == g->L - 1;
         if (attn_block) {
-            // ---- LN1 + QKV + attention (+ out-projection + residual) in one kernel: q, k, v (, y) stay on chip ----
+            // ---- LN1 + QKV + attention + out-projection + residual in one kernel: q, k, v, y stay on chip ----
             ProfScope ps(P_ATTN, s);
             const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 4;   // K, V^T planes + 4 weight packet slots
-#define MGPT_ATTN_BLOCK(CT_, PROJ_, LAST_, EMB_)                                                                                 \
-    {                                                                                                                            \
-        static bool once = false;                                                                                                \
-        if (!once) {                                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, CT_, PROJ_, LAST_, EMB_>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
-            once = true;                                                                                                         \
-        }                                                                                                                        \
-        hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, PROJ_, LAST_, EMB_>), dim3((unsigned)rows), dim3(512), lds, s,  \
-                           g->x, P + lo.ln1, m->qkv_pk[l], m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e,           \
-                           m->proj_pk[l], m->proj[l].inv_scale, m->stats, m->x_last, d_tokens, P + g->off_wte, P + g->off_wpe);  \
-    }
+#define MGPT_ATTN_BLOCK(CT_, LAST_, EMB_)                                                                                        \
+    hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, true, LAST_, EMB_>), dim3((unsigned)rows), dim3(512), lds, s, g->x, \
+                       P + lo.ln1, m->qkv_pk[l], m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e, m->proj_pk[l],     \
+                       m->proj[l].inv_scale, m->stats, m->x_last, d_tokens, P + g->off_wte, P + g->off_wpe)
             const bool emb = embed_fused && l == 0;
-            if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, true, false) else if (emb) MGPT_ATTN_BLOCK(5, true, false, true) else if (proj_fused) MGPT_ATTN_BLOCK(5, true, false, false) else MGPT_ATTN_BLOCK(5, false, false, false) }
-            else { if (last_short) MGPT_ATTN_BLOCK(2, true, true, false) else if (emb) MGPT_ATTN_BLOCK(2, true, false, true) else if (proj_fused) MGPT_ATTN_BLOCK(2, true, false, false) else MGPT_ATTN_BLOCK(2, false, false, false) }
+            if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, false); else if (emb) MGPT_ATTN_BLOCK(5, false, true); else MGPT_ATTN_BLOCK(5, false, false); }
+            else { if (last_short) MGPT_ATTN_BLOCK(2, true, false); else if (emb) MGPT_ATTN_BLOCK(2, false, true); else MGPT_ATTN_BLOCK(2, false, false); }
 #undef MGPT_ATTN_BLOCK
-            MGPT_LAUNCH_CHECK();
-        } else if (m->qkv_fused) {
-            ProfScope ps(P_LNQKV_FUSED, s);
-            const size_t lds = (size_t)(C / 16) * NP * 1024 * 2;
-            if (C == 160)
-                hipLaunchKernelGGL((fastk::ln_qkv_kernel<T, NP, 5>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, m->qkv_pk[l],
-                                   m->attn[l].inv_scale, m->qk[0], m->qk[1], m->vt[0], m->vt[1], g->nh, g->hs, (int64_t)(M * C));
-            else
-                hipLaunchKernelGGL((fastk::ln_qkv_kernel<T, NP, 2>), dim3((unsigned)rows), dim3(512), lds, s, g->x, P + lo.ln1, m->qkv_pk[l],
-                                   m->attn[l].inv_scale, m->qk[0], m->qk[1], m->vt[0], m->vt[1], g->nh, g->hs, (int64_t)(M * C));
             MGPT_LAUNCH_CHECK();
         } else if (m->pk_gemm) {
             if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln1, m->apk, M, C, s)) != MGPT_OK) return rc;
@@ -364,19 +376,19 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_VT>(a, C, s)) != MGPT_OK) return rc;
         }
         if (!attn_block) {
-            ProfScope ps(P_ATTN, s);
-            const uint16_t *qh = m->qk[0], *ql = m->qk[1], *kh = m->qk[0] + M * C, *kl = (NP == 2) ? m->qk[1] + M * C : nullptr;
-            if (g->hs == 32)
-                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
-            else
-                hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
-            MGPT_LAUNCH_CHECK();
-        }
-        // ---- attention output projection + residual (+ stats of the new rows) ----
-        a.a_hi = m->y[0]; a.a_lo = m->y[1]; a.K = C; a.N = C;
-        a.w_hi = m->proj[l].hi; a.w_lo = m->proj[l].lo; a.out_scale = m->proj[l].inv_scale;
-        a.x_out = g->x; a.stats_out = m->stats;
-        if (!proj_fused) {
+            {
+                ProfScope ps(P_ATTN, s);
+                const uint16_t *qh = m->qk[0], *ql = m->qk[1], *kh = m->qk[0] + M * C, *kl = (NP == 2) ? m->qk[1] + M * C : nullptr;
+                if (g->hs == 32)
+                    hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
+                else
+                    hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
+                MGPT_LAUNCH_CHECK();
+            }
+            // ---- attention output projection + residual (+ stats of the new rows) ----
+            a.a_hi = m->y[0]; a.a_lo = m->y[1]; a.K = C; a.N = C;
+            a.w_hi = m->proj[l].hi; a.w_lo = m->proj[l].lo; a.out_scale = m->proj[l].inv_scale;
+            a.x_out = g->x; a.stats_out = m->stats;
             ProfScope ps(P_GEMM_PROJ, s);
             if (m->pk_gemm) {
                 a.w_hi = m->proj_pk2[l];
@@ -389,42 +401,23 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         if (m->mlp_fused) {
             // ---- whole MLP block in one kernel (hidden stays in registers) ----
             ProfScope ps(P_MLP_FUSED, s);
-            const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * (C == 256 ? 2 : 3);
-            static const int abl = getenv("MGPT_MLP_ABL") ? atoi(getenv("MGPT_MLP_ABL")) : 0;   // timing experiments only
-            static const bool no_pair = getenv("MGPT_NO_MLP_PAIR") != nullptr;            // A/B: one-wave-per-SIMD kernel instead
-            if (C == 160 && NP == 2 && abl != 0) {
-#define MGPT_ABL_LAUNCH(A_)                                                                                                         \
-    {                                                                                                                               \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5, A_>),                           \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                            \
-        hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5, A_>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2, \
-                           m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);                              \
-    }
-                if (abl == 1) MGPT_ABL_LAUNCH(1) else if (abl == 2) MGPT_ABL_LAUNCH(2) else if (abl == 3) MGPT_ABL_LAUNCH(3) else MGPT_ABL_LAUNCH(4)
-#undef MGPT_ABL_LAUNCH
-            } else if (C == 256 && NP == 2 && abl != 0) {
-#define MGPT_ABL_LAUNCH(A_)                                                                                                         \
-    hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 8, A_, 4, 2, 1, 4>), dim3((unsigned)(mlp_M / 128)), dim3(256), lds, s, mlp_x, P + lo.ln2, \
-                       m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)mlp_M);
-                if (abl == 1) MGPT_ABL_LAUNCH(1) else if (abl == 2) MGPT_ABL_LAUNCH(2) else if (abl == 3) MGPT_ABL_LAUNCH(3) else MGPT_ABL_LAUNCH(4)
-#undef MGPT_ABL_LAUNCH
-            } else if (C == 256 && !no_pair) {
-                hipLaunchKernelGGL((fastk::mlp_pair_kernel<T, NP, 8>), dim3((unsigned)(mlp_M / 128)), dim3(512),
-                                   lds + 8 * 2048 + 8 * 32 * 4 + 64, s, mlp_x, P + lo.ln2, m->mlp_pk[l], m->fc[l].inv_scale,
-                                   m->proj2[l].inv_scale);
-                if (!m->pk_gemm && l + 1 < g->L) {                       // the pair kernel leaves no LayerNorm statistics behind
+            if (C == 256) {
+                const int n_blocks = (int)(mlp_M / 128);
+                hipLaunchKernelGGL((fastk::mlp256_kernel<T, NP>), dim3((unsigned)n_blocks), dim3(256), (size_t)kM256Lds<NP>, s,
+                                   mlp_x, P + lo.ln2, m->mlp256_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->gelu_lut);
+                if (!m->pk_gemm && l + 1 < g->L) {                       // this kernel leaves no LayerNorm statistics behind
                     MGPT_LAUNCH_CHECK();
                     if ((rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
                 }
-            } else if (C == 256)
-                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 8, 0, 4, 2, 1, 4>), dim3((unsigned)(mlp_M / 128)), dim3(256), lds, s, mlp_x, P + lo.ln2,
-                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->stats, (int)mlp_M);
-            else if (C == 160)
-                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
-                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
-            else
-                hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 2>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
-                                   m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
+            } else {
+                const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 3;
+                if (C == 160)
+                    hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
+                                       m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
+                else
+                    hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 2>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
+                                       m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
+            }
             MGPT_LAUNCH_CHECK();
             continue;
         }
@@ -463,12 +456,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         }
         if (!fused_stats(C) && l + 1 < g->L && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
     }
-    {
-        static const bool no_last = getenv("MGPT_NO_LAST_SHORTCUT") != nullptr;
-        static const bool no_proj_fuse = getenv("MGPT_NO_PROJ_FUSE") != nullptr, no_attn_block = getenv("MGPT_NO_ATTN_BLOCK") != nullptr;
-        if (m->qkv_fused && g->hs == 32 && m->mlp_fused && !no_last && !no_proj_fuse && !no_attn_block)
-            return gpt_launch_head_at(g, m->x_last, (int64_t)C, 0, rows, d_logits, s);
-    }
+    if (attn_block) return gpt_launch_head_at(g, m->x_last, (int64_t)C, 0, rows, d_logits, s);
     return gpt_launch_head(g, rows, d_logits, s);
 }
 
@@ -519,7 +507,7 @@ int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_lo
             rc = build_mode<fastk::BF16T, 1>(g, m, false);
             if (rc == MGPT_OK) rc = (g->hs == 32) ? raise_attn_lds<fastk::BF16T, 1, 32>(attn_lds) : raise_attn_lds<fastk::BF16T, 1, 64>(attn_lds);
         }
-        if (rc != MGPT_OK) return rc;
+        if (rc != MGPT_OK) { free_mode(m); return rc; }         // no half-built planes survive a failed build (e.g. out of memory)
     }
     if (precision == MGPT_PREC_F16X3) return forward_chunk<fastk::F16T, 2>(g, m, d_tokens, rows, d_logits, s);
     return forward_chunk<fastk::BF16T, 1>(g, m, d_tokens, rows, d_logits, s);

@@ -1,0 +1,401 @@
+// gpt_kernels_c256.h -- 16-bit-MFMA kernels for n_embd = 256 (the MAPF-GPT-6M shape), gfx950.
+//
+// What round 1 got wrong for this shape, measured in round 2 (tools/probe_interleave.hip,
+// profiles/r02_probe_interleave.txt): when non-MFMA instructions are INTERLEAVED one v_mfma_f32_32x32x16 at a time, a
+// SIMD hides ~6 plain VALU instructions (or ~3 transcendentals, or 1-2 ds_read_b128 whose latency is covered) behind
+// every MFMA at no cost in MFMA rate; only when they are clumped before/after a run of MFMAs does their issue time add
+// (which is what round 1's probes measured, and what its kernels did: c_fc MFMAs -> GELU -> c_proj MFMAs with all eight
+// waves in lock-step between three barriers per hidden tile, 31 % MFMA issue).  The kernels here are therefore written as
+// software pipelines in which every MFMA carries its share of the VALU / LDS / DMA work of OTHER pipeline stages.
+#pragma once
+#include "gpt_kernels_fast.h"
+
+namespace mgpt {
+namespace fastk {
+
+// split of 4 values into hi/lo fp16 words with the packed conversions (10 instead of 13 VALU per 4 values; same
+// results as split4: hi = RNE fp16(v), lo = RNE fp16(v - hi) with v - hi exact in fp32)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <class T, int NP>
+__device__ __forceinline__ void split4p(const float v[4], u32x2 &hi, u32x2 &lo)
+{
+    if constexpr (NP == 2 && std::is_same<T, F16T>::value) {
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { x[i] = v[i]; asm("" : "+v"(x[i])); }     // one rounded fp32 value first (see split4)
+        const f16x2 a = __builtin_convertvector((f32x2){x[0], x[1]}, f16x2), b = __builtin_convertvector((f32x2){x[2], x[3]}, f16x2);
+        const float r0 = x[0] - (float)a[0], r1 = x[1] - (float)a[1], r2 = x[2] - (float)b[0], r3 = x[3] - (float)b[1];
+        const f16x2 c = __builtin_convertvector((f32x2){r0, r1}, f16x2), d = __builtin_convertvector((f32x2){r2, r3}, f16x2);
+        hi[0] = __builtin_bit_cast(unsigned, a); hi[1] = __builtin_bit_cast(unsigned, b);
+        lo[0] = __builtin_bit_cast(unsigned, c); lo[1] = __builtin_bit_cast(unsigned, d);
+    } else {
+        split4<T, NP>(v, hi, lo);
+    }
+}
+
+// the same for one pair of values -> one hi word and one lo word
+template <class T, int NP>
+__device__ __forceinline__ void split2p(float v0, float v1, unsigned &hi, unsigned &lo)
+{
+    asm("" : "+v"(v0));
+    asm("" : "+v"(v1));
+    if constexpr (NP == 2 && std::is_same<T, F16T>::value) {
+        const f16x2 a = __builtin_convertvector((f32x2){v0, v1}, f16x2);
+        const float r0 = v0 - (float)a[0], r1 = v1 - (float)a[1];
+        const f16x2 c = __builtin_convertvector((f32x2){r0, r1}, f16x2);
+        hi = __builtin_bit_cast(unsigned, a);
+        lo = __builtin_bit_cast(unsigned, c);
+    } else if constexpr (NP == 1 && std::is_same<T, BF16T>::value) {
+        hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
+        lo = 0u;
+    } else {
+        const uint16_t a0 = T::cvt(v0), a1 = T::cvt(v1);
+        const uint16_t b0 = (NP == 2) ? T::cvt(v0 - T::back(a0)) : (uint16_t)0, b1 = (NP == 2) ? T::cvt(v1 - T::back(a1)) : (uint16_t)0;
+        hi = (unsigned)a0 | ((unsigned)a1 << 16);
+        lo = (unsigned)b0 | ((unsigned)b1 << 16);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused MLP block for C = 256:  x <- x + c_proj(GELU(c_fc(LayerNorm(x))))   (model.py:84-89, 103)
+//
+// Workgroup = 4 waves = 128 tokens, ONE wave per SIMD with the whole 512-register file: a wave owns 32 tokens and keeps
+// the normalised rows as MFMA operand planes (128 registers) and the 32 x 256 output accumulators (128 registers) for the
+// whole kernel, "swapped" C/D layout as in mlp_fused_kernel (lane = token, registers = features).
+// Software pipeline over the 32 hidden tiles (32 hidden units each); iteration i runs, interleaved MFMA by MFMA,
+//     c_fc   of tile i+1   (48 MFMAs: 16 k-steps x 3 split passes)      -> pre-activations of the NEXT tile
+//     GELU + fp16 split of tile i (~90 VALU per 24 MFMAs, riding in the MFMA shadows)
+//     c_proj of tile i-1   (48 MFMAs: 8 output tiles x 2 k-steps x 3)   <- hidden planes of the PREVIOUS tile
+// so the matrix pipe never waits for the activation function and no barrier separates the stages.
+// Weights arrive as ONE stream in consumption order (pack_mlp256_kernel): "steps" of 8 fragment pairs (16 KiB in the
+// split mode) = 24 MFMAs per wave; an 8-slot LDS ring is filled by direct global->LDS loads 7 steps ahead (counted
+// vmcnt), one raw s_barrier per step hands a slot over; the first fragments of the next step are read before that barrier.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kM256Steps = 2 + 4 * 32 + 2;     // c_fc(0) | 32 x 4 mixed steps | c_proj(31)
+
+// GELU by table: gelu(v) = v Phi(v), Phi = standard normal CDF = (1 + erf(v / sqrt 2)) / 2 (model.py:86, exact-erf GELU).
+// Phi is tabulated on [-6, 6) in steps of 1/512 as pairs (Phi(v_i), Phi(v_i+1) - Phi(v_i)) and interpolated linearly:
+// |error in Phi| <= h^2 / 8 max|Phi''| = 1.2e-7, i.e. <= 1.2e-7 |v| in gelu (the rational approximation used elsewhere has
+// 1.6e-6); beyond +-6 the end entries apply (Phi = 1e-9 / 1 - 1e-9).  8 VALU + one 8-byte LDS gather per value instead of
+// 19 VALU: on this kernel the VALU port, which the MFMAs share, is the scarce resource (section 3 of DESIGN.md).
+constexpr int kGeluLutN = 6144;                // entries (float2 each: 48 KiB of LDS)
+constexpr float kGeluLutScale = 512.0f, kGeluLutBias = 3072.0f;
+
+template <class T, int NP>
+__global__ __launch_bounds__(256) void pack_mlp256_kernel(const float *__restrict__ fc_w, const float *__restrict__ pj_w,
+                                                          uint16_t *__restrict__ out, float scale1, float scale2)
+{
+    constexpr int C = 256, NT = 32;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (step, micro-step, lane)
+    if (gid >= (int64_t)kM256Steps * 8 * 64) return;
+    const int lane = (int)(gid & 63), ms = (int)((gid >> 6) & 7), s = (int)(gid >> 9);
+    const int i = lane & 31, h = lane >> 5;
+    int kind, t, idx;                                                     // kind 0: zeros, 1: c_fc (t, k-step), 2: c_proj (t, group)
+    if (s < 2) { kind = 1; t = 0; idx = 8 * s + ms; }
+    else if (s < 2 + 4 * NT) {
+        const int it = (s - 2) >> 2, q = (s - 2) & 3;
+        if (ms < 4) { kind = it + 1 < NT ? 1 : 0; t = it + 1; idx = 4 * q + ms; }
+        else { kind = it >= 1 ? 2 : 0; t = it - 1; idx = 4 * q + ms - 4; }
+    } else { kind = 2; t = NT - 1; idx = 8 * (s - (2 + 4 * NT)) + ms; }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        if (kind == 1) {                                                  // A rows = hidden units, k-slots = features (tau-permuted)
+            const int g = 8 * (idx & 1) + e;
+            const int feat = 32 * (idx >> 1) + (g & 3) + 8 * (g >> 2) + 4 * h;
+            v[e] = fc_w[(size_t)(32 * t + i) * C + feat] * scale1;
+        } else if (kind == 2) {                                           // A rows = output features of tile j, k-slots = hidden units
+            const int kk = idx >> 3, j = idx & 7, g = 8 * kk + e;
+            const int u = 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+            v[e] = pj_w[(size_t)(32 * j + i) * (4 * C) + u] * scale2;
+        } else v[e] = 0.f;
+    }
+    u32x2 h0, l0, h1, l1;
+    split4<T, NP>(v, h0, l0);
+    split4<T, NP>(v + 4, h1, l1);
+    u32x4 hi, lo;
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+    uint16_t *dst = out + (((size_t)s * 8 + ms) * NP) * 512 + (size_t)lane * 8;
+    *reinterpret_cast<u32x4 *>(dst) = hi;
+    if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
+}
+
+// ABL (tools/probe_mlp256.hip only; the library instantiates ABL = 0): 1 no weight DMA in the loop, 2 no GELU table gather,
+// 4 no barrier, 8 no MFMAs, 16 no fragment reads in the loop -- results are wrong unless ABL == 0.
+//
+// Register plan (one wave per SIMD, 512 registers): operand planes xn 128 + hidden planes 2 x 16 + GELU temporaries in the
+// arch VGPRs; output accumulators 128 + pre-activation accumulators 2 x 16 + weight fragments 32 in the accumulator file.
+// The fragments are read by inline-asm ds_read_b128 with accumulator-file destinations (MFMA takes A/B operands from
+// there directly): left to itself hipcc keeps them in arch VGPRs, runs out, and spills INSIDE the loop -- and every scratch
+// reload is a VMEM load whose s_waitcnt vmcnt(0) drains the whole weight ring (measured: 3.3 -> 5.0 ms per launch); a
+// compiler-visible LDS read has the same effect (hipcc orders it behind every LDS-DMA in flight), hence asm for the
+// table gathers as well.  Asm reads are invisible to hipcc's lgkmcnt bookkeeping: every chunk opens with an explicit
+// s_waitcnt lgkmcnt + sched_barrier(0) (no MFMA may be hoisted above the wait: cdna guide 5.4 rule 18, 5.7).
+// (A persistent variant -- one workgroup per CU walking the blocks with the ring running across block seams, residual rows
+//  prefetched into the dead operand-plane registers -- was built and measured: no gain, and hipcc hoists the 128 registers
+//  of LayerNorm gains out of the block loop and spills; one block per workgroup it is.)
+template <class T, int NP, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, const float *__restrict__ gain,
+                                                        const uint16_t *__restrict__ wstream, float inv1, float inv2,
+                                                        const float2 *__restrict__ gelu_lut)
+{
+    constexpr int C = 256, CT = 8, KS = 16, NT = 32;
+    constexpr int MS = 8;                                  // fragment pairs per step
+    constexpr int STEP = MS * NP * 1024;                   // bytes per step
+    constexpr int NSLOT = 6;
+    constexpr int LUT_BYTES = kGeluLutN * 8;
+    constexpr int PW = MS * NP / 4;                        // direct-to-LDS loads per wave per step
+    constexpr int NSTEP = kM256Steps;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NSLOT][STEP] ring, then the GELU table
+    unsigned char *lut = smem + NSLOT * STEP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(size_t)smem + lane16;                 // LDS byte address of this lane's 16 bytes in fragment 0 of slot 0
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(wave * PW) * 1024;   // wave-uniform
+    int gstep = 0;                                         // steps done so far (ring position of the NEXT step after sync)
+
+    {   // GELU table -> LDS (48 pieces of 1 KiB, 12 per wave); older than every ring piece, so the first counted wait covers it
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(gelu_lut) + (size_t)wave * (LUT_BYTES / 4);
+#pragma unroll
+        for (int i = 0; i < LUT_BYTES / 4096; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024 + lane16), (lds_void_t *)(lut + wave * (LUT_BYTES / 4) + i * 1024), 16, 0, 0);
+    }
+    auto issue = [&](int src_step, int slot) {             // this wave moves pieces wave*PW .. +PW of a step
+        const unsigned char *src = wbase + (size_t)src_step * STEP;                                              // scalar address math
+        unsigned char *dst = smem + (size_t)slot * STEP + (size_t)(wave * PW) * 1024;
+#pragma unroll
+        for (int i = 0; i < PW; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024 + lane16), (lds_void_t *)(dst + i * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < NSLOT - 1; s_++) issue(s_, s_);
+
+    // ---- ring protocol: sync(s) at the top of step s ----
+    //   after the barrier the steps up to s+1 have landed for every wave (each wave counted its own pieces) and every wave
+    //   has finished reading the slot of step s-1, which is refilled with step s+NSLOT-1
+    auto sync = [&](int s_) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3)) : "memory");
+        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+        if (!(ABL & 1) && s_ + NSLOT - 1 < NSTEP) issue(s_ + NSLOT - 1, (gstep + NSLOT - 1) % NSLOT);
+        gstep++;
+    };
+
+    // ---- 32 x 256 row block in swapped layout, LayerNorm in-lane (two-pass, model.py:19-20) ----
+    float *xrow = x + ((int64_t)blockIdx.x * 128 + wave * 32 + r) * C;    // this lane's token
+    f32x16 acc[CT];                                        // x now, output accumulators later
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+            acc[j][4 * gq] = v[0]; acc[j][4 * gq + 1] = v[1]; acc[j][4 * gq + 2] = v[2]; acc[j][4 * gq + 3] = v[3];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)C;
+    float qv = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) { const float d = acc[j][g] - mean; qv += d * d; }
+    qv += __shfl_xor(qv, 32);
+    const float rstd = rsqrtf(qv / (float)C + 1e-5f);
+    u32x4 xn[KS][2];                                       // B operand of c_fc: k-step ks <-> registers 8 (ks & 1) .. + 8 of tile ks >> 1
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const int j = ks >> 1, g0 = 8 * (ks & 1);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 4 * h);
+        const f32x4 gb = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 8 + 4 * h);
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v0[e] = (acc[j][g0 + e] - mean) * rstd * ga[e];
+            v1[e] = (acc[j][g0 + 4 + e] - mean) * rstd * gb[e];
+        }
+        u32x2 h0, l0, h1, l1;
+        split4<T, NP>(v0, h0, l0);
+        split4<T, NP>(v1, h1, l1);
+        xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
+        xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
+    }
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) acc[j][g] = 0.f;
+
+    // ---- weight fragments (accumulator file): two small register sets of 2 pairs each.  Every step uses pairs c and 4+c in
+    //      chunk c; chunk c requests the pairs of chunk c+1 (chunk 3: pairs 0 and 4 of the NEXT step, whose slot has landed),
+    //      so a fragment is requested one chunk = 6 MFMAs (>= 192 cycles, LDS latency is ~130) before its first MFMA and
+    //      both register files keep > 50 registers of slack (with 64 fragment registers hipcc started to copy freshly
+    //      requested, not yet landed fragments between the files). ----
+    u32x4 wb[2][2][2];                                     // [set][0: pair c, 1: pair 4+c][plane]
+    auto lds_pair = [&](unsigned slot_addr, auto ms_c, u32x4 (&dst)[2]) {  // fragment pair ms of the slot at LDS address slot_addr
+        constexpr int ms = decltype(ms_c)::value;
+        if ((ABL & 16) && gstep > 2) return;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst[0]) : "v"(slot_addr), "n"(ms * NP * 1024) : "memory");
+        if (NP == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst[1]) : "v"(slot_addr), "n"((ms * NP + 1) * 1024) : "memory");
+        else dst[1] = dst[0];
+    };
+    unsigned cur_addr = 0, nxt_addr = 0;                   // slots of this step and of the next one
+    auto step_begin = [&](int s_) {
+        sync(s_);
+        cur_addr = lds0 + (unsigned)((gstep - 1) % NSLOT) * STEP;
+        nxt_addr = lds0 + (unsigned)(gstep % NSLOT) * STEP;
+    };
+    // chunk prologue: this chunk's pairs (requested one chunk ago) must have landed; then request the next chunk's.
+    // GATHERS: chunk 0 of a mixed step issues four table gathers after its requests; they may still be in flight in chunk 1
+    // (consumed in chunks 2 and 3).
+    auto chunk_begin = [&](auto c_c, bool has_next, bool gathers = false) {
+        constexpr int c = decltype(c_c)::value;
+        if (gathers && c == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (c < 3) { lds_pair(cur_addr, std::integral_constant<int, (c + 1) % 4>{}, wb[(c + 1) & 1][0]); lds_pair(cur_addr, std::integral_constant<int, 4 + (c + 1) % 4>{}, wb[(c + 1) & 1][1]); }
+        else if (has_next) { lds_pair(nxt_addr, std::integral_constant<int, 0>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, 4>{}, wb[0][1]); }
+    };
+    // one split product step on two independent accumulators, passes interleaved (no back-to-back dependent MFMAs)
+    auto mma2 = [&](const u32x4 (&wa)[2], const u32x4 (&ba)[2], f32x16 &ca, const u32x4 (&wb)[2], const u32x4 (&bb)[2], f32x16 &cb) {
+        if (ABL & 8) { asm volatile("" :: "a"(wa[0]), "a"(wa[1]), "a"(wb[0]), "a"(wb[1]), "v"(ba[0]), "v"(bb[0]), "v"(ba[1]), "v"(bb[1])); return; }
+        if (NP == 2) {
+            ca = T::mfma(wa[1], ba[0], ca); cb = T::mfma(wb[1], bb[0], cb);
+            ca = T::mfma(wa[0], ba[1], ca); cb = T::mfma(wb[0], bb[1], cb);
+        }
+        ca = T::mfma(wa[0], ba[0], ca); cb = T::mfma(wb[0], bb[0], cb);
+    };
+    // inside a chunk every MFMA is followed by its share of the chunk's VALU work
+    auto pin = [&](auto n_valu_c) {
+        constexpr int n_valu = decltype(n_valu_c)::value;
+#pragma unroll
+        for (int n = 0; n < (NP == 2 ? 6 : 2); n++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (n_valu > 0) __builtin_amdgcn_sched_group_barrier(0x002, n_valu, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using VN = std::integral_constant<int, (NP == 2 ? 4 : 12)>;
+    using V0 = std::integral_constant<int, 0>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    const float lut_scale = inv1 * kGeluLutScale;
+    const unsigned lut_addr = (unsigned)(size_t)lut;
+
+    f32x16 hA, hB;                                         // pre-activations: one accumulates c_fc(i+1) while the other feeds GELU(i)
+#pragma unroll
+    for (int g = 0; g < 16; g++) { hA[g] = 0.f; hB[g] = 0.f; }
+
+    // ---- steps 0, 1: c_fc of hidden tile 0 (two chains, summed) ----
+    auto step_fc0 = [&](int s_, bool first) {
+        step_begin(s_);
+        if (first) { lds_pair(cur_addr, I0{}, wb[0][0]); lds_pair(cur_addr, std::integral_constant<int, 4>{}, wb[0][1]); }   // the very first pairs
+        auto chunk = [&](auto c_c) {
+            constexpr int c = decltype(c_c)::value;
+            chunk_begin(c_c, true);
+            mma2(wb[c & 1][0], xn[8 * (first ? 0 : 1) + c], hA, wb[c & 1][1], xn[8 * (first ? 0 : 1) + 4 + c], hB);
+            pin(V0{});
+        };
+        chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
+    };
+    step_fc0(0, true);
+    step_fc0(1, false);
+#pragma unroll
+    for (int g = 0; g < 16; g++) { hA[g] += hB[g]; hB[g] = 0.f; }
+
+    u32x4 hfA[2][2], hfB[2][2];                            // hidden planes [k-step kk][plane]: B operand of c_proj
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) { hfA[kk][pl][e] = 0u; hfB[kk][pl][e] = 0u; }
+
+    // one step of a pipeline iteration: fragment pairs 0-3 = c_fc(i+1) k-steps 4q.., 4-7 = c_proj(i-1) groups 4q..
+    // chunk c: c_fc k-step 4q+c and c_proj group 4q+c; GELU of pre-activations 4q .. 4q+3 (hidden units tau(4q + e, h) of
+    // tile i) by table: chunk 0 forms the four table addresses and issues the gathers, chunks 2 and 3 interpolate,
+    // multiply and split one pair each (the gathers have >= 2 chunks = 12 MFMAs to land)
+    auto step_main = [&](int s_, auto q_c, const f32x16 &hsrc, f32x16 &hdst, const u32x4 (&hfi)[2][2], u32x4 (&hfo)[2][2]) {
+        constexpr int q = decltype(q_c)::value;
+        step_begin(s_);
+        float gvv[4], gfr[4];
+        f32x2 gtab[4];                                     // (Phi, dPhi) pairs, gathered by asm ds_read_b64: a compiler-visible LDS read
+        auto chunk = [&](auto c_c) {                       // would make hipcc drain the weight ring (vmcnt(0)) before it
+            constexpr int c = decltype(c_c)::value;
+            chunk_begin(c_c, true, true);
+            if (c == 2) asm volatile("" : "+v"(gtab[0]), "+v"(gtab[1]), "+v"(gtab[2]), "+v"(gtab[3]));   // gathers landed (lgkmcnt(0) above)
+            if (c == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float hv = hsrc[4 * q + e];
+                    gvv[e] = hv * inv1;
+                    const float t = __builtin_amdgcn_fmed3f(fmaf(hv, lut_scale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.01f);
+                    gfr[e] = __builtin_amdgcn_fractf(t);
+                    const unsigned idx = (unsigned)t;
+                    if (ABL & 2) gtab[e] = (f32x2){1.f, 0.f};
+                    else asm volatile("ds_read_b64 %0, %1" : "=v"(gtab[e]) : "v"(lut_addr + idx * 8u) : "memory");
+                }
+            }
+            if (c >= 2) {
+                constexpr int e0 = 2 * (c >= 2 ? c - 2 : 0);
+                const float g0 = gvv[e0] * fmaf(gfr[e0], gtab[e0][1], gtab[e0][0]), g1 = gvv[e0 + 1] * fmaf(gfr[e0 + 1], gtab[e0 + 1][1], gtab[e0 + 1][0]);
+                unsigned hi, lo;
+                split2p<T, NP>(g0, g1, hi, lo);
+                hfo[q >> 1][0][2 * (q & 1) + (c >= 2 ? c - 2 : 0)] = hi;
+                hfo[q >> 1][1][2 * (q & 1) + (c >= 2 ? c - 2 : 0)] = lo;
+            }
+            constexpr int g = 4 * q + c;                   // c_proj group: k-step g >> 3 of the slice, output tile g & 7
+            mma2(wb[c & 1][0], xn[4 * q + c], hdst, wb[c & 1][1], hfi[g >> 3], acc[g & 7]);
+            pin(VN{});
+        };
+        chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
+    };
+    // one pipeline iteration = 4 steps: c_fc(i+1) -> hdst, GELU(hsrc) -> hfo, c_proj(hfi) -> acc
+    auto iteration = [&](int sbase, const f32x16 &hsrc, f32x16 &hdst, const u32x4 (&hfi)[2][2], u32x4 (&hfo)[2][2]) {
+        step_main(sbase + 0, I0{}, hsrc, hdst, hfi, hfo);
+        step_main(sbase + 1, I1{}, hsrc, hdst, hfi, hfo);
+        step_main(sbase + 2, I2{}, hsrc, hdst, hfi, hfo);
+        step_main(sbase + 3, I3{}, hsrc, hdst, hfi, hfo);
+    };
+
+#pragma unroll 1
+    for (int i = 0; i < NT; i += 2) {
+        iteration(2 + 4 * i, hA, hB, hfB, hfA);            // even tile: GELU(hA) -> hfA, c_fc(i+1) -> hB, c_proj(hfB = tile i-1)
+#pragma unroll
+        for (int g = 0; g < 16; g++) hA[g] = 0.f;
+        iteration(2 + 4 * (i + 1), hB, hA, hfA, hfB);      // odd tile
+#pragma unroll
+        for (int g = 0; g < 16; g++) hB[g] = 0.f;
+    }
+    // ---- last two steps: c_proj of hidden tile 31 (its planes are in hfB): pair ms = output tile ms, k-step = step ----
+    auto step_pj31 = [&](int s_, bool last) {
+        step_begin(s_);
+        auto chunk = [&](auto c_c) {
+            constexpr int c = decltype(c_c)::value;
+            chunk_begin(c_c, !last);
+            mma2(wb[c & 1][0], hfB[last ? 1 : 0], acc[c], wb[c & 1][1], hfB[last ? 1 : 0], acc[4 + c]);
+            pin(V0{});
+        };
+        chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
+    };
+    step_pj31(2 + 4 * NT, false);
+    step_pj31(2 + 4 * NT + 1, true);
+
+    // ---- residual add and store ----
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+            f32x4 cur = *dst;
+#pragma unroll
+            for (int e = 0; e < 4; e++) cur[e] += acc[j][4 * gq + e] * inv2;
+            *dst = cur;
+        }
+}
+
+}  // namespace fastk
+}  // namespace mgpt
