@@ -42,6 +42,9 @@ struct ModeState {          // one precision mode
     // C = 256 (6M): mlp256_kernel's weight stream in consumption order, per layer [step][micro-step][plane][lane][8]
     std::vector<uint16_t *> mlp256_pk;
     float2 *gelu_lut = nullptr;                // mlp256_kernel's Phi table (kGeluLutN pairs)
+    // C = 256, head size 32 (6M): attn256_kernel's c_attn stream in consumption order, per layer
+    std::vector<uint16_t *> attn256_pk;
+    bool attn256 = false;
     // register-resident LN+QKV (C = 64 / 160): per layer [tile][k-step][plane][lane][8] of c_attn.weight
     std::vector<uint16_t *> qkv_pk;
     bool qkv_fused = false;
@@ -49,6 +52,7 @@ struct ModeState {          // one precision mode
     std::vector<uint16_t *> proj_pk;
     // last-layer shortcut: new residual rows of token 255 only, [round_up(max_rows, 256)][C] fp32
     float *x_last = nullptr;
+    uint16_t *y_last = nullptr;                // packed-GEMM path: attention output of token 255 of every row, PK planes [rows_pad][C]
     // PK GEMM path (C % 256 == 0: 6M, 85M): weights as MFMA-fragment streams, activations produced in the same layout
     bool pk_gemm = false;
     std::vector<uint16_t *> attn_pk2, proj_pk2, fc_pk2, proj2_pk2;   // [row tile][k-step][plane][lane][8]
@@ -84,6 +88,8 @@ float pick_scale(const float *h_w, size_t n, bool f16)
     return ldexpf(1.0f, e);
 }
 
+template <int NP>
+constexpr int kA256Lds = 5 * 8 * NP * 1024 + NP * (256 * 80 + 32 * 528);    // attn256_kernel: 5-slot weight ring + K and V^T planes of a head
 template <int NP>
 constexpr int kM256Lds = 6 * 8 * NP * 1024 + fastk::kGeluLutN * 8;      // mlp256_kernel: 6-slot weight ring + GELU table
 
@@ -138,6 +144,20 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         }
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kM256Lds<NP>));
+        m->attn256 = (g->hs == 32 && g->nh == 8);
+        if (m->attn256) {
+            const size_t n16 = (size_t)8 * fastk::kA256StepsPerHead * 8 * NP * 512;
+            m->attn256_pk.assign(g->L, nullptr);
+            for (int l = 0; l < g->L; l++) {
+                MGPT_HIP(hipMalloc(&m->attn256_pk[l], n16 * sizeof(uint16_t)));
+                ProfScope ps(P_PACK, nullptr);
+                hipLaunchKernelGGL((fastk::pack_attn256_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)8 * fastk::kA256StepsPerHead * 8 * 64, 256)), dim3(256), 0,
+                                   nullptr, g->params + g->layers[l].attn_w, m->attn256_pk[l], 1.0f / m->attn[l].inv_scale);
+                MGPT_LAUNCH_CHECK();
+            }
+            MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256_kernel<T, NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
+            MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256_kernel<T, NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
+        }
     } else if (m->mlp_fused) {
         const size_t frags = C / 16 + 2 * (C / 32), nt = 4 * C / 32;
         const size_t n16 = nt * frags * NP * 512;
@@ -217,6 +237,10 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         const size_t nl = (size_t)((g->max_rows + 255) / 256) * 256 * C;
         MGPT_HIP(hipMalloc(&m->x_last, nl * sizeof(float)));
         MGPT_HIP(hipMemset(m->x_last, 0, nl * sizeof(float)));           // padding rows stay finite
+        if (m->pk_gemm) {
+            MGPT_HIP(hipMalloc(&m->y_last, nl * NP * sizeof(uint16_t)));
+            MGPT_HIP(hipMemset(m->y_last, 0, nl * NP * sizeof(uint16_t)));
+        }
     }
     const size_t M = (size_t)g->max_rows * kT;
     MGPT_HIP(hipMalloc(&m->stats, M * sizeof(float2)));
@@ -238,6 +262,7 @@ void free_mode(ModeState *m)
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
     for (auto *p : m->mlp_pk) (void)hipFree(p);
     for (auto *p : m->mlp256_pk) (void)hipFree(p);
+    for (auto *p : m->attn256_pk) (void)hipFree(p);
     (void)hipFree(m->gelu_lut);
     for (auto *p : m->qkv_pk) (void)hipFree(p);
     for (auto *p : m->proj_pk) (void)hipFree(p);
@@ -245,6 +270,7 @@ void free_mode(ModeState *m)
     (void)hipFree(m->apk);
     (void)hipFree(m->stats);
     (void)hipFree(m->x_last);
+    (void)hipFree(m->y_last);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
 }
@@ -344,7 +370,8 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         a.w_hi = m->attn[l].hi; a.w_lo = m->attn[l].lo; a.out_scale = m->attn[l].inv_scale;
         a.N = 2 * C; a.o_hi = m->qk[0]; a.o_lo = m->qk[1];
         // last layer: only token 255 is needed downstream (model.py:186) -> compact buffer, MLP and head on `rows` tokens
-        const bool last_short = attn_block && l == g->L - 1;
+        const bool last_short = (attn_block || m->pk_gemm) && l == g->L - 1;
+        const int rows_pad = ((rows + 255) / 256) * 256;
         if (attn_block) {
             // ---- LN1 + QKV + attention + out-projection + residual in one kernel: q, k, v, y stay on chip ----
             ProfScope ps(P_ATTN, s);
@@ -357,6 +384,16 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, false); else if (emb) MGPT_ATTN_BLOCK(5, false, true); else MGPT_ATTN_BLOCK(5, false, false); }
             else { if (last_short) MGPT_ATTN_BLOCK(2, true, false); else if (emb) MGPT_ATTN_BLOCK(2, false, true); else MGPT_ATTN_BLOCK(2, false, false); }
 #undef MGPT_ATTN_BLOCK
+            MGPT_LAUNCH_CHECK();
+        } else if (m->attn256) {
+            // ---- LN1 + QKV + attention in one kernel (q, k, v stay on chip) -> y operand planes for the out-projection ----
+            ProfScope ps(P_ATTN, s);
+            if (last_short)
+                hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, true>), dim3((unsigned)rows), dim3(512), (size_t)kA256Lds<NP>, s, g->x, P + lo.ln1,
+                                   m->attn256_pk[l], m->attn[l].inv_scale, scale_log2e, m->y_last);
+            else
+                hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, false>), dim3((unsigned)rows), dim3(512), (size_t)kA256Lds<NP>, s, g->x, P + lo.ln1,
+                                   m->attn256_pk[l], m->attn[l].inv_scale, scale_log2e, m->y[0]);
             MGPT_LAUNCH_CHECK();
         } else if (m->pk_gemm) {
             if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln1, m->apk, M, C, s)) != MGPT_OK) return rc;
@@ -376,19 +413,28 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_VT>(a, C, s)) != MGPT_OK) return rc;
         }
         if (!attn_block) {
-            {
+            const bool ls = last_short && m->pk_gemm;       // only token 255 of every row from here on
+            if (!m->attn256) {
                 ProfScope ps(P_ATTN, s);
                 const uint16_t *qh = m->qk[0], *ql = m->qk[1], *kh = m->qk[0] + M * C, *kl = (NP == 2) ? m->qk[1] + M * C : nullptr;
+                uint16_t *yh = ls ? m->y_last : m->y[0];
                 if (g->hs == 32)
-                    hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
+                    hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 32>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], yh, m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0, ls ? 1 : 0);
                 else
-                    hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], m->y[0], m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0);
+                    hipLaunchKernelGGL((fastk::attn16_kernel<T, NP, 64>), dim3(rows * g->nh), dim3(512), attn_lds, s, qh, ql, kh, kl, m->vt[0], m->vt[1], yh, m->y[1], g->nh, scale_log2e, m->pk_gemm ? 1 : 0, m->pk_gemm ? 1 : 0, ls ? 1 : 0);
+                MGPT_LAUNCH_CHECK();
+            }
+            if (ls) {
+                ProfScope ps(P_EMBED, s);
+                hipLaunchKernelGGL(fastk::gather_last_kernel, dim3((unsigned)cdiv64((int64_t)rows_pad * (C / 4), 256)), dim3(256), 0, s, g->x, m->x_last, rows,
+                                   rows_pad, C);
                 MGPT_LAUNCH_CHECK();
             }
             // ---- attention output projection + residual (+ stats of the new rows) ----
-            a.a_hi = m->y[0]; a.a_lo = m->y[1]; a.K = C; a.N = C;
+            a.a_hi = ls ? m->y_last : m->y[0]; a.a_lo = m->y[1]; a.K = C; a.N = C;
             a.w_hi = m->proj[l].hi; a.w_lo = m->proj[l].lo; a.out_scale = m->proj[l].inv_scale;
-            a.x_out = g->x; a.stats_out = m->stats;
+            a.x_out = ls ? m->x_last : g->x; a.stats_out = m->stats;
+            if (ls) a.M = rows_pad;
             ProfScope ps(P_GEMM_PROJ, s);
             if (m->pk_gemm) {
                 a.w_hi = m->proj_pk2[l];
@@ -397,7 +443,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         }
         if (!fused_stats(C) && !m->pk_gemm && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
         float *mlp_x = last_short ? m->x_last : g->x;
-        const int64_t mlp_M = last_short ? (int64_t)((rows + 255) / 256) * 256 : M;
+        const int64_t mlp_M = last_short ? (int64_t)rows_pad : M;
         if (m->mlp_fused) {
             // ---- whole MLP block in one kernel (hidden stays in registers) ----
             ProfScope ps(P_MLP_FUSED, s);
@@ -423,7 +469,8 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         }
         if (m->pk_gemm) {
             // ---- LN2 -> PK planes; FC + GELU -> hidden PK planes; proj2 + residual ----
-            if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln2, m->apk, M, C, s)) != MGPT_OK) return rc;
+            if ((rc = launch_ln_pack<T, NP>(mlp_x, P + lo.ln2, m->apk, mlp_M, C, s)) != MGPT_OK) return rc;
+            a.M = (int)mlp_M;
             a.a_hi = m->apk; a.K = C; a.N = 4 * C; a.w_hi = m->fc_pk2[l]; a.out_scale = m->fc[l].inv_scale;
             a.o_hi = m->hbuf[0]; a.o_pk = 1;
             {
@@ -431,7 +478,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_GELU>(a, s)) != MGPT_OK) return rc;
             }
             a.a_hi = m->hbuf[0]; a.K = 4 * C; a.N = C; a.w_hi = m->proj2_pk2[l]; a.out_scale = m->proj2[l].inv_scale;
-            a.x_out = g->x; a.stats_out = nullptr;
+            a.x_out = mlp_x; a.stats_out = nullptr;
             {
                 ProfScope ps(P_GEMM_PROJ2, s);
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
@@ -456,7 +503,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         }
         if (!fused_stats(C) && l + 1 < g->L && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
     }
-    if (attn_block) return gpt_launch_head_at(g, m->x_last, (int64_t)C, 0, rows, d_logits, s);
+    if (attn_block || m->pk_gemm) return gpt_launch_head_at(g, m->x_last, (int64_t)C, 0, rows, d_logits, s);
     return gpt_launch_head(g, rows, d_logits, s);
 }
 

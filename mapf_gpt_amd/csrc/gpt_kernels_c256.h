@@ -397,5 +397,384 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused attention front half for C = 256, head size 32:  y = attention(LayerNorm(x))   (model.py:46-68, 102), one row
+// (256 tokens) per workgroup, 8 waves x 32 tokens, two waves per SIMD (256 registers each).  q, k, v never touch HBM;
+// the only traffic is x in (1 KiB per token) and the y operand planes out (1 KiB per token, packed-fragment layout, which
+// the out-projection consumes as they are).  Replaces ln_pack_kernel + 2 x gemm_pk_kernel + attn16_kernel for this shape.
+//   per head (8 of them), per wave:
+//     steps 0-3  q and k tiles together (both read the same token planes): chunk = k-step ks of both, 6 MFMAs on two
+//                independent accumulators; k -> LDS planes sK[plane][key][d], q stays in registers as the B operand of S
+//     steps 4-5  v tile ("natural": lane = d) on two chains -> transposed LDS planes sV[plane][d][key]
+//     barrier    (every wave contributed its 32 keys)
+//     attention  8 key tiles: S^T = K Q^T (6 MFMAs), online softmax in-lane (a lane owns one query), P split in-lane
+//                into the B operand of O^T = V^T P^T (6 MFMAs); K / V^T fragments by asm ds_read_b128
+//   the register -> row map tau(g, h) = (g & 3) + 8 (g >> 2) + 4 h is the same for "d of a token" (q, k tiles), "token of
+//   a d" (v tile) and "key of a query" (S^T tile): register octets are MFMA k-slot groups everywhere, nothing is transposed.
+// c_attn.weight arrives as ONE stream in consumption order (pack_attn256_kernel): 6 steps of 8 fragment pairs per head,
+// through a 5-slot LDS ring filled by direct global->LDS loads 4 steps ahead (the next head's first steps land during
+// the attention), counted vmcnt, one raw s_barrier per step.  Every LDS access inside the head loop is inline asm: a
+// compiler-visible LDS access makes hipcc drain the LDS-DMA ring (s_waitcnt vmcnt(0)) in front of it.
+// LAST (last layer, model.py:186): all keys and values, but q / attention only for the wave that owns token 255, whose
+// output row goes to row b of the compact matrix y (packed-fragment layout over rows instead of tokens).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kA256StepsPerHead = 6;
+
+template <class T, int NP>
+__global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restrict__ w, uint16_t *__restrict__ out, float scale)
+{
+    constexpr int C = 256, NH = 8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (global step, pair, lane)
+    if (gid >= (int64_t)NH * kA256StepsPerHead * 8 * 64) return;
+    const int lane = (int)(gid & 63), ms = (int)((gid >> 6) & 7), G = (int)(gid >> 9);
+    const int head = G / kA256StepsPerHead, st = G - head * kA256StepsPerHead;
+    const int i = lane & 31, h = lane >> 5;
+    int which, ks;
+    if (st < 4) { which = ms & 1; ks = 4 * st + (ms >> 1); }              // q and k interleaved per k-step
+    else { which = 2; ks = 8 * (st - 4) + ms; }
+    const float *row = w + (size_t)(which * C + head * 32 + i) * C;        // c_attn.weight row (model.py:50)
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int g = 8 * (ks & 1) + e;
+        v[e] = row[32 * (ks >> 1) + (g & 3) + 8 * (g >> 2) + 4 * h] * scale;
+    }
+    u32x2 h0, l0, h1, l1;
+    split4<T, NP>(v, h0, l0);
+    split4<T, NP>(v + 4, h1, l1);
+    u32x4 hi, lo;
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+    uint16_t *dst = out + (((size_t)G * 8 + ms) * NP) * 512 + (size_t)lane * 8;
+    *reinterpret_cast<u32x4 *>(dst) = hi;
+    if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
+}
+
+template <class T, int NP, bool LAST>
+__global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict__ x, const float *__restrict__ gain,
+                                                         const uint16_t *__restrict__ wstream, float inv_scale, float scale_log2e,
+                                                         uint16_t *__restrict__ y)
+{
+    constexpr int C = 256, CT = 8, KS = 16, NH = 8, HS = 32, NW = 8;
+    constexpr int MS = 8;                                  // fragment pairs per step
+    constexpr int STEP = MS * NP * 1024;
+    constexpr int NSLOT = 5;
+    constexpr int PW = MS * NP / NW;                       // direct-to-LDS loads per wave per step (2 in the split mode)
+    constexpr int SPH = kA256StepsPerHead, NSTEP = NH * SPH;
+    constexpr int KROW = 80, VROW = 528;                   // padded LDS rows (bytes): conflict-free b128 reads
+    constexpr int NST = 4 * NP;                            // y stores per head per wave (8-byte pieces, coalesced 512 B each)
+    static_assert(PW >= 1, "a wave moves at least one piece per step");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [NSLOT][STEP] ring | sK [NP][256][KROW] | sV [NP][32][VROW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.x;
+    const int tok0 = wave * 32;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(size_t)smem + lane16;
+    const unsigned sK = (unsigned)(size_t)smem + NSLOT * STEP, sV = sK + NP * kT * KROW;
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(wave * PW) * 1024;   // wave-uniform
+    const bool full = !LAST || wave == NW - 1;             // wave-uniform: does this wave run the attention?
+    int gstep = 0;
+
+    auto issue = [&](int G) {                              // global step G -> slot G % NSLOT
+        const unsigned char *src = wbase + (size_t)G * STEP;
+        unsigned char *dst = smem + (size_t)(G % NSLOT) * STEP + (size_t)(wave * PW) * 1024;
+#pragma unroll
+        for (int i = 0; i < PW; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024 + lane16), (lds_void_t *)(dst + i * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int G = 0; G < NSLOT - 1; G++) issue(G);
+
+    // ---- LayerNorm of this lane's token; operand planes in registers ----
+    u32x4 xn[KS][2];
+    {
+        const float *xrow = x + (b * kT + tok0 + r) * C;
+        f32x16 xv[CT];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; j++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+                xv[j][4 * gq] = v[0]; xv[j][4 * gq + 1] = v[1]; xv[j][4 * gq + 2] = v[2]; xv[j][4 * gq + 3] = v[3];
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        s += __shfl_xor(s, 32);
+        const float mean = s / (float)C;
+        float qv = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) { const float d = xv[j][g] - mean; qv += d * d; }
+        qv += __shfl_xor(qv, 32);
+        const float rstd = rsqrtf(qv / (float)C + 1e-5f);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int j = ks >> 1, g0 = 8 * (ks & 1);
+            const f32x4 ga = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 4 * h);
+            const f32x4 gb = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 8 + 4 * h);
+            float v0[4], v1[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                v0[e] = (xv[j][g0 + e] - mean) * rstd * ga[e];
+                v1[e] = (xv[j][g0 + 4 + e] - mean) * rstd * gb[e];
+            }
+            u32x2 h0, l0, h1, l1;
+            split4<T, NP>(v0, h0, l0);
+            split4<T, NP>(v1, h1, l1);
+            xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
+            xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
+        }
+    }
+
+    // ---- ring protocol: sync at the top of global step G.  After the barrier the steps up to G+1 have landed for every wave
+    //      and the slot of step G-1 is free; it is refilled with step G+NSLOT-1.  STORES = y stores of this wave that are
+    //      younger than the pieces waited for (they retire in issue order behind them). ----
+    auto sync = [&](bool stores_younger) {                 // (wave-uniform flag)
+        if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3) + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (gstep + NSLOT - 1 < NSTEP) issue(gstep + NSLOT - 1);
+        gstep++;
+    };
+    // (all asm destinations are arch VGPRs here: with no "a" constraint in the kernel hipcc gives the whole 256-register
+    //  budget of a two-waves-per-SIMD kernel to the arch VGPRs, MFMA accumulators included; with one it splits 128 / 128
+    //  and the 128 registers of operand planes no longer fit either half)
+    u32x4 wb[2][2][2];                                     // weight fragments: [set][pair 2c / 2c+1][plane]
+    auto lds_frag = [&](unsigned addr, auto off_c, u32x4 &dst) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off_c)::value) : "memory");
+    };
+    auto lds_pair = [&](unsigned slot_addr, auto ms_c, u32x4 (&dst)[2]) {
+        constexpr int ms = decltype(ms_c)::value;
+        lds_frag(slot_addr, std::integral_constant<int, ms * NP * 1024>{}, dst[0]);
+        if (NP == 2) lds_frag(slot_addr, std::integral_constant<int, (ms * NP + 1) * 1024>{}, dst[1]);
+        else dst[1] = dst[0];
+    };
+    unsigned cur_addr = 0, nxt_addr = 0;
+    auto step_begin = [&](bool stores_younger) {
+        sync(stores_younger);
+        cur_addr = lds0 + (unsigned)((gstep - 1) % NSLOT) * STEP;
+        nxt_addr = lds0 + (unsigned)(gstep % NSLOT) * STEP;
+    };
+    // chunk c of a step uses pairs 2c, 2c+1 (set c & 1), requested one chunk earlier; it requests the pairs of the next chunk
+    auto chunk_begin = [&](auto c_c, bool has_next) {
+        constexpr int c = decltype(c_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (c < 3) { lds_pair(cur_addr, std::integral_constant<int, 2 * c + 2>{}, wb[(c + 1) & 1][0]); lds_pair(cur_addr, std::integral_constant<int, 2 * c + 3>{}, wb[(c + 1) & 1][1]); }
+        else if (has_next) { lds_pair(nxt_addr, std::integral_constant<int, 0>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, 1>{}, wb[0][1]); }
+    };
+    auto pin6 = [&]() {
+#pragma unroll
+        for (int n = 0; n < (NP == 2 ? 6 : 2); n++) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // register octet m (registers 8m .. 8m+7) of a tile -> one 16-byte k-slot group per plane
+    auto pack_octet = [&](const f32x16 &v, int m, u32x4 (&dst)[2]) {
+#pragma unroll
+        for (int wd = 0; wd < 4; wd++) {
+            unsigned a, b2;
+            split2p<T, NP>(v[8 * m + 2 * wd], v[8 * m + 2 * wd + 1], a, b2);
+            dst[0][wd] = a; dst[1][wd] = b2;
+        }
+    };
+    auto lds_write = [&](unsigned addr, const u32x4 &v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // a query's 32 scores of a key tile sit in lanes r and r + 32: exchange by v_permlane32_swap (VALU; a ds_bpermute
+    // would join the fragment reads in lgkmcnt)
+    // (inline asm: the builtin's second result comes back as a copy of the first with this hipcc -- measured, tools/ history;
+    //  s_nop 1 = the two wait states between a VALU write and v_permlane*_swap reading it)
+    auto half_swap = [&](float v, float &lower, float &upper) {
+        lower = v; upper = v;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lower), "+v"(upper));
+        // lower = value of lane r (lanes >= 32 received it), upper = value of lane r + 32 (lanes < 32 received it)
+    };
+    auto other_half_max = [&](float v) { float a, b2; half_swap(v, a, b2); return fmaxf(a, b2); };
+    auto other_half_sum = [&](float v) { float a, b2; half_swap(v, a, b2); return a + b2; };
+    const float sc2 = scale_log2e * inv_scale * inv_scale; // softmax exponent scale for q.k in weight-scaled units
+    const unsigned kw_addr = sK + (unsigned)(tok0 + r) * KROW + h * 16;                   // this lane's key row (write side)
+    const unsigned vw_addr = sV + (unsigned)r * VROW + (unsigned)wave * 64 + h * 16;      // this lane's d row, this wave's keys
+    const unsigned kr_addr = sK + (unsigned)r * KROW + h * 16;                            // read side: key r of a tile
+    const unsigned vr_addr = sV + (unsigned)r * VROW + h * 16;                            // read side: d = r
+
+    // the first pairs of the very first step
+    step_begin(false);
+    lds_pair(cur_addr, I0{}, wb[0][0]);
+    lds_pair(cur_addr, I1{}, wb[0][1]);
+
+#pragma unroll 1
+    for (int hd = 0; hd < NH; hd++) {
+        // ---- steps 0-3: q and k tiles (swapped: lane = token, registers = d) ----
+        f32x16 qa, ka;
+#pragma unroll
+        for (int g = 0; g < 16; g++) { qa[g] = 0.f; ka[g] = 0.f; }
+        // y stores of the previous head's attention are younger than the pieces that steps 0-2 wait for (see sync)
+        const bool st_young = hd > 0 && full;
+        auto step_qk = [&](auto j_c) {
+            constexpr int j = decltype(j_c)::value;
+            if (j > 0 || hd > 0) step_begin(j < 3 && st_young);
+            auto chunk = [&](auto c_c) {
+                constexpr int c = decltype(c_c)::value;
+                chunk_begin(c_c, true);
+                constexpr int ks = 4 * j + c;
+                if (NP == 2) {
+                    qa = T::mfma(wb[c & 1][0][1], xn[ks][0], qa); ka = T::mfma(wb[c & 1][1][1], xn[ks][0], ka);
+                    qa = T::mfma(wb[c & 1][0][0], xn[ks][1], qa); ka = T::mfma(wb[c & 1][1][0], xn[ks][1], ka);
+                }
+                qa = T::mfma(wb[c & 1][0][0], xn[ks][0], qa); ka = T::mfma(wb[c & 1][1][0], xn[ks][0], ka);
+                pin6();
+            };
+            chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
+        };
+        step_qk(I0{});
+        step_qk(I1{});
+        step_qk(I2{});
+        step_qk(I3{});
+        u32x4 qf[2][2];                                    // B operand of S^T = K Q^T: [k-step][plane]
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) pack_octet(qa, ks, qf[ks]);
+        {   // k -> sK[pl][key = tok0 + r][octet ks][half h]   (all waves passed this head's step syncs: the previous head's
+            // attention is over everywhere)
+            u32x4 kp[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) pack_octet(ka, ks, kp[ks]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) lds_write(kw_addr + (unsigned)(pl * kT * KROW + ks * 32), kp[ks][pl]);
+        }
+        // ---- steps 4-5: v tile (natural: lane = d, registers = tokens), two chains ----
+        f32x16 va, vb;
+#pragma unroll
+        for (int g = 0; g < 16; g++) { va[g] = 0.f; vb[g] = 0.f; }
+        auto step_v = [&](auto j_c, bool has_next) {
+            constexpr int j = decltype(j_c)::value;
+            step_begin(false);
+            auto chunk = [&](auto c_c) {
+                constexpr int c = decltype(c_c)::value;
+                chunk_begin(c_c, has_next);
+                constexpr int ks = 8 * j + 2 * c;
+                if (NP == 2) {
+                    va = T::mfma(xn[ks][1], wb[c & 1][0][0], va); vb = T::mfma(xn[ks + 1][1], wb[c & 1][1][0], vb);
+                    va = T::mfma(xn[ks][0], wb[c & 1][0][1], va); vb = T::mfma(xn[ks + 1][0], wb[c & 1][1][1], vb);
+                }
+                va = T::mfma(xn[ks][0], wb[c & 1][0][0], va); vb = T::mfma(xn[ks + 1][0], wb[c & 1][1][0], vb);
+                pin6();
+            };
+            chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
+        };
+        step_v(I0{}, true);
+        step_v(I1{}, hd + 1 < NH);
+        {   // v^T -> sV[pl][d = r][(wave, octet mm)][half h]
+#pragma unroll
+            for (int g = 0; g < 16; g++) va[g] += vb[g];
+            u32x4 vp[2][2];
+#pragma unroll
+            for (int mm = 0; mm < 2; mm++) pack_octet(va, mm, vp[mm]);
+#pragma unroll
+            for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) lds_write(vw_addr + (unsigned)(pl * HS * VROW + mm * 32), vp[mm][pl]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // k, v^T of the head complete
+
+        // ---- attention of this wave's 32 queries against the 256 keys of the head ----
+        f32x16 o;
+#pragma unroll
+        for (int g = 0; g < 16; g++) o[g] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        if (full) {
+            u32x4 kf[2][2], vf[2][2];
+            auto load_k = [&](int kt) {                    // K fragments of key tile kt: [k-step][plane]
+                const unsigned a = kr_addr + (unsigned)kt * (32 * KROW);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][0]) : "v"(a) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(kf[1][0]) : "v"(a) : "memory");
+                if (NP == 2) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][1]) : "v"(a), "n"(kT * KROW) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][1]) : "v"(a), "n"(kT * KROW + 32) : "memory");
+                } else { kf[0][1] = kf[0][0]; kf[1][1] = kf[1][0]; }
+            };
+            load_k(0);
+#pragma unroll 1
+            for (int kt = 0; kt < kT / 32; kt++) {
+                f32x16 sc;
+#pragma unroll
+                for (int g = 0; g < 16; g++) sc[g] = 0.f;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) sc = mma<T, NP>(kf[ks], qf[ks], sc);
+                __builtin_amdgcn_sched_barrier(0);
+                // V^T fragments of this tile, then K of the next one (both land during the softmax arithmetic)
+                {
+                    const unsigned a = vr_addr + (unsigned)kt * 64;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(vf[0][0]) : "v"(a) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(vf[1][0]) : "v"(a) : "memory");
+                    if (NP == 2) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[0][1]) : "v"(a), "n"(HS * VROW) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[1][1]) : "v"(a), "n"(HS * VROW + 32) : "memory");
+                    } else { vf[0][1] = vf[0][0]; vf[1][1] = vf[1][0]; }
+                }
+                if (kt + 1 < kT / 32) load_k(kt + 1);
+                // sc[g] = S[query r][key 32 kt + tau(g, h)]  (times 1/inv_scale^2)
+                float mx = sc[0];
+#pragma unroll
+                for (int g = 1; g < 16; g++) mx = fmaxf(mx, sc[g]);
+                mx = other_half_max(mx);
+                if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {        // some query's running max moved: rescale (wave-uniform branch)
+                    const float m_new = fmaxf(m_run, mx);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int g = 0; g < 16; g++) o[g] *= alpha;
+                    m_run = m_new;
+                }
+                const float nm = -m_run * sc2;
+                float psum = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    sc[g] = __builtin_amdgcn_exp2f(fmaf(sc[g], sc2, nm));
+                    psum += sc[g];
+                }
+                l_run += other_half_sum(psum);
+                u32x4 pf[2][2];
+#pragma unroll
+                for (int mm = 0; mm < 2; mm++) pack_octet(sc, mm, pf[mm]);
+                if (kt + 1 < kT / 32) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NP) : "memory");   // v^T fragments landed, K of the next tile may fly
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mm = 0; mm < 2; mm++) o = mma<T, NP>(vf[mm], pf[mm], o);
+            }
+        }
+        // ---- y planes of the head: o[g] = O[query r][d = tau(g, h)] / l, times the v projection's weight scale ----
+        if (full) {
+            const float inv = inv_scale / l_run;
+            const int64_t m = LAST ? b : b * kT + tok0 + r;                // row of the y matrix
+            if (!LAST || r == 31) {
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    unsigned h0, l0, h1, l1;
+                    split2p<T, NP>(o[4 * gq] * inv, o[4 * gq + 1] * inv, h0, l0);
+                    split2p<T, NP>(o[4 * gq + 2] * inv, o[4 * gq + 3] * inv, h1, l1);
+                    const u32x2 hi = {h0, h1}, lo = {l0, l1};
+                    const int n = hd * HS + 8 * gq + 4 * h;
+                    *reinterpret_cast<u32x2 *>(y + pk_off(m, n, 0, C >> 4, NP)) = hi;
+                    if (NP == 2) *reinterpret_cast<u32x2 *>(y + pk_off(m, n, 1, C >> 4, NP)) = lo;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace fastk
 }  // namespace mgpt

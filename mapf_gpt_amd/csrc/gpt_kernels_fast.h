@@ -187,6 +187,20 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
     if (lane == 0) stats[tok] = make_float2(mean, rsqrtf(q / (float)C + 1e-5f));
 }
 
+// last-layer shortcut of the packed-GEMM path: compact residual rows x_last[b] = x[b, 255, :] for b < rows, zeros for the
+// padding rows up to rows_pad (they go through the compact GEMMs and the MLP and must stay finite whatever ran before)
+__global__ __launch_bounds__(256) void gather_last_kernel(const float *__restrict__ x, float *__restrict__ x_last, int rows,
+                                                          int rows_pad, int C)
+{
+    const int c4n = C >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows_pad * c4n) return;
+    const int b = (int)(i / c4n), c4 = (int)(i - (int64_t)b * c4n);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (b < rows) v = reinterpret_cast<const f32x4 *>(x + ((int64_t)b * kT + kT - 1) * C)[c4];
+    reinterpret_cast<f32x4 *>(x_last + (int64_t)b * C)[c4] = v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // GEMM: D[M,N] = A[M,K] @ W[N,K]^T on 16-bit MFMA planes, 128 x BN output tile per workgroup,
 // K walked in tiles of 32 staged through LDS (register prefetch of the next tile during the MFMAs).
@@ -755,8 +769,10 @@ __global__ __launch_bounds__(NW * 64) void attn16_kernel(const uint16_t *__restr
                                                      const uint16_t *__restrict__ k_hi, const uint16_t *__restrict__ k_lo,
                                                      const uint16_t *__restrict__ vt_hi, const uint16_t *__restrict__ vt_lo,
                                                      uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo, int n_head,
-                                                     float scale_log2e, int y_pk, int chunk_major)
+                                                     float scale_log2e, int y_pk, int chunk_major, int last_only)
 {
+    // last_only (last layer, model.py:186 reads position 255 only): all keys and values, but only the query tile that holds
+    // token 255, and only that token's output row, written to row b of a compact [rows][C] matrix (y_pk layout)
     constexpr int KRS = (HS + 8) * 2;           // K row stride in bytes  (80 for HS = 32)
     constexpr int VRS = (kT + 8) * 2;           // V^T row stride in bytes (528)
     constexpr int KS = HS / 16;                 // k-steps of the S product
@@ -801,7 +817,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_kernel(const uint16_t *__restr
     // the S^T tile row this lane feeds as A-operand is key `kperm` of the tile (bits 2 and 3 of r swapped)
     const int kperm = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);
 
-    for (int qt = wave; qt < kT / 32; qt += NW) {
+    for (int qt = last_only ? kT / 32 - 1 + (wave == 0 ? 0 : kT) : wave; qt < kT / 32; qt += NW) {
         u32x4 qf[KS][2];                                         // B operand: Q[query r][16 ks + 8 h ..]
 #pragma unroll
         for (int ks = 0; ks < KS; ks++)
@@ -880,8 +896,9 @@ __global__ __launch_bounds__(NW * 64) void attn16_kernel(const uint16_t *__restr
                 const float v[4] = {o[dt][4 * gq] * inv, o[dt][4 * gq + 1] * inv, o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv};
                 u32x2 hi, lo;
                 split4<T, NP>(v, hi, lo);
+                if (last_only && r != 31) continue;
                 if (y_pk) {                                 // y feeds gemm_pk_kernel: PK layout, y_hi = base
-                    const int64_t m = (int64_t)b * kT + qt * 32 + r;
+                    const int64_t m = last_only ? (int64_t)b : (int64_t)b * kT + qt * 32 + r;
                     const int n = head * HS + dt * 32 + 8 * gq + 4 * h;
                     *reinterpret_cast<u32x2 *>(y_hi + pk_off(m, n, 0, C >> 4, NP)) = hi;
                     if (NP == 2) *reinterpret_cast<u32x2 *>(y_hi + pk_off(m, n, 1, C >> 4, NP)) = lo;
