@@ -91,7 +91,7 @@ float pick_scale(const float *h_w, size_t n, bool f16)
 template <int NP>
 constexpr int kA256Lds = 5 * 8 * NP * 1024 + NP * (256 * 80 + 32 * 528);    // attn256_kernel: 5-slot weight ring + K and V^T planes of a head
 template <int NP>
-constexpr int kM256Lds = 6 * 8 * NP * 1024 + fastk::kGeluLutN * 8;      // mlp256_kernel: 6-slot weight ring + GELU table
+constexpr int kM256Lds = 8 * 8 * NP * 1024 + fastk::kGeluLutN * 8;      // mlp256_kernel: 8-slot weight ring + GELU table
 
 template <class T, int NP>
 int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
@@ -131,7 +131,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                1.0f / m->proj2[l].inv_scale);
             MGPT_LAUNCH_CHECK();
         }
-        {   // Phi(v) = (1 + erf(v / sqrt 2)) / 2 on [-6, 6) in steps of 1/512, as (value, forward difference) pairs
+        {   // Phi(v) = (1 + erf(v / sqrt 2)) / 2 on [-6, 6) in steps of 1/256, as (value, forward difference) pairs
             std::vector<float2> lut(fastk::kGeluLutN);
             auto phi = [](double v) { return 0.5 * (1.0 + erf(v * 0.70710678118654752440)); };
             for (int i = 0; i < fastk::kGeluLutN; i++) {

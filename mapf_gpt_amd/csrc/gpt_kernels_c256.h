@@ -74,12 +74,12 @@ __device__ __forceinline__ void split2p(float v0, float v1, unsigned &hi, unsign
 constexpr int kM256Steps = 2 + 4 * 32 + 2;     // c_fc(0) | 32 x 4 mixed steps | c_proj(31)
 
 // GELU by table: gelu(v) = v Phi(v), Phi = standard normal CDF = (1 + erf(v / sqrt 2)) / 2 (model.py:86, exact-erf GELU).
-// Phi is tabulated on [-6, 6) in steps of 1/512 as pairs (Phi(v_i), Phi(v_i+1) - Phi(v_i)) and interpolated linearly:
-// |error in Phi| <= h^2 / 8 max|Phi''| = 1.2e-7, i.e. <= 1.2e-7 |v| in gelu (the rational approximation used elsewhere has
-// 1.6e-6); beyond +-6 the end entries apply (Phi = 1e-9 / 1 - 1e-9).  8 VALU + one 8-byte LDS gather per value instead of
+// Phi is tabulated on [-6, 6) in steps of 1/256 as pairs (Phi(v_i), Phi(v_i+1) - Phi(v_i)) and interpolated linearly:
+// |error in Phi| <= h^2 / 8 max|Phi''| = 4.6e-7, i.e. <= 4.6e-7 |v| in gelu (the rational approximation used elsewhere has
+// 1.6e-6); beyond +-6 the end entries apply (Phi = 1e-9 / 1 - 1e-9).  24 KiB: the LDS goes to a deeper weight ring.  8 VALU + one 8-byte LDS gather per value instead of
 // 19 VALU: on this kernel the VALU port, which the MFMAs share, is the scarce resource (section 3 of DESIGN.md).
-constexpr int kGeluLutN = 6144;                // entries (float2 each: 48 KiB of LDS)
-constexpr float kGeluLutScale = 512.0f, kGeluLutBias = 3072.0f;
+constexpr int kGeluLutN = 3072;                // entries (float2 each: 24 KiB of LDS)
+constexpr float kGeluLutScale = 256.0f, kGeluLutBias = 1536.0f;
 
 template <class T, int NP>
 __global__ __launch_bounds__(256) void pack_mlp256_kernel(const float *__restrict__ fc_w, const float *__restrict__ pj_w,
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
     constexpr int C = 256, CT = 8, KS = 16, NT = 32;
     constexpr int MS = 8;                                  // fragment pairs per step
     constexpr int STEP = MS * NP * 1024;                   // bytes per step
-    constexpr int NSLOT = 6;
-    constexpr int LUT_BYTES = kGeluLutN * 8;
+    constexpr int NSLOT = 8;
+    constexpr int LUT_BYTES = kGeluLutN * 8;            // 24 KiB
     constexpr int PW = MS * NP / 4;                        // direct-to-LDS loads per wave per step
     constexpr int NSTEP = kM256Steps;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NSLOT][STEP] ring, then the GELU table
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
                 for (int e = 0; e < 4; e++) {
                     const float hv = hsrc[4 * q + e];
                     gvv[e] = hv * inv1;
-                    const float t = __builtin_amdgcn_fmed3f(fmaf(hv, lut_scale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.01f);
+                    const float t = __builtin_amdgcn_fmed3f(fmaf(hv, lut_scale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.002f);
                     gfr[e] = __builtin_amdgcn_fractf(t);
                     const unsigned idx = (unsigned)t;
                     if (ABL & 2) gtab[e] = (f32x2){1.f, 0.f};
@@ -396,6 +396,11 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
             *dst = cur;
         }
 }
+
+// (A two-waves-per-SIMD variant -- every 32-token tile shared by a pair of 256-register waves, c_fc split over K and c_proj
+//  over N, partial sums and hidden planes handed over through LDS on the ring barrier -- was built in round 2 and measured at
+//  2.82 ms per 4096-row launch against 2.57 ms for this kernel: the second wave per SIMD does not pay for the hand-offs and
+//  the 6 % of dummy steps its uniform pipeline needs.  Both sit at ~62 % of the MFMA rate this chip sustains (2.07 PFLOP/s).)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Fused attention front half for C = 256, head size 32:  y = attention(LayerNorm(x))   (model.py:46-68, 102), one row

@@ -41,7 +41,7 @@ int main()
         lut[i] = make_float2(f0, (float)(0.5 * (1.0 + erf(v1 * 0.70710678118654752440)) - (double)f0));
     }
     float2 *dl; hipMalloc(&dl, lut.size() * 8); hipMemcpy(dl, lut.data(), lut.size() * 8, hipMemcpyHostToDevice);
-    const int lds2 = 6 * 8 * 2 * 1024 + kGeluLutN * 8;
+    const int lds2 = 8 * 8 * 2 * 1024 + kGeluLutN * 8;
     hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256_kernel<F16T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
     mlp256_kernel<F16T, 2><<<M / 128, 256, lds2>>>(x2, g, pk2, 1.f / sc, 1.f / sc, dl);
     hipDeviceSynchronize();

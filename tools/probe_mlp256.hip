@@ -11,7 +11,7 @@ using namespace mgpt::fastk;
 template <int ABL>
 void run(const char *tag, float *x, const float *gain, const uint16_t *ws, int M, int grid = 0)
 {
-    const size_t lds = 6 * 8 * 2 * 1024 + kGeluLutN * 8;
+    const size_t lds = 8 * 8 * 2 * 1024 + kGeluLutN * 8;
     static float2 *lut = nullptr;
     if (!lut) { hipMalloc(&lut, kGeluLutN * 8); hipMemset(lut, 0, kGeluLutN * 8); }
     if (grid == 0) grid = M / 128;
