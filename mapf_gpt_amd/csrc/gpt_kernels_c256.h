@@ -397,6 +397,9 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
         }
 }
 
+// (Fusing the attention out-projection in front of this kernel -- 16 more stream steps on the y operand planes, new residual
+//  rows stored for the final add -- was built and measured in round 2: 84.3 ms per step for the fused kernel against
+//  67.6 + 13.8 ms for this kernel plus the packed-GEMM out-projection; kept separate.)
 // (A two-waves-per-SIMD variant -- every 32-token tile shared by a pair of 256-register waves, c_fc split over K and c_proj
 //  over N, partial sums and hidden planes handed over through LDS on the ring barrier -- was built in round 2 and measured at
 //  2.82 ms per 4096-row launch against 2.57 ms for this kernel: the second wave per SIMD does not pay for the hand-offs and
