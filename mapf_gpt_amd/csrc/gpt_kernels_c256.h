@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
         __builtin_amdgcn_sched_barrier(0);
         if (c < 3) { lds_pair(cur_addr, std::integral_constant<int, (c + 1) % 4>{}, wb[(c + 1) & 1][0]); lds_pair(cur_addr, std::integral_constant<int, 4 + (c + 1) % 4>{}, wb[(c + 1) & 1][1]); }
         else if (has_next) { lds_pair(nxt_addr, std::integral_constant<int, 0>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, 4>{}, wb[0][1]); }
-    };
+        __builtin_amdgcn_sched_barrier(0);                 // the requests stay in front of this chunk's MFMAs (else hipcc sinks them
+    };                                                     // behind the MFMAs, reuses the registers and the next wait eats the LDS latency)
     // one split product step on two independent accumulators, passes interleaved (no back-to-back dependent MFMAs)
     auto mma2 = [&](const u32x4 (&wa)[2], const u32x4 (&ba)[2], f32x16 &ca, const u32x4 (&wb)[2], const u32x4 (&bb)[2], f32x16 &cb) {
         if (ABL & 8) { asm volatile("" :: "a"(wa[0]), "a"(wa[1]), "a"(wb[0]), "a"(wb[1]), "v"(ba[0]), "v"(bb[0]), "v"(ba[1]), "v"(bb[1])); return; }
@@ -458,7 +459,9 @@ __global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restri
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
 }
 
-template <class T, int NP, bool LAST>
+// ABL (tools/probe_attn256.hip only; the library instantiates ABL = 0): 1 no weight DMA in the loop, 2 no softmax arithmetic,
+// 4 no attention phase, 8 no projection MFMAs, 16 no ring barriers -- results are wrong unless ABL == 0.
+template <class T, int NP, bool LAST, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict__ x, const float *__restrict__ gain,
                                                          const uint16_t *__restrict__ wstream, float inv_scale, float scale_log2e,
                                                          uint16_t *__restrict__ y)
@@ -544,8 +547,8 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
     auto sync = [&](bool stores_younger) {                 // (wave-uniform flag)
         if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3) + NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        if (gstep + NSLOT - 1 < NSTEP) issue(gstep + NSLOT - 1);
+        if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+        if (!(ABL & 1) && gstep + NSLOT - 1 < NSTEP) issue(gstep + NSLOT - 1);
         gstep++;
     };
     // (all asm destinations are arch VGPRs here: with no "a" constraint in the kernel hipcc gives the whole 256-register
@@ -574,6 +577,7 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
         __builtin_amdgcn_sched_barrier(0);
         if (c < 3) { lds_pair(cur_addr, std::integral_constant<int, 2 * c + 2>{}, wb[(c + 1) & 1][0]); lds_pair(cur_addr, std::integral_constant<int, 2 * c + 3>{}, wb[(c + 1) & 1][1]); }
         else if (has_next) { lds_pair(nxt_addr, std::integral_constant<int, 0>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, 1>{}, wb[0][1]); }
+        __builtin_amdgcn_sched_barrier(0);                 // the requests stay in front of this chunk's MFMAs
     };
     auto pin6 = [&]() {
 #pragma unroll
@@ -632,11 +636,12 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
                 constexpr int c = decltype(c_c)::value;
                 chunk_begin(c_c, true);
                 constexpr int ks = 4 * j + c;
-                if (NP == 2) {
+                if (ABL & 8) asm volatile("" :: "v"(wb[c & 1][0][0]), "v"(wb[c & 1][0][1]), "v"(wb[c & 1][1][0]), "v"(wb[c & 1][1][1]));
+                else if (NP == 2) {
                     qa = T::mfma(wb[c & 1][0][1], xn[ks][0], qa); ka = T::mfma(wb[c & 1][1][1], xn[ks][0], ka);
                     qa = T::mfma(wb[c & 1][0][0], xn[ks][1], qa); ka = T::mfma(wb[c & 1][1][0], xn[ks][1], ka);
                 }
-                qa = T::mfma(wb[c & 1][0][0], xn[ks][0], qa); ka = T::mfma(wb[c & 1][1][0], xn[ks][0], ka);
+                if (!(ABL & 8)) { qa = T::mfma(wb[c & 1][0][0], xn[ks][0], qa); ka = T::mfma(wb[c & 1][1][0], xn[ks][0], ka); }
                 pin6();
             };
             chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
@@ -669,11 +674,12 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
                 constexpr int c = decltype(c_c)::value;
                 chunk_begin(c_c, has_next);
                 constexpr int ks = 8 * j + 2 * c;
-                if (NP == 2) {
+                if (ABL & 8) asm volatile("" :: "v"(wb[c & 1][0][0]), "v"(wb[c & 1][0][1]), "v"(wb[c & 1][1][0]), "v"(wb[c & 1][1][1]));
+                else if (NP == 2) {
                     va = T::mfma(xn[ks][1], wb[c & 1][0][0], va); vb = T::mfma(xn[ks + 1][1], wb[c & 1][1][0], vb);
                     va = T::mfma(xn[ks][0], wb[c & 1][0][1], va); vb = T::mfma(xn[ks + 1][0], wb[c & 1][1][1], vb);
                 }
-                va = T::mfma(xn[ks][0], wb[c & 1][0][0], va); vb = T::mfma(xn[ks + 1][0], wb[c & 1][1][0], vb);
+                if (!(ABL & 8)) { va = T::mfma(xn[ks][0], wb[c & 1][0][0], va); vb = T::mfma(xn[ks + 1][0], wb[c & 1][1][0], vb); }
                 pin6();
             };
             chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
@@ -699,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
 #pragma unroll
         for (int g = 0; g < 16; g++) o[g] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
-        if (full) {
+        if (full && !(ABL & 4)) {
             u32x4 kf[2][2], vf[2][2];
             auto load_k = [&](int kt) {                    // K fragments of key tile kt: [k-step][plane]
                 const unsigned a = kr_addr + (unsigned)kt * (32 * KROW);
@@ -734,10 +740,12 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
                 if (kt + 1 < kT / 32) load_k(kt + 1);
                 // sc[g] = S[query r][key 32 kt + tau(g, h)]  (times 1/inv_scale^2)
                 float mx = sc[0];
+                if (!(ABL & 2)) {
 #pragma unroll
                 for (int g = 1; g < 16; g++) mx = fmaxf(mx, sc[g]);
                 mx = other_half_max(mx);
-                if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {        // some query's running max moved: rescale (wave-uniform branch)
+                }
+                if (!(ABL & 2) && __builtin_amdgcn_ballot_w64(mx > m_run) != 0) {        // some query's running max moved: rescale (wave-uniform branch)
                     const float m_new = fmaxf(m_run, mx);
                     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
                     l_run *= alpha;
@@ -747,12 +755,14 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
                 }
                 const float nm = -m_run * sc2;
                 float psum = 0.f;
+                if (!(ABL & 2)) {
 #pragma unroll
                 for (int g = 0; g < 16; g++) {
                     sc[g] = __builtin_amdgcn_exp2f(fmaf(sc[g], sc2, nm));
                     psum += sc[g];
                 }
                 l_run += other_half_sum(psum);
+                } else l_run = 1.f;
                 u32x4 pf[2][2];
 #pragma unroll
                 for (int mm = 0; mm < 2; mm++) pack_octet(sc, mm, pf[mm]);

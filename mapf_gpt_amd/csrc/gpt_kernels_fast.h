@@ -967,12 +967,9 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
 }
 
 
-// ABL: timing ablations for tools/ (results are WRONG unless ABL == 0): 1 no GELU, 2 no weight streaming,
-//      3 no c_proj MFMAs, 4 no c_fc MFMAs
-// C = 256 (6M) instantiates NW = 4, NBUF = 2, MINW = 1, NCH = 4: the row block needs ~330 registers, i.e. one wave per SIMD;
-// with no partner wave to fill the matrix pipe, NCH = 4 independent accumulator chains (instead of 2) keep dependent MFMAs apart.
-template <class T, int NP, int CT, int ABL = 0, int NW = 8, int NBUF = 3, int MINW = 2, int NCH = 2>
-__global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restrict__ x, const float *__restrict__ gain,
+// (C = 64, 160: the 2M and tiny shapes; C = 256 has its own pipelined kernel in gpt_kernels_c256.h)
+template <class T, int NP, int CT, int NW = 8, int NBUF = 3, int NCH = 2>
+__global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                             const uint16_t *__restrict__ wpk, float inv1, float inv2,
                                                             float2 *__restrict__ stats_out, int M)
 {
@@ -987,16 +984,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
     float *xrow = x + m * C;
 
     // ---- stream helper: packet t -> LDS buffer (t & 1); every wave moves FRAGS*NP/4 fragment-planes of 1 KiB ----
-    auto issue_part = [&](int t, int i0, int i1) {         // pieces i0 .. i1-1 of this wave's share of packet t
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)t * PKT;
-        unsigned char *dst = smem + (size_t)(t % NBUF) * PKT;
-#pragma unroll
-        for (int i = i0; i < i1; i++) {
-            const int c = min(wave + NW * i, FRAGS * NP - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)c * 1024 + lane * 16),
-                                             (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
-        }
-    };
     auto issue = [&](int t) {
         const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)t * PKT;
         unsigned char *dst = smem + (size_t)(t % NBUF) * PKT;
@@ -1063,13 +1050,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
 #pragma unroll 1
     for (int t = 0; t < NT; t++) {
         // refill the buffer that was read during tile t-1 (all waves are past the barrier that ended it)
-        // (one wave per SIMD: the refill is spread over the c_fc MFMA rounds below.  s_memtime stamps showed the 16 back-to-back
-        //  1 KiB loads holding the wave at the issue stage for ~1500 of ~7600 cycles per tile; spreading them moved the stall
-        //  into the rounds without shortening the tile -- an in-order wave with no partner on its SIMD serialises matrix issue,
-        //  GELU, LDS waits and this refill, which is the real cost of the one-wave-per-SIMD shape)
-        if (MINW != 1 && ABL != 2 && t + NBUF - 1 < NT) issue(t + NBUF - 1);
-        const bool refill = MINW == 1 && ABL != 2 && t + NBUF - 1 < NT;
-        const unsigned char *pk = smem + (size_t)(ABL == 2 ? 0 : (t % NBUF)) * PKT + lane * 16;
+        if (t + NBUF - 1 < NT) issue(t + NBUF - 1);
+        const unsigned char *pk = smem + (size_t)(t % NBUF) * PKT + lane * 16;
         // ---- hidden tile: c_fc output for (token r, hidden 32 t + (g&3) + 8 (g>>2) + 4 h) ----
         // Two partial accumulators (even / odd k-steps) with their MFMA passes interleaved: a 32x32x16 MFMA
         // that reads the previous one's result as C waits for its full latency (~2x the issue interval), so a
@@ -1079,53 +1061,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
         for (int c = 0; c < NCH; c++)
 #pragma unroll
             for (int g = 0; g < 16; g++) hch[c][g] = 0.f;
-        if constexpr (MINW == 1) {
-            // One wave per SIMD: nothing else fills the matrix pipe, so the order is pinned by hand -- fragments are
-            // requested two groups of k-steps ahead of the MFMAs that use them, each round visits the NCH chains in turn
-            // (left to itself the scheduler serialises each chain), and the packet refill rides between the rounds.
-            constexpr int NGF = KS / NCH;
-            constexpr int PPG = (PER_WAVE + 2 * NGF - 1) / (2 * NGF);              // refill pieces per slot (2 slots per group)
-            u32x4 wq[3][NCH][2];
-            auto ld = [&](int g_, int buf) {
-#pragma unroll
-                for (int c = 0; c < NCH; c++)
-#pragma unroll
-                    for (int pl = 0; pl < NP; pl++)
-                        wq[buf][c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((g_ * NCH + c) * NP + pl) * 1024);
-            };
-            ld(0, 0);
-            if (NGF > 1) ld(1, 1);
-#pragma unroll
-            for (int g_ = 0; g_ < NGF; g_++) {
-                const int cur = g_ % 3, ks = g_ * NCH;
-                if (g_ + 2 < NGF) ld(g_ + 2, (g_ + 2) % 3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ABL != 4) {
-                    if (NP == 2) {
-#pragma unroll
-                        for (int c = 0; c < NCH; c++) hch[c] = T::mfma(wq[cur][c][1], xn[ks + c][0], hch[c]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (refill) issue_part(t + NBUF - 1, min((2 * g_) * PPG, PER_WAVE), min((2 * g_ + 1) * PPG, PER_WAVE));
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int c = 0; c < NCH; c++) hch[c] = T::mfma(wq[cur][c][0], xn[ks + c][1], hch[c]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (refill) issue_part(t + NBUF - 1, min((2 * g_ + 1) * PPG, PER_WAVE), min((2 * g_ + 2) * PPG, PER_WAVE));
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if (refill) {
-                        issue_part(t + NBUF - 1, min((2 * g_) * PPG, PER_WAVE), min((2 * g_ + 2) * PPG, PER_WAVE));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) hch[c] = T::mfma(wq[cur][c][0], xn[ks + c][0], hch[c]);
-                } else {
-                    if (refill) issue_part(t + NBUF - 1, min((2 * g_) * PPG, PER_WAVE), min((2 * g_ + 2) * PPG, PER_WAVE));
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) asm volatile("" :: "v"(wq[cur][c][0]), "v"(wq[cur][c][NP - 1]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
+        {
 #pragma unroll
             for (int ks = 0; ks < KS; ks += NCH) {
                 u32x4 w[NCH][2];
@@ -1134,19 +1070,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
 #pragma unroll
                     for (int pl = 0; pl < NP; pl++)
                         w[c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + c) * NP + pl) * 1024);
-                if (ABL != 4) {
-                    if (NP == 2) {
+                if (NP == 2) {
 #pragma unroll
-                        for (int c = 0; c < NCH; c++) hch[c] = T::mfma(w[c][1], xn[ks + c][0], hch[c]);
+                    for (int c = 0; c < NCH; c++) hch[c] = T::mfma(w[c][1], xn[ks + c][0], hch[c]);
 #pragma unroll
-                        for (int c = 0; c < NCH; c++) hch[c] = T::mfma(w[c][0], xn[ks + c][1], hch[c]);
-                    }
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) hch[c] = T::mfma(w[c][0], xn[ks + c][0], hch[c]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) asm volatile("" :: "v"(w[c][0]), "v"(w[c][NP - 1]));
+                    for (int c = 0; c < NCH; c++) hch[c] = T::mfma(w[c][0], xn[ks + c][1], hch[c]);
                 }
+#pragma unroll
+                for (int c = 0; c < NCH; c++) hch[c] = T::mfma(w[c][0], xn[ks + c][0], hch[c]);
             }
             // fragment reads run one group of k-steps ahead of the MFMAs that consume them
             __builtin_amdgcn_sched_group_barrier(0x100, NCH * NP, 0);
@@ -1168,8 +1099,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
             float v0[4], v1[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                v0[e] = (ABL == 1) ? hacc[8 * kk + e] * inv1 : gelu_folded(hacc[8 * kk + e] * inv1);
-                v1[e] = (ABL == 1) ? hacc[8 * kk + 4 + e] * inv1 : gelu_folded(hacc[8 * kk + 4 + e] * inv1);
+                v0[e] = gelu_folded(hacc[8 * kk + e] * inv1);
+                v1[e] = gelu_folded(hacc[8 * kk + 4 + e] * inv1);
             }
             u32x2 h0, l0, h1, l1;
             split4<T, NP>(v0, h0, l0);
@@ -1180,42 +1111,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
         // ---- c_proj: for each kk the CT output tiles are independent accumulators; interleave them pairwise ----
         constexpr int NG = 2 * CT;                         // (kk, j) groups, visited kk-major so neighbours differ in j
         static_assert(NG % NCH == 0 && KS % NCH == 0, "chain count must divide the k-steps and the output groups");
-        if constexpr (MINW == 1) {
-            constexpr int NGP = NG / NCH;
-            u32x4 wq[3][NCH][2];
-            auto ld = [&](int g_, int buf) {
-#pragma unroll
-                for (int c = 0; c < NCH; c++)
-#pragma unroll
-                    for (int pl = 0; pl < NP; pl++)
-                        wq[buf][c][pl] = *reinterpret_cast<const u32x4 *>(
-                            pk + (size_t)((KS + 2 * ((g_ * NCH + c) % CT) + (g_ * NCH + c) / CT) * NP + pl) * 1024);
-            };
-            ld(0, 0);
-            if (NGP > 1) ld(1, 1);
-#pragma unroll
-            for (int g_ = 0; g_ < NGP; g_++) {
-                const int cur = g_ % 3, gi = g_ * NCH;
-                if (g_ + 2 < NGP) ld(g_ + 2, (g_ + 2) % 3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ABL != 3) {
-                    if (NP == 2) {
-#pragma unroll
-                        for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(wq[cur][c][1], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(wq[cur][c][0], hf[(gi + c) / CT][1], acc[(gi + c) % CT]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(wq[cur][c][0], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) asm volatile("" :: "v"(wq[cur][c][0]), "v"(wq[cur][c][NP - 1]), "v"(hf[(gi + c) / CT][0]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
+        {
 #pragma unroll
             for (int gi = 0; gi < NG; gi += NCH) {
                 u32x4 w[NCH][2];
@@ -1224,19 +1120,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
 #pragma unroll
                     for (int pl = 0; pl < NP; pl++)
                         w[c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((KS + 2 * ((gi + c) % CT) + (gi + c) / CT) * NP + pl) * 1024);
-                if (ABL != 3) {
-                    if (NP == 2) {
+                if (NP == 2) {
 #pragma unroll
-                        for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(w[c][1], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
+                    for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(w[c][1], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
 #pragma unroll
-                        for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(w[c][0], hf[(gi + c) / CT][1], acc[(gi + c) % CT]);
-                    }
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(w[c][0], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) asm volatile("" :: "v"(w[c][0]), "v"(w[c][NP - 1]), "v"(hf[(gi + c) / CT][0]));
+                    for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(w[c][0], hf[(gi + c) / CT][1], acc[(gi + c) % CT]);
                 }
+#pragma unroll
+                for (int c = 0; c < NCH; c++) acc[(gi + c) % CT] = T::mfma(w[c][0], hf[(gi + c) / CT][0], acc[(gi + c) % CT]);
             }
             __builtin_amdgcn_sched_group_barrier(0x100, NCH * NP, 1);
 #pragma unroll
@@ -1282,235 +1173,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void mlp_fused_kernel(float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused MLP block for wide rows (C = 256, the 6M shape): mlp_fused_kernel's dataflow with every 32-token tile shared by
-// a PAIR of waves, so that each wave fits 256 registers and two waves live on every SIMD (the one-wave-per-SIMD
-// instance of mlp_fused_kernel serialises matrix issue, GELU, LDS waits and the weight refill: ~7600 cycles per hidden
-// tile against 3072 cycles of MFMA work, measured with s_memtime).
-//   wave `half` of a pair holds x[:, 128 half .. +128] as operand planes (64 registers) and the output accumulators
-//   for columns 128 half .. +128 (64 registers);
-//   c_fc:   partial pre-activations over its half of K (8 k-steps); the halves are exchanged through LDS so that each
-//           wave owns the full sum for 16 of the tile's 32 hidden units (register octet `half`, i.e. k-step `half` of
-//           the c_proj slice), applies GELU and splits them;
-//   c_proj: the two octets of split hidden values are exchanged, each wave accumulates its 4 output tiles.
-// Three workgroup barriers per hidden tile (partial sums visible / hidden planes visible / ring hand-over).
-// Weight packets, ring and packing are mlp_fused_kernel's (pack_mlp_kernel); NBUF = 2.
-// ---------------------------------------------------------------------------------------------
-template <class T, int NP, int CT>
-__global__ __launch_bounds__(512, 2) void mlp_pair_kernel(float *__restrict__ x, const float *__restrict__ gain,
-                                                          const uint16_t *__restrict__ wpk, float inv1, float inv2)
-{
-    static_assert(CT % 2 == 0, "the row is split in two halves of whole 32-column tiles");
-    constexpr int C = CT * 32, KS = C / 16, NT = 4 * CT, NW = 8, HT = CT / 2, HK = KS / 2;
-    constexpr int FRAGS = KS + 2 * CT;
-    constexpr int PKT = FRAGS * NP * 1024;
-    constexpr int PER_WAVE = (FRAGS * NP + NW - 1) / NW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][PKT] ring, then exchange areas
-    // exchange area R[8 waves][2 KiB]: wave w publishes its 8 fp32 partial sums per lane in R[w]; after reading R[mate] it
-    // reuses THAT region (which only it reads) for its hidden octet planes, which the mate then finds in its own R[mate's w]
-    unsigned char *xch = smem + 2 * PKT;
-    float *xstat = reinterpret_cast<float *>(xch + NW * 2048);             // [8 waves][32]: LayerNorm partials
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int half = wave & 1, mate = wave ^ 1;
-    const int64_t m = (int64_t)blockIdx.x * (NW / 2 * 32) + (wave >> 1) * 32 + r;
-    float *xrow = x + m * C + half * (C / 2);                              // this wave's half of the row
-
-    auto issue = [&](int t) {
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)t * PKT;
-        unsigned char *dst = smem + (size_t)(t & 1) * PKT;
-#pragma unroll
-        for (int i = 0; i < PER_WAVE; i++) {
-            const int c = min(wave + NW * i, FRAGS * NP - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)c * 1024 + lane * 16),
-                                             (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
-        }
-    };
-    issue(0);
-
-    // ---- half row -> registers, LayerNorm with the pair's partial sums exchanged through LDS ----
-    f32x16 acc[HT];                                        // x now, output accumulators later
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < HT; j++)
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
-            acc[j][4 * gq] = v[0]; acc[j][4 * gq + 1] = v[1]; acc[j][4 * gq + 2] = v[2]; acc[j][4 * gq + 3] = v[3];
-            s += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-    s += __shfl_xor(s, 32);
-    if (h == 0) xstat[wave * 32 + r] = s;
-    __syncthreads();
-    const float mean = (s + xstat[mate * 32 + r]) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < HT; j++)
-#pragma unroll
-        for (int g = 0; g < 16; g++) { const float d = acc[j][g] - mean; q += d * d; }
-    q += __shfl_xor(q, 32);
-    __syncthreads();                                       // everyone has read the sums
-    if (h == 0) xstat[wave * 32 + r] = q;
-    __syncthreads();
-    const float rstd = rsqrtf((q + xstat[mate * 32 + r]) / (float)C + 1e-5f);
-    u32x4 xn[HK][2];                                       // B operand of c_fc for k-steps HK*half .. +HK
-#pragma unroll
-    for (int ks = 0; ks < HK; ks++) {
-        const int j = ks >> 1, g0 = 8 * (ks & 1);
-        const float *gp = gain + half * (C / 2) + 32 * j + 8 * (g0 >> 2) + 4 * h;
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gp), gb = *reinterpret_cast<const f32x4 *>(gp + 8);
-        float v0[4], v1[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            v0[e] = (acc[j][g0 + e] - mean) * rstd * ga[e];
-            v1[e] = (acc[j][g0 + 4 + e] - mean) * rstd * gb[e];
-        }
-        u32x2 h0, l0, h1, l1;
-        split4<T, NP>(v0, h0, l0);
-        split4<T, NP>(v1, h1, l1);
-        xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
-        xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
-    }
-#pragma unroll
-    for (int j = 0; j < HT; j++)
-#pragma unroll
-        for (int g = 0; g < 16; g++) acc[j][g] = 0.f;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // packet 0 landed
-
-#pragma unroll 1
-    for (int t = 0; t < NT; t++) {
-        if (t + 1 < NT) issue(t + 1);                      // into the buffer read during tile t-1 (everyone is past its last barrier)
-        const unsigned char *pk = smem + (size_t)(t & 1) * PKT + lane * 16;
-        // ---- c_fc over this wave's half of K: two interleaved chains (even / odd k-steps) ----
-        f32x16 hch[2];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int g = 0; g < 16; g++) hch[c][g] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < HK; ks += 2) {
-            u32x4 w[2][2];
-#pragma unroll
-            for (int c = 0; c < 2; c++)
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++)
-                    w[c][pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((HK * half + ks + c) * NP + pl) * 1024);
-            if (NP == 2) {
-                hch[0] = T::mfma(w[0][1], xn[ks][0], hch[0]);
-                hch[1] = T::mfma(w[1][1], xn[ks + 1][0], hch[1]);
-                hch[0] = T::mfma(w[0][0], xn[ks][1], hch[0]);
-                hch[1] = T::mfma(w[1][0], xn[ks + 1][1], hch[1]);
-            }
-            hch[0] = T::mfma(w[0][0], xn[ks][0], hch[0]);
-            hch[1] = T::mfma(w[1][0], xn[ks + 1][0], hch[1]);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
-#pragma unroll
-        for (int ks = 0; ks < HK; ks += 2) {
-            if (ks + 2 < HK) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NP == 2 ? 6 : 2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- exchange: the octet the mate owns goes to LDS, mine stays ----
-        float mine8[8];
-        {
-            f32x4 o0, o1;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                o0[e] = hch[0][8 * (1 - half) + e] + hch[1][8 * (1 - half) + e];
-                o1[e] = hch[0][8 * (1 - half) + 4 + e] + hch[1][8 * (1 - half) + 4 + e];
-            }
-            *reinterpret_cast<f32x4 *>(xch + wave * 2048 + lane * 16) = o0;
-            *reinterpret_cast<f32x4 *>(xch + wave * 2048 + 1024 + lane * 16) = o1;
-#pragma unroll
-            for (int e = 0; e < 8; e++) mine8[e] = hch[0][8 * half + e] + hch[1][8 * half + e];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // B1: partial sums visible
-        {
-            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(xch + mate * 2048 + lane * 16);
-            const f32x4 p1 = *reinterpret_cast<const f32x4 *>(xch + mate * 2048 + 1024 + lane * 16);
-#pragma unroll
-            for (int e = 0; e < 4; e++) { mine8[e] += p0[e]; mine8[4 + e] += p1[e]; }
-        }
-        u32x4 hf[2][2];                                    // [k-step kk of the c_proj slice][plane]
-        {
-            float v0[4], v1[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) { v0[e] = gelu_folded(mine8[e] * inv1); v1[e] = gelu_folded(mine8[4 + e] * inv1); }
-            u32x2 h0, l0, h1, l1;
-            split4<T, NP>(v0, h0, l0);
-            split4<T, NP>(v1, h1, l1);
-            u32x4 a, b;
-            a[0] = h0[0]; a[1] = h0[1]; a[2] = h1[0]; a[3] = h1[1];
-            b[0] = l0[0]; b[1] = l0[1]; b[2] = l1[0]; b[3] = l1[1];
-            *reinterpret_cast<u32x4 *>(xch + mate * 2048 + lane * 16) = a;
-            if (NP == 2) *reinterpret_cast<u32x4 *>(xch + mate * 2048 + 1024 + lane * 16) = b;
-            if (half == 0) { hf[0][0] = a; hf[0][1] = b; } else { hf[1][0] = a; hf[1][1] = b; }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // B2: hidden planes visible
-        {
-            const u32x4 a = *reinterpret_cast<const u32x4 *>(xch + wave * 2048 + lane * 16);
-            u32x4 b = a;
-            if (NP == 2) b = *reinterpret_cast<const u32x4 *>(xch + wave * 2048 + 1024 + lane * 16);
-            if (half == 0) { hf[1][0] = a; hf[1][1] = b; } else { hf[0][0] = a; hf[0][1] = b; }
-        }
-        // ---- c_proj for output tiles HT*half .. +HT: (kk, j) groups pairwise, neighbours differ in j ----
-        constexpr int NG = 2 * HT;
-#pragma unroll
-        for (int gi = 0; gi < NG; gi += 2) {
-            u32x4 w[2][2];
-#pragma unroll
-            for (int c = 0; c < 2; c++)
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++)
-                    w[c][pl] = *reinterpret_cast<const u32x4 *>(
-                        pk + (size_t)((KS + 2 * (HT * half + (gi + c) % HT) + (gi + c) / HT) * NP + pl) * 1024);
-            if (NP == 2) {
-                acc[gi % HT] = T::mfma(w[0][1], hf[gi / HT][0], acc[gi % HT]);
-                acc[(gi + 1) % HT] = T::mfma(w[1][1], hf[(gi + 1) / HT][0], acc[(gi + 1) % HT]);
-                acc[gi % HT] = T::mfma(w[0][0], hf[gi / HT][1], acc[gi % HT]);
-                acc[(gi + 1) % HT] = T::mfma(w[1][0], hf[(gi + 1) / HT][1], acc[(gi + 1) % HT]);
-            }
-            acc[gi % HT] = T::mfma(w[0][0], hf[gi / HT][0], acc[gi % HT]);
-            acc[(gi + 1) % HT] = T::mfma(w[1][0], hf[(gi + 1) / HT][0], acc[(gi + 1) % HT]);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
-#pragma unroll
-        for (int gi = 0; gi < NG; gi += 2) {
-            if (gi + 2 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
-            __builtin_amdgcn_sched_group_barrier(0x008, NP == 2 ? 6 : 2, 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of packet t+1 landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // B3: ... everyone's; packet t and the exchange areas are free
-    }
-
-    // ---- residual add and store for this wave's half of the columns ----
-#pragma unroll
-    for (int j = 0; j < HT; j++)
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
-            f32x4 cur = *dst;
-#pragma unroll
-            for (int e = 0; e < 4; e++) cur[e] += acc[j][4 * gq + e] * inv2;
-            *dst = cur;
-        }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fused LayerNorm + QKV projection in the register-resident style of mlp_fused_kernel: a workgroup = one row
-// (8 waves x 32 tokens), every wave normalises its 32 tokens once, keeps them as MFMA operand planes in registers
-// and walks all 3C/32 output tiles; weight fragments stream through an LDS ring by direct global->LDS loads.
-// Q and K tiles run "swapped" (lane = token: 4 consecutive d per store into the head-major planes), V tiles run
-// "natural" (lane = d: 4 consecutive tokens per store into the transposed planes).  No A-tile staging, no barrier
-// besides the ring hand-over, no LayerNorm statistics input.
-//   wpk: [tile][k-step][plane][lane][8]  (rows 32 tile .. +32 of c_attn.weight, k-slots permuted like the MLP's)
+// c_attn.weight for attn_block_kernel: [tile][k-step][plane][lane][8]  (rows 32 tile .. +32 of c_attn.weight, k-slots
+// permuted like the MLP's: the normalised tokens are MFMA operand planes in the swapped C/D register layout)
 // ---------------------------------------------------------------------------------------------
 template <class T, int NP>
 __global__ __launch_bounds__(256) void pack_rows_perm_kernel(const float *__restrict__ w, uint16_t *__restrict__ out,
@@ -1537,152 +1201,6 @@ __global__ __launch_bounds__(256) void pack_rows_perm_kernel(const float *__rest
     uint16_t *dst = out + (((size_t)t * KS + ks) * NP) * 512 + (size_t)lane * 8;
     *reinterpret_cast<u32x4 *>(dst) = hi;
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
-}
-
-template <class T, int NP, int CT>
-__global__ __launch_bounds__(512, 2) void ln_qkv_kernel(const float *__restrict__ x, const float *__restrict__ gain,
-                                                         const uint16_t *__restrict__ wpk, float inv_scale,
-                                                         uint16_t *__restrict__ qk_hi, uint16_t *__restrict__ qk_lo,
-                                                         uint16_t *__restrict__ vt_hi, uint16_t *__restrict__ vt_lo,
-                                                         int n_head, int hs, int64_t plane)
-{
-    constexpr int C = CT * 32, KS = C / 16, NTILE = 3 * CT, NW = 8, NBUF = 2;
-    constexpr int F = KS * NP;                             // fragment-planes (1 KiB) per tile packet
-    constexpr int PKT = F * 1024;
-    constexpr int PER_WAVE = (F + NW - 1) / NW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NBUF][PKT]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int64_t b = blockIdx.x;                                          // row (256 tokens)
-    const int tok0 = wave * 32;                                            // first token of this wave inside the row
-    const float *xrow = x + (b * kT + tok0 + r) * C;
-    const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(wpk);
-
-    auto issue = [&](int t) {
-        unsigned char *dst = smem + (size_t)(t % NBUF) * PKT;
-#pragma unroll
-        for (int i = 0; i < PER_WAVE; i++) {
-            const int c = min(wave + NW * i, F - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(wsrc + (size_t)t * PKT + (size_t)c * 1024 + lane * 16),
-                                             (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
-        }
-    };
-    issue(0);
-
-    // ---- LayerNorm of this lane's token (in-lane + one exchange), operand planes in registers ----
-    f32x16 xv[CT];
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < CT; j++)
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
-            xv[j][4 * gq] = v[0]; xv[j][4 * gq + 1] = v[1]; xv[j][4 * gq + 2] = v[2]; xv[j][4 * gq + 3] = v[3];
-            s += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-    s += __shfl_xor(s, 32);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < CT; j++)
-#pragma unroll
-        for (int g = 0; g < 16; g++) { const float d = xv[j][g] - mean; q += d * d; }
-    q += __shfl_xor(q, 32);
-    const float rstd = rsqrtf(q / (float)C + 1e-5f);
-    u32x4 xn[KS][2];
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-        const int j = ks >> 1, g0 = 8 * (ks & 1);
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 4 * h);
-        const f32x4 gb = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 8 + 4 * h);
-        float v0[4], v1[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            v0[e] = (xv[j][g0 + e] - mean) * rstd * ga[e];
-            v1[e] = (xv[j][g0 + 4 + e] - mean) * rstd * gb[e];
-        }
-        u32x2 h0, l0, h1, l1;
-        split4<T, NP>(v0, h0, l0);
-        split4<T, NP>(v1, h1, l1);
-        xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
-        xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
-    }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // packet 0 landed
-    __builtin_amdgcn_s_barrier();
-
-#pragma unroll 1
-    for (int t = 0; t < NTILE; t++) {
-        if (t + NBUF - 1 < NTILE) issue(t + NBUF - 1);
-        const unsigned char *pk = smem + (size_t)(t % NBUF) * PKT + lane * 16;
-        const bool is_v = t >= 2 * CT;                                     // workgroup-uniform
-        f32x16 a0, a1;
-#pragma unroll
-        for (int g = 0; g < 16; g++) { a0[g] = 0.f; a1[g] = 0.f; }
-        if (!is_v) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ks += 2) {
-                u32x4 w0[2], w1[2];
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) {
-                    w0[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(ks * NP + pl) * 1024);
-                    w1[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + 1) * NP + pl) * 1024);
-                }
-                a0 = mma<T, NP>(w0, xn[ks], a0);                           // swapped: rows = output features, cols = tokens
-                a1 = mma<T, NP>(w1, xn[ks + 1], a1);
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < KS; ks += 2) {
-                u32x4 w0[2], w1[2];
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) {
-                    w0[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)(ks * NP + pl) * 1024);
-                    w1[pl] = *reinterpret_cast<const u32x4 *>(pk + (size_t)((ks + 1) * NP + pl) * 1024);
-                }
-                a0 = mma<T, NP>(xn[ks], w0, a0);                           // natural: rows = tokens, cols = output features
-                a1 = mma<T, NP>(xn[ks + 1], w1, a1);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 16; g++) a0[g] = (a0[g] + a1[g]) * inv_scale;
-        // ---- epilogue of the tile ----
-        const int n0 = 32 * (t % CT);                                      // first feature of this tile inside q, k or v
-        if (!is_v) {
-            // lane = token tok0 + r; registers = features n0 + (g&3) + 8 (g>>2) + 4 h
-            const int which = t / CT;
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                const int n = n0 + 8 * gq + 4 * h;
-                const int head = n / hs, d = n - head * hs;
-                const int64_t off = (int64_t)which * plane + ((b * n_head + head) * kT + tok0 + r) * hs + d;
-                const float v[4] = {a0[4 * gq], a0[4 * gq + 1], a0[4 * gq + 2], a0[4 * gq + 3]};
-                u32x2 hi, lo;
-                split4<T, NP>(v, hi, lo);
-                *reinterpret_cast<u32x2 *>(qk_hi + off) = hi;
-                if (NP == 2) *reinterpret_cast<u32x2 *>(qk_lo + off) = lo;
-            }
-        } else {
-            // lane = feature n0 + r; registers = tokens tok0 + (g&3) + 8 (g>>2) + 4 h
-            const int n = n0 + r;
-            const int head = n / hs, d = n - head * hs;
-            const int64_t rowbase = ((b * n_head + head) * hs + d) * kT + tok0;
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                const float v[4] = {a0[4 * gq], a0[4 * gq + 1], a0[4 * gq + 2], a0[4 * gq + 3]};
-                u32x2 hi, lo;
-                split4<T, NP>(v, hi, lo);
-                *reinterpret_cast<u32x2 *>(vt_hi + rowbase + 8 * gq + 4 * h) = hi;
-                if (NP == 2) *reinterpret_cast<u32x2 *>(vt_lo + rowbase + 8 * gq + 4 * h) = lo;
-            }
-        }
-        // hand the ring over: packet t+1 (issued at the top of this iteration) must have landed everywhere.
-        // Plain vmcnt(0): this wave's epilogue stores share the counter and may retire out of order with the
-        // LDS-DMA loads, so a counted wait could not tell them apart.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
 }
 
 // out-projection weights for attn_block_kernel: [head t][out tile j][kk][plane][lane][8]; A rows = output features

@@ -1,5 +1,5 @@
-// tools/check_mlp256.hip -- mlp256_kernel against round 1's mlp_pair_kernel (validated against the reference goldens) on the
-// same random rows and weights; prints the largest difference per 32-column tile and per 32-token tile.
+// tools/check_mlp256.hip -- mlp256_kernel against an fp64 host computation of x + c_proj(GELU_erf(c_fc(LayerNorm(x))))
+// (model.py:84-89, 103) on random rows and weights.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,20 +18,12 @@ int main()
     for (auto &v : hg) v = 1.f + 0.1f * frand(seed);
     for (auto &v : hfc) v = 0.05f * frand(seed);
     for (auto &v : hpj) v = 0.05f * frand(seed);
-    float *x1, *x2, *g, *fc, *pj;
-    hipMalloc(&x1, hx.size() * 4); hipMalloc(&x2, hx.size() * 4); hipMalloc(&g, C * 4); hipMalloc(&fc, hfc.size() * 4); hipMalloc(&pj, hpj.size() * 4);
-    hipMemcpy(x1, hx.data(), hx.size() * 4, hipMemcpyHostToDevice); hipMemcpy(x2, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    float *x2, *g, *fc, *pj;
+    hipMalloc(&x2, hx.size() * 4); hipMalloc(&g, C * 4); hipMalloc(&fc, hfc.size() * 4); hipMalloc(&pj, hpj.size() * 4);
+    hipMemcpy(x2, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(g, hg.data(), C * 4, hipMemcpyHostToDevice); hipMemcpy(fc, hfc.data(), hfc.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(pj, hpj.data(), hpj.size() * 4, hipMemcpyHostToDevice);
     const float sc = 32768.f;
-    // old kernel
-    const size_t frags = C / 16 + 2 * (C / 32), nt = 4 * C / 32;
-    uint16_t *pk1; hipMalloc(&pk1, nt * frags * 2 * 512 * 2);
-    pack_mlp_kernel<F16T, 2><<<(unsigned)((nt * frags * 64 + 255) / 256), 256>>>(fc, pj, pk1, C, sc, sc);
-    const int lds1 = (int)(frags * 2 * 1024 * 2 + 8 * 2048 + 8 * 32 * 4 + 64);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_pair_kernel<F16T, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-    mlp_pair_kernel<F16T, 2, 8><<<M / 128, 512, lds1>>>(x1, g, pk1, 1.f / sc, 1.f / sc);
-    // new kernel
     uint16_t *pk2; hipMalloc(&pk2, (size_t)kM256Steps * 8 * 2 * 512 * 2);
     pack_mlp256_kernel<F16T, 2><<<(kM256Steps * 8 * 64 + 255) / 256, 256>>>(fc, pj, pk2, sc, sc);
     std::vector<float2> lut(kGeluLutN);
@@ -46,12 +38,30 @@ int main()
     mlp256_kernel<F16T, 2><<<M / 128, 256, lds2>>>(x2, g, pk2, 1.f / sc, 1.f / sc, dl);
     hipDeviceSynchronize();
     printf("launch status: %s\n", hipGetErrorString(hipGetLastError()));
-    std::vector<float> a(hx.size()), b(hx.size());
-    hipMemcpy(a.data(), x1, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), x2, b.size() * 4, hipMemcpyDeviceToHost);
-    double mx = 0, mxd = 0;
-    for (size_t i = 0; i < a.size(); i++) { mx = fmax(mx, fabs(a[i] - hx[i])); mxd = fmax(mxd, fabs(a[i] - b[i])); }
-    printf("max |mlp output| (old) %.4f   max |new - old| %.3e\n", mx, mxd);
-    for (int jt = 0; jt < 8; jt++) { double d = 0; for (int m = 0; m < M; m++) for (int c = 0; c < 32; c++) d = fmax(d, fabs(a[(size_t)m * C + jt * 32 + c] - b[(size_t)m * C + jt * 32 + c])); printf("col tile %d: %.3e\n", jt, d); }
-    for (int tt = 0; tt < M / 32; tt++) { double d = 0; for (int m = 0; m < 32; m++) for (int c = 0; c < C; c++) d = fmax(d, fabs(a[(size_t)(tt * 32 + m) * C + c] - b[(size_t)(tt * 32 + m) * C + c])); printf("token tile %d: %.3e\n", tt, d); }
-    return 0;
+    std::vector<float> b(hx.size());
+    hipMemcpy(b.data(), x2, b.size() * 4, hipMemcpyDeviceToHost);
+    // fp64 reference
+    double mxd = 0, mx = 0;
+    std::vector<double> xn(C), hid(4 * C);
+    for (int m = 0; m < M; m++) {
+        double mean = 0, var = 0;
+        for (int c = 0; c < C; c++) mean += hx[(size_t)m * C + c];
+        mean /= C;
+        for (int c = 0; c < C; c++) { const double d = hx[(size_t)m * C + c] - mean; var += d * d; }
+        const double rstd = 1.0 / sqrt(var / C + 1e-5);
+        for (int c = 0; c < C; c++) xn[c] = (hx[(size_t)m * C + c] - mean) * rstd * hg[c];
+        for (int u = 0; u < 4 * C; u++) {
+            double a = 0;
+            for (int c = 0; c < C; c++) a += xn[c] * hfc[(size_t)u * C + c];
+            hid[u] = 0.5 * a * (1.0 + erf(a * 0.70710678118654752440));
+        }
+        for (int o = 0; o < C; o++) {
+            double a = 0;
+            for (int u = 0; u < 4 * C; u++) a += hid[u] * hpj[(size_t)o * 4 * C + u];
+            mx = fmax(mx, fabs(a));
+            mxd = fmax(mxd, fabs(hx[(size_t)m * C + o] + a - b[(size_t)m * C + o]));
+        }
+    }
+    printf("max |mlp output| %.4f   max |kernel - fp64| %.3e\n", mx, mxd);
+    return mxd < 5e-6 ? 0 : 1;
 }
