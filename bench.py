@@ -250,7 +250,7 @@ def tokenizer_cfg4_launch(local_rank, reps=20):
             "note": "cfg4 per-GPU shard: 512 instances x 128 agents on per-instance 50 x 50 padded maps"}
 
 
-def build_workload(name, precision, rank, world, local_rank, instances=0):
+def build_workload(name, precision, rank, world, local_rank, instances=0, use_graph=True):
     """-> dict(run, pos, goal, grid, s_ok, g_ok, rows, n_total, ...) for this rank's shard of workload `name`."""
     from mapf_gpt_amd import maps
     from mapf_gpt_amd.model import build_model
@@ -270,7 +270,7 @@ def build_workload(name, precision, rank, world, local_rank, instances=0):
         grid, s_ok, g_ok = maps.load_named(map_name)
         pos, goal = make_instances(grid, hi - lo, n_agents, first_seed=lo, start_ok=s_ok, goal_ok=g_ok)
     run = BatchedRunner(grid, hi - lo, n_agents, net, max_episode_steps=max_steps, seed=0, do_sample=True,
-                        precision=precision, device=f"cuda:{local_rank}", row_offset=lo * n_agents)
+                        precision=precision, device=f"cuda:{local_rank}", row_offset=lo * n_agents, use_graph=use_graph)
     run.reset(pos, goal)
     return dict(name=name, run=run, net=net, pos=pos, goal=goal, grid=grid, s_ok=s_ok, g_ok=g_ok, rows=rows, n_total=n_total,
                 n_agents=n_agents, inst_per_gpu=inst_per_gpu, model=model, max_steps=max_steps, map_name=map_name)
@@ -443,6 +443,18 @@ def main():
                                          "value": w2["n_total"] * w2["n_agents"] * 8 / dt2, "unit": "agent-steps/s", "ms_per_step": 1e3 * dt2 / 8,
                                          "steps": 8, "warmup": 2, "dtype": a.precision}}
             del w2
+            torch.cuda.empty_cache()
+            # cfg1 (the reference's own CPU-runnable case: one 32-agent instance) is launch-bound: whole step replayed as a hipGraph
+            c1 = {}
+            for tag, ug in (("graph", True), ("eager", False)):
+                w1 = build_workload("cfg1", a.precision, 0, 1, local_rank, use_graph=ug)
+                dt1, _ = timed_steps(w1, 120, 8, 1, False, coll_dev)
+                c1[tag] = 1e3 * dt1 / 120
+                del w1
+            out["secondary"]["cfg1"] = {"workload": "cfg1: validation-random-seed-000, 32 agents, MAPF-GPT-2M shape, 1 instance, 32 rows/step",
+                                        "value": 32 / (c1["graph"] * 1e-3), "unit": "agent-steps/s", "ms_per_step": c1["graph"],
+                                        "ms_per_step_eager_launches": c1["eager"], "graph_speedup": c1["eager"] / c1["graph"],
+                                        "steps": 120, "warmup": 8, "dtype": a.precision}
             torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline and name != "cfg4":
             out["cpu_baseline"] = cpu_baseline(map_name, n_agents, model)

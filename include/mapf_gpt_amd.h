@@ -181,9 +181,34 @@ int mgpt_gpt_debug_copy(mgpt_gpt *gpt, int which, float *d_out, int64_t n_elem, 
  * 5/6 = attention output planes hi/lo; 7/8 = MLP hidden planes hi/lo (lo only for MGPT_PREC_F16X3). */
 int mgpt_gpt_debug_copy_raw(mgpt_gpt *gpt, int precision, int which, void *d_out, int64_t nbytes, void *stream);
 
+/* mgpt_gpt_act with the RNG step read from device memory when the kernel runs (*d_step): for callers that replay the call
+ * from a captured hipGraph, where a per-step scalar argument would be frozen */
+int mgpt_gpt_act_dev(mgpt_gpt *gpt, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits,
+                     int do_sample, uint64_t seed, const uint64_t *d_step, uint64_t row0, int precision, void *stream);
+
 /* sampling alone (same RNG and key as mgpt_gpt_act), for callers that already hold logits */
 int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_actions, int do_sample,
                         uint64_t seed, uint64_t step, uint64_t row0, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One whole environment step = the body of the reference's episode loop (example.py:63-65 around
+ * inference.py:151-172):  update_agents(pos, goal, last actions) -> generate_observations -> act -> env.step.
+ * The launch sequence is static, so after one eager step it is captured as a hipGraph and replayed: one call, no
+ * per-launch host cost.  The contexts stay owned by the caller and must outlive the step object.
+ *   create: rows = n_inst * n_agents of the tokenizer/env pair; precision / do_sample / seed / row0 as in mgpt_gpt_act.
+ *   run:    d_tokens uint8 [rows, 256] scratch (holds this step's observation rows afterwards); d_actions int32 [rows]
+ *           IN: the previous intended actions (-1 on the first step, inference.py:140), OUT: this step's actions, already
+ *           executed by the env.  goals_may_change as in mgpt_tokenizer_update_agents.  use_graph = 0 forces eager launches
+ *           (identical results); eager is also used while the timing hooks are enabled.
+ *   reset:  sets the RNG step counter (call with 0 when an episode starts; the k-th run after it draws with step k) and
+ *           drops the captured graph -- call it after anything that re-allocates inside the contexts (mgpt_env_set_lifelong).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mgpt_step mgpt_step;
+int mgpt_step_create(mgpt_step **out, mgpt_tokenizer *tok, mgpt_gpt *gpt, mgpt_env *env, int rows, int precision,
+                     int do_sample, uint64_t seed, uint64_t row0);
+int mgpt_step_destroy(mgpt_step *step);
+int mgpt_step_reset(mgpt_step *step, uint64_t step0, void *stream);
+int mgpt_step_run(mgpt_step *step, uint8_t *d_tokens, int32_t *d_actions, int goals_may_change, int use_graph, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dataset-side bulk tokenizer: replaces dataset/tokenizer/generate_observations.py:8-92 with its two native modules

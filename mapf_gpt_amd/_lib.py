@@ -66,6 +66,11 @@ SYMBOLS = {
     "mgpt_gpt_finalize": (_i, [_vp]),
     "mgpt_gpt_forward": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "mgpt_gpt_act": (_i, [_vp, _vp, _i, _vp, _vp, _i, _u64, _u64, _u64, _i, _vp]),
+    "mgpt_gpt_act_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _u64, _vp, _u64, _i, _vp]),
+    "mgpt_step_create": (_i, [_pp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64]),
+    "mgpt_step_destroy": (_i, [_vp]),
+    "mgpt_step_reset": (_i, [_vp, _u64, _vp]),
+    "mgpt_step_run": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "mgpt_gpt_debug_copy": (_i, [_vp, _i, _vp, _i64, _vp]),
     "mgpt_gpt_debug_copy_raw": (_i, [_vp, _i, _i, _vp, _i64, _vp]),
     "mgpt_sample_actions": (_i, [_vp, _i, _vp, _i, _u64, _u64, _u64, _vp]),

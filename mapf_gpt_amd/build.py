@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(CSRC, "libmapf_gpt_amd.so")
-SOURCES = ["prof.hip", "tokenizer.hip", "env.hip", "gpt.hip", "gpt_fast.hip"]
+SOURCES = ["prof.hip", "tokenizer.hip", "env.hip", "gpt.hip", "gpt_fast.hip", "step.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]

@@ -27,10 +27,12 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t step, uint64_
 }
 
 __global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ logits, int rows, int32_t *__restrict__ actions,
-                                                     int do_sample, uint64_t seed, uint64_t step, uint64_t row0)
+                                                     int do_sample, uint64_t seed, uint64_t step, uint64_t row0,
+                                                     const uint64_t *__restrict__ d_step)
 {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
+    if (d_step) step = *d_step;                  // step counter kept on the device (mgpt_step_run's graph)
     const float *l = logits + (size_t)row * kV;
     float v[MGPT_NUM_ACTIONS];
     float mx = -INFINITY;
@@ -304,13 +306,13 @@ extern "C" int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_a
     MGPT_REQUIRE(d_logits && d_actions && rows > 0, MGPT_ERR_ARG, "bad argument");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(P_SAMPLE, s);
-    hipLaunchKernelGGL(sample_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, d_logits, rows, d_actions, do_sample, seed, step, row0);
+    hipLaunchKernelGGL(sample_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, d_logits, rows, d_actions, do_sample, seed, step, row0, (const uint64_t *)nullptr);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
 
-extern "C" int mgpt_gpt_act(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits,
-                            int do_sample, uint64_t seed, uint64_t step, uint64_t row0, int precision, void *stream)
+static int gpt_act_impl(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits, int do_sample,
+                        uint64_t seed, uint64_t step, const uint64_t *d_step, uint64_t row0, int precision, void *stream)
 {
     MGPT_REQUIRE(g && d_tokens && d_actions, MGPT_ERR_ARG, "NULL argument");
     MGPT_REQUIRE(rows > 0, MGPT_ERR_ARG, "rows=%d", rows);
@@ -324,8 +326,23 @@ extern "C" int mgpt_gpt_act(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int3
         if (rc != MGPT_OK) return rc;
         ProfScope ps(P_SAMPLE, s);
         hipLaunchKernelGGL(sample_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, lg, n, d_actions + r0, do_sample,
-                           seed, step, row0 + (uint64_t)r0);
+                           seed, step, row0 + (uint64_t)r0, d_step);
         MGPT_LAUNCH_CHECK();
     }
     return MGPT_OK;
+}
+
+extern "C" int mgpt_gpt_act(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits,
+                            int do_sample, uint64_t seed, uint64_t step, uint64_t row0, int precision, void *stream)
+{
+    return gpt_act_impl(g, d_tokens, rows, d_actions, d_logits, do_sample, seed, step, nullptr, row0, precision, stream);
+}
+
+// the same with the RNG step counter read from device memory at run time (step.hip: a captured graph cannot carry a
+// per-step scalar argument)
+extern "C" int mgpt_gpt_act_dev(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits, int do_sample,
+                                uint64_t seed, const uint64_t *d_step, uint64_t row0, int precision, void *stream)
+{
+    MGPT_REQUIRE(d_step, MGPT_ERR_ARG, "NULL step counter");
+    return gpt_act_impl(g, d_tokens, rows, d_actions, d_logits, do_sample, seed, 0, d_step, row0, precision, stream);
 }

@@ -34,6 +34,7 @@ struct ProfState {
     int64_t launches[P_COUNT] = {0};
 };
 static ProfState g_prof;
+bool prof_is_enabled() { return g_prof.on; }
 static const size_t kMaxRecs = 1u << 17;
 
 ProfScope::ProfScope(ProfId id, hipStream_t stream) : slot(-1), s(stream)
@@ -80,7 +81,7 @@ using namespace mgpt;
 
 extern "C" const char *mgpt_last_error(void) { return g_err; }
 
-extern "C" int mgpt_abi_version(void) { return 1001; }
+extern "C" int mgpt_abi_version(void) { return 1002; }
 
 extern "C" int mgpt_device_count(int *count)
 {

@@ -58,7 +58,7 @@ def make_instances(grid, n_inst, n_agents, first_seed=0, start_ok=None, goal_ok=
 
 class BatchedRunner:
     def __init__(self, grids, n_inst, n_agents, net, max_episode_steps=128, seed=0, do_sample=True, precision=None,
-                 device="cuda", row_offset=0):
+                 device="cuda", row_offset=0, use_graph=True):
         self.device = torch.device(device)
         self.env = BatchedEnv(grids, n_inst, n_agents, max_episode_steps, device=device)
         self.tok = BatchedTokenizer(grids, n_inst, n_agents, device=device)
@@ -71,6 +71,22 @@ class BatchedRunner:
         self.actions = torch.full((n_inst, n_agents), -1, dtype=torch.int32, device=self.device)
         self.t = 0
         self._pos_ptr, self._goal_ptr, _ = self.env.state_ptrs()
+        # the whole step behind one library call, replayed as a hipGraph after the first (eager) step
+        self.use_graph = bool(use_graph)
+        self._step = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_step_create(ctypes.byref(self._step), self.tok._h, self.net._h, self.env._h, self.rows,
+                                                   _lib.PRECISIONS[precision or net.precision], 1 if do_sample else 0,
+                                                   int(seed) & (2 ** 64 - 1), int(row_offset)))
+
+    def __del__(self):
+        h = getattr(self, "_step", None)
+        if h:
+            try:
+                _lib.lib().mgpt_step_destroy(h)
+            except Exception:      # interpreter shutdown
+                pass
+            self._step = None
 
     def reset(self, pos, goal, goal_queue=None):
         """goal_queue int16 [n_inst, n_agents, Q, 2]: lifelong mode (on_target="restart"), the tokenizer then re-checks
@@ -81,18 +97,14 @@ class BatchedRunner:
         self.tok.create_agents(self.env.pos, self.env.goal)
         self.actions.fill_(-1)                                   # inference.py:140
         self.t = 0
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_step_reset(self._step, 0, _lib.stream_ptr()))
 
     def step(self):
-        L = _lib.lib()
-        s = _lib.stream_ptr()
+        """update_agents -> generate_observations -> act -> env.step in ONE library call (mgpt_step_run)."""
         with torch.cuda.device(self.device):
-            _lib.check(L.mgpt_tokenizer_update_agents(self.tok._h, self._pos_ptr, self._goal_ptr, _lib.ptr(self.actions),
-                                                      1 if self.env.lifelong else 0, s))
-            _lib.check(L.mgpt_tokenizer_generate_observations(self.tok._h, _lib.ptr(self.tokens), s))
-        self.net.act_tokens(self.tokens, do_sample=self.do_sample, seed=self.seed, step=self.t, precision=self.precision,
-                            out=self.actions.view(-1), row0=self.row_offset)
-        with torch.cuda.device(self.device):
-            _lib.check(L.mgpt_env_step(self.env._h, _lib.ptr(self.actions), s))
+            _lib.check(_lib.lib().mgpt_step_run(self._step, _lib.ptr(self.tokens), _lib.ptr(self.actions.view(-1)),
+                                                1 if self.env.lifelong else 0, 1 if self.use_graph else 0, _lib.stream_ptr()))
         self.t += 1
 
     def run(self, steps):

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(L):
 
 
 def test_version_and_error_string(L):
-    assert L.mgpt_abi_version() == 1001
+    assert L.mgpt_abi_version() == 1002
     rc = L.mgpt_gpt_create(None, 1, 1, 32, 256, 1)
     assert rc == _lib.ERR_ARG and b"NULL" in L.mgpt_last_error()
 
