@@ -98,14 +98,37 @@ def _cpu_worker(job):
     return n_agents * timed, t_tok + t_fwd + t_env, (t_tok, t_fwd, t_env), timed
 
 
-def cpu_baseline(map_name, n_agents, model, budget_s=8.0):
+def usable_cpus():
+    """Cores this container may actually burn: the affinity mask capped by the cgroup CPU quota (the round-2 GPU box shows
+    256 logical CPUs but cpu.max = 1600000/100000, i.e. 16 cores; a pool sized by the mask was 16x oversubscribed)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+def cpu_baseline(map_name, n_agents, model, budget_s=10.0):
     """Oracle (C env + tokenizer restatement, PyTorch-CPU fp32 forward = the ops the reference executes) timed on the host
     cores, bounded sample, two ways: (a) a pool of processes (the reference's own CPU path is a `num_process` pool,
     inference.py:30-31, eval_configs/01-random/01-random.yaml:147-148), 16 intra-op threads each, one instance of the same
-    workload per process pinned to its own block of cores; (b) ONE process with 32 intra-op threads.  `value` is the better
-    of the two (on the 256-thread driver box the pool loses: 16 concurrent fp32 forwards are memory-bound)."""
+    workload per process pinned to its own block of cores; (b) ONE process with up to 32 intra-op threads.  `value` is the
+    better of the two.  The core count is the cgroup-quota-capped one (usable_cpus): with 16 usable cores (a) and (b) are the
+    same single 16-thread process and only (a) runs."""
     import multiprocessing as mp
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncpu, quota = usable_cpus()
     threads = min(16, ncpu)
     procs = max(1, ncpu // threads)
     from oracle import oracle as orc
@@ -121,10 +144,13 @@ def cpu_baseline(map_name, n_agents, model, budget_s=8.0):
     wall = time.perf_counter() - t0
     rate_pool = sum(a / t for a, t, _, _ in res)  # processes run concurrently: rates add
     one_threads = min(32, ncpu)
-    os.environ["OMP_NUM_THREADS"] = str(one_threads)
-    os.environ["MKL_NUM_THREADS"] = str(one_threads)
-    with ctx.Pool(1) as pool:
-        one = pool.map(_cpu_worker, [(map_name, n_agents, model, 0, one_threads, budget_s, allc[:one_threads])])[0]
+    if procs == 1 and one_threads == threads:
+        one = res[0]
+    else:
+        os.environ["OMP_NUM_THREADS"] = str(one_threads)
+        os.environ["MKL_NUM_THREADS"] = str(one_threads)
+        with ctx.Pool(1) as pool:
+            one = pool.map(_cpu_worker, [(map_name, n_agents, model, 0, one_threads, budget_s, allc[:one_threads])])[0]
     rate_one = one[0] / one[1]
     best_pool = rate_pool >= rate_one
     src = res if best_pool else [one]
@@ -150,7 +176,7 @@ def cpu_baseline(map_name, n_agents, model, budget_s=8.0):
         pass
     return {"value": max(rate_pool, rate_one), "unit": "agent-steps/s", "cores": procs * threads if best_pool else one_threads,
             "processes": procs if best_pool else 1, "threads_per_process": threads if best_pool else one_threads,
-            "host_cpus": ncpu, "kind": "port",
+            "usable_cpus": ncpu, "cgroup_cpu_quota": quota, "logical_cpus_visible": os.cpu_count(), "kind": "port",
             "pool_rate": rate_pool, "single_process_rate": rate_one,
             "sample": f"(a) {procs} pinned processes x {threads} threads, each 1 instance x {n_agents} agents of the same workload for ~{budget_s:.0f} s "
                       f"({sum(r[3] for r in res)} timed steps in all, {wall:.0f} s wall incl. start-up): {rate_pool:.0f} agent-steps/s; "

@@ -123,8 +123,10 @@ int mgpt_env_step(mgpt_env *env, const int32_t *d_actions, void *stream);
 int mgpt_env_state(mgpt_env *env, const int16_t **d_pos, const int16_t **d_goal, const uint8_t **d_done);
 /* the same state copied (stream-ordered, device to device) into caller-owned buffers; any may be NULL */
 int mgpt_env_copy_state(mgpt_env *env, int16_t *d_pos_out, int16_t *d_goal_out, uint8_t *d_done_out, void *stream);
-/* per-instance episode metrics, float32 [n_inst, 5] = {CSR, ISR, SoC, makespan, ep_length}
- * (the keys the reference's result tables use: eval_configs/05-puzzles/05-puzzles.yaml:49-58). */
+/* per-instance episode metrics, float32 [n_inst, 6] = {CSR, ISR, SoC, makespan, ep_length, avg_agents_density}
+ * (the keys the reference's result tables use: eval_configs/05-puzzles/05-puzzles.yaml:49-58; avg_agents_density =
+ * POGEMA's AgentsDensityWrapper of experiment_setup/create_env.py:38: mean over the reset observation and every step of
+ * the agents' mean [agents in the 11 x 11 window / traversable cells of the window]). */
 int mgpt_env_metrics(mgpt_env *env, float *d_metrics, void *stream);
 
 /* Lifelong mode (POGEMA on_target="restart", experiment_setup/create_env.py:28-32): d_goal_queue is int16

@@ -18,6 +18,12 @@
 //   the episode only ends by truncation.  The tokenizer sees the goal change through update_agents
 //   (observation_generator.cpp:464-477: a new cost-to-go field for that agent).
 //
+//   avg_agents_density (POGEMA's AgentsDensityWrapper, wired in at create_env.py:38,49; result key of
+//   eval_configs/05-puzzles/05-puzzles.yaml:55): after reset and after every step, each agent's local density =
+//   (agents inside its (2r+1)^2 observation window, itself included) / (traversable cells of that window, out-of-map
+//   cells counting as obstacles), averaged over the agents; the metric is the mean of those T+1 samples.  r = 5
+//   (example.py:48; the eval YAMLs keep POGEMA's default).
+//
 // One workgroup per instance, one thread per agent; the per-agent current/target cell ids live in
 // LDS and every conflict test is an O(n_agents) LDS scan (n_agents <= 1024), so no per-cell scratch
 // grid is needed.  Traffic is ~13 B per agent-step: negligible next to the tokenizer and the policy.
@@ -42,17 +48,79 @@ __global__ void env_reset_kernel(int16_t *__restrict__ pos, int16_t *__restrict_
     if (i < n_inst) { tcount[i] = 0; done[i] = 0; }
 }
 
+constexpr int kDensityRadius = 5;       // obs_radius of the reference's GridConfig (example.py:48)
+
+// traversable cells of the (2r+1)^2 window around every cell (out-of-frame = obstacle), one byte per cell (<= 121)
+__global__ void env_window_free_kernel(const uint8_t *__restrict__ grids, int n_grids, int H, int W, uint8_t *__restrict__ wfree)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n_grids * H * W) return;
+    const int c = (int)(i % W), r = (int)((i / W) % H);
+    const uint8_t *grid = grids + (i / ((size_t)H * W)) * H * W;
+    int n = 0;
+    for (int dr = -kDensityRadius; dr <= kDensityRadius; dr++)
+        for (int dc = -kDensityRadius; dc <= kDensityRadius; dc++) {
+            const int rr = r + dr, cc = c + dc;
+            n += (rr >= 0 && rr < H && cc >= 0 && cc < W && grid[rr * W + cc] == 0) ? 1 : 0;
+        }
+    wfree[i] = (uint8_t)n;
+}
+
+// One density sample of an instance: cells[] (LDS, cell id per agent) -> mean over agents of in-window agents / in-window
+// traversable cells, added to dens[inst].  Fixed reduction shape (wave shuffle tree, then wave partials in order) so that
+// the sum does not depend on scheduling.  Must be called by every thread of the block; cells[] must be visible.
+__device__ void density_sample(const int *cells, int n_agents, int W, const uint8_t *__restrict__ wfree, double *part,
+                               double *__restrict__ dens)
+{
+    const int a = threadIdx.x;
+    double d = 0.0;
+    if (a < n_agents) {
+        const int me = cells[a], r = me / W, c = me - r * W;
+        int cnt = 0;
+        for (int b = 0; b < n_agents; b++) {
+            const int o = cells[b], orow = o / W, ocol = o - orow * W;
+            cnt += (abs(orow - r) <= kDensityRadius && abs(ocol - c) <= kDensityRadius) ? 1 : 0;
+        }
+        d = (double)cnt / (double)wfree[me];
+    }
+    for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+    if ((a & 63) == 0) part[a >> 6] = d;
+    __syncthreads();
+    if (a == 0) {
+        double sum = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) sum += part[w];
+        *dens += sum / (double)n_agents;
+    }
+}
+
+// the sample of the initial observation (AgentsDensityWrapper.reset)
+__global__ __launch_bounds__(1024) void env_density0_kernel(const int16_t *__restrict__ pos, int n_agents, int n_grids, int H, int W,
+                                                            const uint8_t *__restrict__ wfree, double *__restrict__ dens)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *cells = reinterpret_cast<int *>(smem);
+    double *part = reinterpret_cast<double *>(cells + 2 * n_agents);
+    const int inst = blockIdx.x, a = threadIdx.x;
+    const size_t g = (size_t)inst * n_agents + a;
+    if (a < n_agents) cells[a] = pos[2 * g] * W + pos[2 * g + 1];
+    if (a == 0) dens[inst] = 0.0;
+    __syncthreads();
+    density_sample(cells, n_agents, W, wfree + (size_t)(inst % n_grids) * H * W, part, dens + inst);
+}
+
 __global__ __launch_bounds__(1024) void env_step_kernel(const uint8_t *__restrict__ grids, int n_grids, int n_agents,
                                                         int H, int W, int max_steps, int16_t *__restrict__ pos,
                                                         int16_t *__restrict__ goal,
                                                         const int32_t *__restrict__ actions, int32_t *__restrict__ arrive,
                                                         int32_t *__restrict__ tcount, uint8_t *__restrict__ done,
                                                         const int16_t *__restrict__ goal_queue, int queue_len,
-                                                        int32_t *__restrict__ qnext, int32_t *__restrict__ reached)
+                                                        int32_t *__restrict__ qnext, int32_t *__restrict__ reached,
+                                                        const uint8_t *__restrict__ wfree, double *__restrict__ dens)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *cur = reinterpret_cast<int *>(smem);
     int *tgt = cur + n_agents;
+    double *part = reinterpret_cast<double *>(tgt + n_agents);      // 2 * n_agents ints: 8-byte aligned
     const int inst = blockIdx.x;
     if (done[inst] != 0) return;                      // workgroup-uniform
     const uint8_t *grid = grids + (size_t)(inst % n_grids) * H * W;
@@ -117,6 +185,7 @@ __global__ __launch_bounds__(1024) void env_step_kernel(const uint8_t *__restric
         }
     }
     const int n_on = __syncthreads_count(on);
+    density_sample(tgt, n_agents, W, wfree + (size_t)(inst % n_grids) * H * W, part, dens + inst);   // tgt[] = the new cells
     if (a == 0) {
         tcount[inst] = t_new;
         if (goal_queue == nullptr && n_on == n_agents) done[inst] = 1;
@@ -124,10 +193,10 @@ __global__ __launch_bounds__(1024) void env_step_kernel(const uint8_t *__restric
     }
 }
 
-// {CSR, ISR, SoC, makespan, ep_length} per instance (keys of eval_configs/*/*.yaml results_views)
+// {CSR, ISR, SoC, makespan, ep_length, avg_agents_density} per instance (keys of eval_configs/*/*.yaml results_views)
 __global__ void env_metrics_kernel(const int16_t *__restrict__ pos, const int16_t *__restrict__ goal,
-                                   const int32_t *__restrict__ arrive, const int32_t *__restrict__ tcount, int n_inst,
-                                   int n_agents, float *__restrict__ out)
+                                   const int32_t *__restrict__ arrive, const int32_t *__restrict__ tcount,
+                                   const double *__restrict__ dens, int n_inst, int n_agents, float *__restrict__ out)
 {
     const int inst = blockIdx.x * blockDim.x + threadIdx.x;
     if (inst >= n_inst) return;
@@ -141,7 +210,8 @@ __global__ void env_metrics_kernel(const int16_t *__restrict__ pos, const int16_
         soc += ta;
         mk = max(mk, ta);
     }
-    float *m = out + (size_t)inst * 5;
+    float *m = out + (size_t)inst * 6;
+    m[5] = (float)(dens[inst] / (double)(t + 1));       // samples: the reset observation + one per step
     m[0] = (on == n_agents) ? 1.f : 0.f;
     m[1] = (float)on / (float)n_agents;
     m[2] = (float)soc;
@@ -151,12 +221,17 @@ __global__ void env_metrics_kernel(const int16_t *__restrict__ pos, const int16_
 
 }  // namespace
 
+// LDS of the per-instance kernels: cur[] + tgt[] cell ids, then 16 wave partials of the density reduction (8-byte aligned)
+static size_t env_lds_bytes(int n_agents) { return (size_t)n_agents * 2 * sizeof(int) + 16 * sizeof(double); }
+
 struct mgpt_env {
     int n_inst, n_agents, H, W, n_grids, max_steps;
     uint8_t *grids = nullptr;
     int16_t *pos = nullptr, *goal = nullptr;
     int32_t *arrive = nullptr, *tcount = nullptr;
     uint8_t *done = nullptr;
+    uint8_t *wfree = nullptr;           // [n_grids][H][W] traversable cells of the observation window around each cell
+    double *dens = nullptr;             // [n_inst] running sum of the per-sample mean agent densities
     int16_t *goal_queue = nullptr;      // lifelong: [n_inst][n_agents][queue_len][2], else NULL
     int32_t *qnext = nullptr, *reached = nullptr;
     int queue_len = 0;
@@ -178,6 +253,8 @@ extern "C" int mgpt_env_create(mgpt_env **out, int n_inst, int n_agents, int H, 
     if (err == hipSuccess) err = hipMalloc(&e->arrive, total * sizeof(int32_t));
     if (err == hipSuccess) err = hipMalloc(&e->tcount, (size_t)n_inst * sizeof(int32_t));
     if (err == hipSuccess) err = hipMalloc(&e->done, (size_t)n_inst);
+    if (err == hipSuccess) err = hipMalloc(&e->wfree, (size_t)n_grids * H * W);
+    if (err == hipSuccess) err = hipMalloc(&e->dens, (size_t)n_inst * sizeof(double));
     if (err != hipSuccess) {
         set_error("hipMalloc failed in mgpt_env_create: %s", hipGetErrorString(err));
         mgpt_env_destroy(e);
@@ -192,6 +269,7 @@ extern "C" int mgpt_env_destroy(mgpt_env *e)
     if (!e) return MGPT_OK;
     (void)hipFree(e->grids); (void)hipFree(e->pos); (void)hipFree(e->goal);
     (void)hipFree(e->arrive); (void)hipFree(e->tcount); (void)hipFree(e->done);
+    (void)hipFree(e->wfree); (void)hipFree(e->dens);
     (void)hipFree(e->goal_queue); (void)hipFree(e->qnext); (void)hipFree(e->reached);
     delete e;
     return MGPT_OK;
@@ -202,6 +280,10 @@ extern "C" int mgpt_env_set_grids(mgpt_env *e, const uint8_t *d_grids, void *str
     MGPT_REQUIRE(e && d_grids, MGPT_ERR_ARG, "NULL argument");
     MGPT_HIP(hipMemcpyAsync(e->grids, d_grids, (size_t)e->n_grids * e->H * e->W, hipMemcpyDeviceToDevice,
                             (hipStream_t)stream));
+    const size_t cells = (size_t)e->n_grids * e->H * e->W;
+    hipLaunchKernelGGL(env_window_free_kernel, dim3((unsigned)cdiv64((int64_t)cells, 256)), dim3(256), 0, (hipStream_t)stream, e->grids,
+                       e->n_grids, e->H, e->W, e->wfree);
+    MGPT_LAUNCH_CHECK();
     e->have_grids = true;
     return MGPT_OK;
 }
@@ -214,6 +296,10 @@ extern "C" int mgpt_env_reset(mgpt_env *e, const int16_t *d_pos, const int16_t *
     const int total = e->n_inst * e->n_agents;
     hipLaunchKernelGGL(env_reset_kernel, dim3(cdiv(total > e->n_inst ? total : e->n_inst, 256)), dim3(256), 0, s, e->pos,
                        e->goal, d_pos, d_goal, e->arrive, e->tcount, e->done, e->n_inst, e->n_agents);
+    MGPT_LAUNCH_CHECK();
+    const int threads = cdiv(e->n_agents, 64) * 64;
+    hipLaunchKernelGGL(env_density0_kernel, dim3(e->n_inst), dim3(threads), env_lds_bytes(e->n_agents), s, e->pos, e->n_agents,
+                       e->n_grids, e->H, e->W, e->wfree, e->dens);
     MGPT_LAUNCH_CHECK();
     if (e->goal_queue != nullptr) {
         const size_t total_b = (size_t)total * sizeof(int32_t);
@@ -265,9 +351,9 @@ extern "C" int mgpt_env_step(mgpt_env *e, const int32_t *d_actions, void *stream
     hipStream_t s = (hipStream_t)stream;
     const int threads = cdiv(e->n_agents, 64) * 64;
     ProfScope ps(P_ENV_STEP, s);
-    hipLaunchKernelGGL(env_step_kernel, dim3(e->n_inst), dim3(threads), (size_t)e->n_agents * 2 * sizeof(int), s, e->grids,
+    hipLaunchKernelGGL(env_step_kernel, dim3(e->n_inst), dim3(threads), env_lds_bytes(e->n_agents), s, e->grids,
                        e->n_grids, e->n_agents, e->H, e->W, e->max_steps, e->pos, e->goal, d_actions, e->arrive,
-                       e->tcount, e->done, e->goal_queue, e->queue_len, e->qnext, e->reached);
+                       e->tcount, e->done, e->goal_queue, e->queue_len, e->qnext, e->reached, e->wfree, e->dens);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
@@ -288,7 +374,7 @@ extern "C" int mgpt_env_metrics(mgpt_env *e, float *d_metrics, void *stream)
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(P_ENV_METRICS, s);
     hipLaunchKernelGGL(env_metrics_kernel, dim3(cdiv(e->n_inst, 64)), dim3(64), 0, s, e->pos, e->goal, e->arrive,
-                       e->tcount, e->n_inst, e->n_agents, d_metrics);
+                       e->tcount, e->dens, e->n_inst, e->n_agents, d_metrics);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }

@@ -172,8 +172,11 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             MGPT_LAUNCH_CHECK();
         }
         const int pkt = (int)(frags * NP * 1024 * 3);
-        if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
-        else MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt));
+#define MGPT_MLP_ATTR(CT_, NW_) \
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, CT_, NW_>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt))
+        if (C == 160) { MGPT_MLP_ATTR(5, 8); MGPT_MLP_ATTR(5, 4); MGPT_MLP_ATTR(5, 2); }
+        else { MGPT_MLP_ATTR(2, 8); MGPT_MLP_ATTR(2, 4); MGPT_MLP_ATTR(2, 2); }
+#undef MGPT_MLP_ATTR
     }
     m->qkv_fused = (C == 160 || C == 64);
     if (m->qkv_fused) {
@@ -457,12 +460,15 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                 }
             } else {
                 const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 3;
-                if (C == 160)
-                    hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 5>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
-                                       m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
-                else
-                    hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, 2>), dim3((unsigned)(mlp_M / 256)), dim3(512), lds, s, mlp_x, P + lo.ln2,
-                                       m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M);
+                // 32 tokens per wave whatever the block size: small launches (cfg1: 32 rows = 32 blocks of 256 tokens) take
+                // fewer waves per block so that the tokens spread over more CUs; results do not depend on the choice
+#define MGPT_MLP(CT_, NW_)                                                                                                           \
+    hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, CT_, NW_>), dim3((unsigned)(mlp_M / (32 * NW_))), dim3(64 * NW_), lds, s, mlp_x, \
+                       P + lo.ln2, m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M)
+                const int nw = (mlp_M >= (int64_t)256 * m->n_cu) ? 8 : (mlp_M >= (int64_t)128 * m->n_cu ? 4 : 2);
+                if (C == 160) { if (nw == 8) MGPT_MLP(5, 8); else if (nw == 4) MGPT_MLP(5, 4); else MGPT_MLP(5, 2); }
+                else { if (nw == 8) MGPT_MLP(2, 8); else if (nw == 4) MGPT_MLP(2, 4); else MGPT_MLP(2, 2); }
+#undef MGPT_MLP
             }
             MGPT_LAUNCH_CHECK();
             continue;

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib, maps
 
-METRIC_KEYS = ("CSR", "ISR", "SoC", "makespan", "ep_length")   # eval_configs/*/*.yaml results_views
+METRIC_KEYS = ("CSR", "ISR", "SoC", "makespan", "ep_length", "avg_agents_density")   # eval_configs/*/*.yaml results_views
 
 
 class BatchedEnv:
@@ -95,8 +95,8 @@ class BatchedEnv:
         return self.pos, self.goal, self.done
 
     def metrics(self):
-        """float32 [n_inst, 5] = CSR, ISR, SoC, makespan, ep_length (device tensor)."""
-        out = torch.empty((self.n_inst, 5), dtype=torch.float32, device=self.device)
+        """float32 [n_inst, 6] = CSR, ISR, SoC, makespan, ep_length, avg_agents_density (device tensor)."""
+        out = torch.empty((self.n_inst, len(METRIC_KEYS)), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().mgpt_env_metrics(self._h, _lib.ptr(out), _lib.stream_ptr()))
         return out

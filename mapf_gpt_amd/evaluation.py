@@ -29,7 +29,7 @@ import numpy as np
 
 from . import maps as _maps
 
-METRIC_KEYS = ("CSR", "ISR", "SoC", "makespan", "ep_length")
+METRIC_KEYS = ("CSR", "ISR", "SoC", "makespan", "ep_length", "avg_agents_density")
 LIFELONG_QUEUE = 64          # goals pre-generated per agent in on_target="restart" runs (the queue wraps)
 
 
@@ -121,6 +121,63 @@ def tabular_view(results, view_cfg, print_fn=print):
     return table
 
 
+def plot_series(results, view_cfg):
+    """Data of a `type: plot` view (eval_configs/01-random/01-random.yaml:162-186): per algorithm, the mean of metric
+    `y` at every value of grid key `x` over all other grid keys (seeds, maps), with a normal-approximation 95 % interval
+    of that mean -> {algorithm: [(x, mean, lo, hi, n), ...]} sorted by x."""
+    xk, yk = view_cfg["x"], view_cfg["y"]
+    acc = OrderedDict()
+    for r in results:
+        if xk not in r["env_grid_search"] or yk not in r["metrics"]:
+            continue
+        acc.setdefault(r["algorithm"], OrderedDict()).setdefault(r["env_grid_search"][xk], []).append(float(r["metrics"][yk]))
+    out = OrderedDict()
+    for algo, by_x in acc.items():
+        pts = []
+        for x in sorted(by_x):
+            v = np.asarray(by_x[x], dtype=np.float64)
+            half = 1.96 * v.std(ddof=1) / np.sqrt(len(v)) if len(v) > 1 else 0.0
+            pts.append((x, float(v.mean()), float(v.mean() - half), float(v.mean() + half), len(v)))
+        out[algo] = pts
+    return out
+
+
+def plot_view(results, view_cfg, path):
+    """`type: plot` of results_views: one line per algorithm, metric `y` against grid key `x` with the interval band;
+    honours width/height (inches), line_width, use_log_scale_x, ticks, font_size, legend_font_size, name (title).
+    Writes `path` (format by extension) and returns the plotted series."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    series = plot_series(results, view_cfg)
+    fs = view_cfg.get("font_size", 8)
+    fig, ax = plt.subplots(figsize=(float(view_cfg.get("width", 3.0)), float(view_cfg.get("height", 2.5))))
+    for algo, pts in series.items():
+        xs = [p[0] for p in pts]
+        line, = ax.plot(xs, [p[1] for p in pts], marker="o", markersize=3, linewidth=float(view_cfg.get("line_width", 2)), label=algo)
+        ax.fill_between(xs, [p[2] for p in pts], [p[3] for p in pts], alpha=0.2, color=line.get_color(), linewidth=0)
+    if view_cfg.get("use_log_scale_x", False):
+        ax.set_xscale("log")
+    if view_cfg.get("use_log_scale_y", False):
+        ax.set_yscale("log")
+    if view_cfg.get("ticks"):
+        ax.set_xticks(list(view_cfg["ticks"]))
+        ax.set_xticklabels([str(t) for t in view_cfg["ticks"]])
+        ax.minorticks_off()
+    ax.set_xlabel(str(view_cfg["x"]), fontsize=fs)
+    ax.set_ylabel(str(view_cfg["y"]), fontsize=fs)
+    ax.tick_params(labelsize=fs)
+    if view_cfg.get("name"):
+        ax.set_title(str(view_cfg["name"]), fontsize=fs)
+    if series:
+        ax.legend(fontsize=view_cfg.get("legend_font_size", fs))
+    ax.grid(True, alpha=0.3)
+    fig.tight_layout()
+    fig.savefig(path)
+    plt.close(fig)
+    return series
+
+
 # ---- the batched evaluation (GPU) -----------------------------------------------------------------
 def _build_algorithm(algo_cfg, max_rows):
     from .inference import MAPFGPTInference, MAPFGPTInferenceConfig
@@ -202,7 +259,8 @@ def evaluation(evaluation_config, eval_dir=None, registry=None, precision=None, 
             if view.get("type") == "tabular":
                 print_fn(f"== {view_name}")
                 tabular_view(results, view, print_fn)
-            # `type: plot` views need matplotlib; the saved JSON has everything a plot needs
+            elif view.get("type") == "plot" and eval_dir is not None:
+                plot_view(results, view, os.path.join(eval_dir, f"{view_name}.pdf"))
     return results
 
 

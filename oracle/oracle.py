@@ -120,3 +120,24 @@ def env_step(grid, pos, goal, actions):
     gl, a = _i32(goal).reshape(-1, 2), _i32(actions)
     k = lib().orc_env_step(g.ctypes.data, H, W, p.shape[0], p.ctypes.data, gl.ctypes.data, a.ctypes.data)
     return p, int(k)
+
+
+def agents_density(grid, pos, radius=5):
+    """One sample of POGEMA's AgentsDensityWrapper (wired in at experiment_setup/create_env.py:38,49; the wrapper itself
+    lives in the un-vendored `pogema` pip dependency, so this is a restatement of its published behaviour: PARITY
+    UNPINNED).  Per agent: non-zero cells of its obs["agents"] window (itself included) / traversable cells of its
+    obs["obstacles"] window ((2r+1)^2, the map padded with obstacles); the sample is the mean over agents.  The episode
+    metric `avg_agents_density` is the mean of the samples taken at reset and after every step."""
+    g = np.asarray(grid) != 0
+    H, W = g.shape
+    pad = np.ones((H + 2 * radius, W + 2 * radius), bool)
+    pad[radius:radius + H, radius:radius + W] = g
+    occ = np.zeros_like(pad, dtype=bool)
+    p = np.asarray(pos).reshape(-1, 2).astype(np.int64)
+    occ[p[:, 0] + radius, p[:, 1] + radius] = True
+    vals = []
+    for r, c in p:
+        wo = pad[r:r + 2 * radius + 1, c:c + 2 * radius + 1]
+        wa = occ[r:r + 2 * radius + 1, c:c + 2 * radius + 1]
+        vals.append(np.count_nonzero(wa) / (wo.size - np.count_nonzero(wo)))
+    return float(np.mean(vals))

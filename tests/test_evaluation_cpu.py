@@ -56,3 +56,23 @@ def test_tabular_view_drops_and_averages():
     assert [t["num_agents"] for t in table] == [8, 16]
     assert table[0]["CSR"] == 0.5 and table[1]["SoC"] == 160.0 and "runtime" not in table[0]
     assert len(lines) == 3 and lines[0].split()[:2] == ["num_agents", "algorithm"]
+
+
+def test_plot_view_series_and_file(tmp_path):
+    """`type: plot` (eval_configs/01-random/01-random.yaml:162-186): mean of y per x and algorithm over seeds/maps."""
+    res = []
+    for algo, base in (("A", 10.0), ("B", 20.0)):
+        for n in (8, 16, 32):
+            for seed in (0, 1, 2, 3):
+                res.append({"metrics": {"SoC": base * n + seed, "CSR": 1.0}, "env_grid_search": {"seed": seed, "num_agents": n, "map_name": "m"},
+                            "algorithm": algo})
+    view = {"type": "plot", "x": "num_agents", "y": "SoC", "width": 3.0, "height": 2.5, "line_width": 2, "use_log_scale_x": True,
+            "legend_font_size": 8, "font_size": 8, "name": "Random / Mazes", "ticks": [8, 16, 32]}
+    series = ev.plot_series(res, view)
+    assert list(series) == ["A", "B"] and [p[0] for p in series["A"]] == [8, 16, 32]
+    x, mean, lo, hi, n = series["B"][1]
+    assert n == 4 and mean == 20.0 * 16 + 1.5 and lo < mean < hi
+    assert np.isclose(hi - mean, 1.96 * np.std([0, 1, 2, 3], ddof=1) / 2)
+    out = tmp_path / "v.pdf"
+    assert ev.plot_view(res, view, str(out)) == series
+    assert out.stat().st_size > 1000

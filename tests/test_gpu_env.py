@@ -21,6 +21,8 @@ def test_env_step_matches_spec_and_invariants(name, n_agents, n_inst):
     p = pos.numpy().astype(np.int32).copy()
     g = goal.numpy().astype(np.int32)
     rng = np.random.Generator(np.random.PCG64(11))
+    dens = [[orc.agents_density(grid, p[i])] for i in range(n_inst)]          # the reset observation's sample
+    was_done = np.zeros(n_inst, bool)
     for t in range(40):
         act = rng.integers(0, 5, (n_inst, n_agents)).astype(np.int32)
         if t % 3 == 0:       # provoke swaps and chains: everybody pushes the same way
@@ -40,8 +42,12 @@ def test_env_step_matches_spec_and_invariants(name, n_agents, n_inst):
                 b = old.get(tuple(exp[a]))
                 if b is not None and b != a:
                     assert tuple(exp[b]) != tuple(p[i][a]), "edge swap"
+            if not was_done[i]:                                # the step that ends the episode still samples
+                dens[i].append(orc.agents_density(grid, exp))
             p[i] = exp
+        was_done = done.cpu().numpy() != 0
     m = env.metrics().cpu().numpy()
+    assert np.allclose(m[:, 5], [np.mean(d) for d in dens], rtol=1e-6, atol=0), "avg_agents_density"
     assert (m[:, 4] == 40).all() or (env.done.cpu().numpy() == 1).any()
     on = (p == g).all(2)
     assert np.allclose(m[:, 1], on.mean(1))
@@ -61,7 +67,7 @@ def test_grid_env_list_api_shape():
     for t in range(5):
         obs, rew, term, trunc, infos = env.step([0] * 8)
         assert len(rew) == len(term) == len(trunc) == len(infos) == 8
-    assert all(trunc) and set(infos[0]["metrics"]) == {"CSR", "ISR", "SoC", "makespan", "ep_length"}
+    assert all(trunc) and set(infos[0]["metrics"]) == {"CSR", "ISR", "SoC", "makespan", "ep_length", "avg_agents_density"}
     assert infos[0]["metrics"]["ep_length"] == 5
 
 

@@ -20,7 +20,8 @@ def test_smoke_config_end_to_end(tmp_path):
         assert set(r) == {"metrics", "env_grid_search", "algorithm"}
         assert set(r["env_grid_search"]) == {"seed", "num_agents", "map_name"}
         m = r["metrics"]
-        assert set(m) == {"CSR", "ISR", "SoC", "makespan", "ep_length", "runtime"}
+        assert set(m) == {"CSR", "ISR", "SoC", "makespan", "ep_length", "avg_agents_density", "runtime"}
+        assert 0.0 < m["avg_agents_density"] <= 1.0
         assert 0.0 <= m["ISR"] <= 1.0 and m["CSR"] in (0.0, 1.0) and 0 < m["ep_length"] <= 64
         assert m["makespan"] <= m["ep_length"] and m["SoC"] <= r["env_grid_search"]["num_agents"] * m["ep_length"]
     assert lines[0] == "== TabularView1" and lines[1].split()[:2] == ["num_agents", "algorithm"]
