@@ -186,6 +186,26 @@ def cpu_baseline(map_name, n_agents, model, budget_s=10.0):
             "reference_tokenizer_us_per_agent": ref_tok}
 
 
+def stream_floor_ms(total_bytes, dev, reps=20):
+    """What a launch moving the SAME number of bytes costs with nothing to compute: a device copy of total_bytes / 2 (reads
+    half, writes half), torch.cuda events on the current stream.  At cfg4's 45 MB per launch this is what separates "the
+    kernel is slow" from "a 20 us launch cannot reach the 8 TB/s plateau" (ramp-up and tail of the grid)."""
+    n = int(total_bytes // 2)
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(reps):
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
 def tokenizer_large_launch(grid, s_ok, g_ok, n_agents, local_rank, target_rows=524288, reps=20):
     """the tokenizer's HBM roofline is to be read on launches of >= 1e5 rows (cfg4/5-sized per-GPU shards), not on
     cfg2's 16 384 rows.  Same map and agent count as the workload, instances replicated up to ~5e5 rows, HIP-event timing
@@ -221,8 +241,10 @@ def tokenizer_large_launch(grid, s_ok, g_ok, n_agents, local_rank, target_rows=5
     del tok, out
     torch.cuda.empty_cache()
     traffic = traffic_for(f"tok_generate_observations_{rows}_rows")
+    floor = stream_floor_ms(TOKENIZER_BYTES_PER_ROW * rows, dev)
     return {"kernel": "tok_generate_observations", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows,
+            "same_bytes_copy_ms": floor, "frac_of_same_bytes_copy": floor / (ms / n),
             "algorithmic_bytes_per_row": TOKENIZER_BYTES_PER_ROW,
             "note": "694 B/row = SURVEY 8d (u16 window 242 + own record 14 + 13 neighbour records 182 + uint8 row 256); the kernel "
                     "itself reads one-byte fields when every distance fits (573 B/row by its own layout)"}
@@ -270,9 +292,11 @@ def tokenizer_cfg4_launch(local_rank, reps=20):
     ach = TOKENIZER_BYTES_PER_ROW * rows / (ms / n * 1e-3) / 1e9
     del tok, out
     torch.cuda.empty_cache()
+    floor = stream_floor_ms(TOKENIZER_BYTES_PER_ROW * rows, dev)
     return {"kernel": "tok_generate_observations", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": ach / PEAK_HBM_GBS, "traffic": traffic_for(f"cfg4_tok_generate_observations_{rows}_rows"),
             "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows, "algorithmic_bytes_per_row": TOKENIZER_BYTES_PER_ROW,
+            "same_bytes_copy_ms": floor, "frac_of_same_bytes_copy": floor / (ms / n),
             "note": "cfg4 per-GPU shard: 512 instances x 128 agents on per-instance 50 x 50 padded maps"}
 
 
@@ -454,7 +478,7 @@ def main():
                                              "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows,
                                              "note": "the workload's own launch (latency-bound when rows_per_launch < 1e5)"}
             out["kernel_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-        if world == 1 and use_prof and not a.no_tokenizer_leg:
+        if world == 1 and not a.no_tokenizer_leg:
             # SURVEY 8d asks for the tokenizer's HBM roofline on >= 1e5-row launches: cfg4's own per-GPU launch (65 536 rows on
             # per-instance maps, 128 agents: the KP = 2 path) is the headline tokenizer figure; the 524 288-row leg is secondary
             out["roofline_tokenizer_cfg4_shard"] = tokenizer_cfg4_launch(local_rank)
