@@ -13,7 +13,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
 for r in rows:
-    k = (r["Kernel_Name"].split("(")[0][-60:] + " grid=" + r.get("Grid_Size", "?"))[:78]      # launches of different sizes stay apart
+    k = (r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:] + " grid=" + r.get("Grid_Size", "?"))[:78]      # launches of different sizes stay apart
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
 names = sorted({r["Counter_Name"] for r in rows})
 print("# rocprofv3 --pmc %s --kernel-trace -- %s" % (sys.argv[2], sys.argv[3]))
