@@ -97,7 +97,8 @@ int mgpt_tokenizer_generate_observations(mgpt_tokenizer *tok, uint8_t *d_tokens,
 
 /* test/debug read-backs (device pointers into the context's state, valid until destroy):
  * distance fields uint16 [n_inst, n_agents, H, W]; agent records 16 B each
- * {int16 pos_r,pos_c,goal_r,goal_c; uint8 hist[5]; uint8 next; uint8 pad[2]}. */
+ * {int16 pos_r,pos_c,goal_r,goal_c; uint8 hist[5]; uint8 next; uint8 org[2]}, org = origin (row / 64, col / 64) of the
+ * partial cost-to-go window the reference would hold for the agent (observation_generator.cpp:204-207, 469-477). */
 int mgpt_tokenizer_state(mgpt_tokenizer *tok, const uint16_t **d_dist, const void **d_records);
 /* same state copied into caller-owned device buffers (either may be NULL) */
 int mgpt_tokenizer_copy_state(mgpt_tokenizer *tok, uint16_t *d_dist_out, void *d_records_out, void *stream);
@@ -227,6 +228,13 @@ typedef struct mgpt_dataset mgpt_dataset;
 int mgpt_dataset_create(mgpt_dataset **out, const uint8_t *d_grid, int H, int W, void *stream);
 int mgpt_dataset_destroy(mgpt_dataset *ds);
 int mgpt_dataset_tokenize(mgpt_dataset *ds, int n_agents, int n_steps, const int16_t *d_paths, uint8_t *d_tokens, void *stream);
+/* the same with the two options of the reference's generator:
+ *   d_goals  int16 [n_agents][n_steps][2] or NULL: lifelong logs (generate_observations.py:55-60,143-153) -- the goal every
+ *            agent pursued at every timestep (relative goal + greedy-direction bits of its records); the cost-to-go window
+ *            stays that of the path's last cell, as in the reference (:75-78);
+ *   only_obstacles != 0: the mask_cost2go ablation (cost2go.cpp:52-62) -- window cells become the integers 0 / 1 (blocked). */
+int mgpt_dataset_tokenize_ex(mgpt_dataset *ds, int n_agents, int n_steps, const int16_t *d_paths, const int16_t *d_goals,
+                             int only_obstacles, uint8_t *d_tokens, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel timing hooks (bench.py's live roofline): when enabled, the library brackets every kernel

@@ -60,6 +60,7 @@ SYMBOLS = {
     "mgpt_dataset_create": (_i, [_pp, _vp, _i, _i, _vp]),
     "mgpt_dataset_destroy": (_i, [_vp]),
     "mgpt_dataset_tokenize": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "mgpt_dataset_tokenize_ex": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "mgpt_gpt_create": (_i, [_pp, _i, _i, _i, _i, _i]),
     "mgpt_gpt_destroy": (_i, [_vp]),
     "mgpt_gpt_set_param": (_i, [_vp, ctypes.c_char_p, _vp, _i64, _i]),

@@ -25,7 +25,7 @@ struct __attribute__((aligned(16))) AgentRec {
     int16_t pr, pc, gr, gc;
     uint8_t hist[5];
     uint8_t next;
-    uint8_t pad[2];
+    uint8_t org[2];     // origin (row / 64, col / 64) of the reference's cached partial window for this agent (cpp:204-207)
 };
 static_assert(sizeof(AgentRec) == 16, "AgentRec must be 16 bytes");
 
@@ -36,12 +36,19 @@ constexpr int kR = 5;               // obs_radius == agents_radius == 5 (inferen
 constexpr int kWin = 2 * kR + 1;    // 11
 constexpr int kLimit = 20;          // cost2go_value_limit (inference.py:17)
 constexpr int kSlots = 13;          // num_agents (inference.py:15)
+constexpr int kStep = 64;           // grid_step (inference.py:28)
 constexpr int TOK_UNREACH = 41, TOK_NEG = 42, TOK_POS = 43, TOK_N = 44, TOK_BITS0 = 50, TOK_PAD = 66;
 
 // ---------------------------------------------------------------------------------------------
 // Distance field.  The reference's tiled / border-table / priority-queue construction (cpp:43-286)
 // equals the plain 4-connected BFS distance from the goal (SURVEY.md finding 4, re-verified by
-// tests/test_oracle_vs_reference.py).  Here: chaotic min-plus relaxation, d[i] <- min(d[i], min_nb+1),
+// tests/test_oracle_vs_reference.py) -- except for ONE cell per cached partial window: get_cells_on_border (cpp:178-198)
+// seeds every border cell of the agent's 129 x 129 window but its (right, bottom) corner, which the flood fill then reaches
+// from its two in-window neighbours only (value min + 1, e.g. 2 too large when the goal lies beyond the corner).  The cell is
+// in view only from (left + 123, top + 123), reached without a recompute (cpp:469-477).  The window origin is therefore kept
+// per agent (AgentRec::org, maintained by create / update exactly as the reference maintains its partials) and
+// tokens_kernel patches that one window cell; the distance fields themselves stay plain BFS.  tests/golden/tok_corner_*.npz.
+// Here: chaotic min-plus relaxation, d[i] <- min(d[i], min_nb+1),
 // until a full sweep changes nothing.  Every value ever stored is the length of a real path, the
 // update is monotone, so the fixpoint is the exact shortest distance regardless of thread order.
 // `d` lives in LDS when the map fits (<= 32768 cells), else directly in the output buffer.
@@ -113,6 +120,13 @@ __device__ __forceinline__ int next_action_token(const uint16_t *__restrict__ d,
     return TOK_BITS0 + 8 * (u < cur) + 4 * (dn < cur) + 2 * (l < cur) + (rt < cur);
 }
 
+// origin of the partial window the reference computes for an agent standing at (pr, pc), cpp:204-207 (H, W <= 16384: a byte each)
+__device__ __forceinline__ void window_origin(AgentRec &r)
+{
+    r.org[0] = (uint8_t)(max(r.pr - kR, 0) / kStep);
+    r.org[1] = (uint8_t)(max(r.pc - kR, 0) / kStep);
+}
+
 // create_agents, cpp:391-410 (history <- "n" x 5)
 __global__ __launch_bounds__(256) void tok_create_kernel(AgentRec *__restrict__ recs, const int16_t *__restrict__ pos,
                                                          const int16_t *__restrict__ goal, int total,
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(256) void tok_create_kernel(AgentRec *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 5; k++) r.hist[k] = TOK_N;
     r.next = TOK_BITS0;
-    r.pad[0] = r.pad[1] = 0;
+    window_origin(r);                                                                               // cpp:408
     recs[i] = r;
 }
 
@@ -146,11 +160,20 @@ __global__ __launch_bounds__(256) void tok_update_kernel(AgentRec *__restrict__ 
     const int act = actions[i];
     r.hist[0] = r.hist[1]; r.hist[1] = r.hist[2]; r.hist[2] = r.hist[3]; r.hist[3] = r.hist[4];   // cpp:463
     r.hist[4] = (uint8_t)((act >= 0 && act <= 4) ? TOK_N + 1 + act : TOK_N);                        // cpp:442-462
+    bool moved_goal = false;
     if (check_goals) {
         const int16_t gr = goal[2 * i], gc = goal[2 * i + 1];
-        dirty[i] = (gr != r.gr || gc != r.gc) ? 1 : 0;                                              // cpp:464-468
+        moved_goal = gr != r.gr || gc != r.gc;
+        dirty[i] = moved_goal ? 1 : 0;                                                              // cpp:464-468
         r.gr = gr; r.gc = gc;
-    } else {
+    }
+    {   // cpp:464-477: the partial window is recomputed around the new position on a goal change or when the observation
+        // window leaves it; only its origin matters here (it decides which cell is the unseeded corner)
+        const int left = kStep * r.org[0], top = kStep * r.org[1];
+        const int right = min(left + 2 * kStep, H - 1), bottom = min(top + 2 * kStep, W - 1);
+        if (moved_goal || r.pr - kR < left || r.pr + kR > right || r.pc - kR < top || r.pc + kR > bottom) window_origin(r);
+    }
+    if (!check_goals) {
         r.next = (uint8_t)next_action_token(dist + (size_t)i * H * W, H, W, r.pr, r.pc);            // cpp:483-484
     }
     recs[i] = r;
@@ -259,10 +282,14 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
         const int a = a_begin + tid;
         int4 h = make_int4(0, 0, -1, 0);                 // state -1: no such agent
         if (a < n_agents) {
-            const uint32_t my0 = grec[a].x;
+            const uint4 me = grec[a];
+            const uint32_t my0 = me.x;
             const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
             const bool inside = pr >= kR && pr + kR < H && pc >= kR && pc + kR < W;   // whole window inside the frame
-            h = make_int4((int)my0, pr * W + pc, inside ? 1 : 0, 0);
+            // is the unseeded corner of the agent's cached partial window (cpp:178-198) the window cell (10, 10)?
+            const int cr = kStep * (int)((me.w >> 16) & 0xffu) + 2 * kStep, cc = kStep * (int)(me.w >> 24) + 2 * kStep;
+            const bool corner = cr <= H - 1 && cc <= W - 1 && pr + kR == cr && pc + kR == cc;
+            h = make_int4((int)my0, pr * W + pc, inside ? 1 : 0, corner ? 1 : 0);
         }
         hdr[tid] = h;
     }
@@ -303,6 +330,13 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
         if (st > 0) {                                                   // wave-uniform; always taken for env states
             w0[q] = (int)d[(uint32_t)(centre + off0)];
             w1[q] = (int)d[(uint32_t)(centre + off1)];
+            if (__builtin_amdgcn_readfirstlane(h.w) != 0 && lane == kWin * kWin - 1 - 64) {
+                // rare (agent at offset (123, 123) of its cached window): the reference reaches this cell only from its two
+                // in-window neighbours, whose values are exact border seeds (cpp:252-268)
+                const int n1 = (int)d[(uint32_t)(centre + off1 - W)], n2 = (int)d[(uint32_t)(centre + off1 - 1)];
+                const int m = min(n1, n2);
+                if (w1[q] != UNR && w1[q] != 0) w1[q] = (m == UNR) ? UNR : m + 1;
+            }
         } else if (st == 0) {                                           // out-of-frame cells read as walls
             const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
             const int rr0 = pr - kR + i0, cc0 = pc - kR + j0, rr1 = pr - kR + i1, cc1 = pc - kR + j1;
@@ -487,7 +521,10 @@ __global__ __launch_bounds__(256) void ds_sources_kernel(AgentRec *__restrict__ 
 }
 
 // paths int16 [n_agents][n_steps][2] -> recs [n_steps][n_agents]
-__global__ __launch_bounds__(256) void ds_records_kernel(const int16_t *__restrict__ paths, int n_agents, int n_steps, int H, int W,
+// goals (lifelong logs, generate_observations.py:55-60,143-153): the goal each agent pursued at every timestep, same shape
+// as paths; NULL = the path's last cell.
+__global__ __launch_bounds__(256) void ds_records_kernel(const int16_t *__restrict__ paths, const int16_t *__restrict__ goals,
+                                                         int n_agents, int n_steps, int H, int W,
                                                          const uint16_t *__restrict__ allpairs, AgentRec *__restrict__ recs)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -496,7 +533,11 @@ __global__ __launch_bounds__(256) void ds_records_kernel(const int16_t *__restri
     const int16_t *p = paths + (size_t)a * n_steps * 2;
     AgentRec r;
     r.pr = p[2 * t]; r.pc = p[2 * t + 1];
-    r.gr = p[2 * (n_steps - 1)]; r.gc = p[2 * (n_steps - 1) + 1];                  // generate_observations.py:199
+    if (goals != nullptr) {                                                         // generate_observations.py:196-197
+        r.gr = goals[((size_t)a * n_steps + t) * 2]; r.gc = goals[((size_t)a * n_steps + t) * 2 + 1];
+    } else {
+        r.gr = p[2 * (n_steps - 1)]; r.gc = p[2 * (n_steps - 1) + 1];              // generate_observations.py:199
+    }
 #pragma unroll
     for (int s = 0; s < 5; s++) {                                                   // slot s <-> move index i = t - 4 + s
         const int m = t - 4 + s;
@@ -514,7 +555,7 @@ __global__ __launch_bounds__(256) void ds_records_kernel(const int16_t *__restri
     const int cells = H * W;
     const bool gok = r.gr >= 0 && r.gr < H && r.gc >= 0 && r.gc < W;
     r.next = (uint8_t)(gok ? next_action_token(allpairs + (size_t)(r.gr * W + r.gc) * cells, H, W, r.pr, r.pc) : TOK_BITS0);   // :230-243
-    r.pad[0] = r.pad[1] = 0;
+    r.org[0] = r.org[1] = 0;
     recs[i] = r;
 }
 
@@ -529,7 +570,10 @@ __device__ __forceinline__ int window_token(int v, int mid)
     return w > kLimit ? TOK_POS : (w < -kLimit ? TOK_NEG : w + kLimit);
 }
 
+// The window is cut from the field of the PATH'S LAST CELL (generate_observations.py:75-78) -- in lifelong logs that is not
+// the goal the record carries; only_obstacles = the mask_cost2go ablation (cost2go.cpp:52-62: cell -> 0 / 1 = blocked).
 __global__ __launch_bounds__(256) void ds_tokens_kernel(const AgentRec *__restrict__ recs, const uint16_t *__restrict__ allpairs,
+                                                        const int16_t *__restrict__ paths, int only_obstacles,
                                                         int n_agents, int n_steps, int H, int W, int chunks_per_step,
                                                         uint8_t *__restrict__ tokens)
 {
@@ -550,7 +594,8 @@ __global__ __launch_bounds__(256) void ds_tokens_kernel(const AgentRec *__restri
         if (a >= n_agents) break;                                                         // wave-uniform
         const uint4 me = srec[a];
         const int pr = (int16_t)(me.x & 0xffffu), pc = (int16_t)(me.x >> 16);
-        const int gr = (int16_t)(me.y & 0xffffu), gc = (int16_t)(me.y >> 16);
+        const int16_t *pend = paths + ((size_t)a * n_steps + (n_steps - 1)) * 2;
+        const int gr = pend[0], gc = pend[1];
         const bool gok = gr >= 0 && gr < H && gc >= 0 && gc < W;
         const uint16_t *dg = allpairs + (size_t)(gok ? gr * W + gc : 0) * cells;          // distance-to-goal field = a table row
         const uint16_t *dm = allpairs + (size_t)(pr * W + pc) * cells;                    // distances from my own cell
@@ -590,8 +635,13 @@ __global__ __launch_bounds__(256) void ds_tokens_kernel(const AgentRec *__restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        row[1 + lane] = (uint8_t)window_token(v[0], mid);
-        if (lane + 64 < kWin * kWin) row[65 + lane] = (uint8_t)window_token(v[1], mid);
+        if (only_obstacles) {                                                             // tokens of the integers 1 / 0
+            row[1 + lane] = (uint8_t)(kLimit + (v[0] == kUnreach ? 1 : 0));
+            if (lane + 64 < kWin * kWin) row[65 + lane] = (uint8_t)(kLimit + (v[1] == kUnreach ? 1 : 0));
+        } else {
+            row[1 + lane] = (uint8_t)window_token(v[0], mid);
+            if (lane + 64 < kWin * kWin) row[65 + lane] = (uint8_t)window_token(v[1], mid);
+        }
         for (int c = lane; c < cnt; c += 64) {
             const uint32_t key = cand[c];
             int rank = 0;
@@ -850,6 +900,12 @@ extern "C" int mgpt_dataset_destroy(mgpt_dataset *d)
 
 extern "C" int mgpt_dataset_tokenize(mgpt_dataset *d, int n_agents, int n_steps, const int16_t *d_paths, uint8_t *d_tokens, void *stream)
 {
+    return mgpt_dataset_tokenize_ex(d, n_agents, n_steps, d_paths, nullptr, 0, d_tokens, stream);
+}
+
+extern "C" int mgpt_dataset_tokenize_ex(mgpt_dataset *d, int n_agents, int n_steps, const int16_t *d_paths, const int16_t *d_goals,
+                                        int only_obstacles, uint8_t *d_tokens, void *stream)
+{
     MGPT_REQUIRE(d && d_paths && d_tokens, MGPT_ERR_ARG, "NULL argument");
     MGPT_REQUIRE(n_agents > 0 && n_agents <= 2048 && n_steps > 0, MGPT_ERR_ARG, "n_agents=%d n_steps=%d", n_agents, n_steps);
     hipStream_t s = (hipStream_t)stream;
@@ -863,15 +919,15 @@ extern "C" int mgpt_dataset_tokenize(mgpt_dataset *d, int n_agents, int n_steps,
     }
     {
         ProfScope ps(P_TOK_UPDATE, s);
-        hipLaunchKernelGGL(ds_records_kernel, dim3(cdiv((int)total, 256)), dim3(256), 0, s, d_paths, n_agents, n_steps, d->H, d->W,
+        hipLaunchKernelGGL(ds_records_kernel, dim3(cdiv((int)total, 256)), dim3(256), 0, s, d_paths, d_goals, n_agents, n_steps, d->H, d->W,
                            d->allpairs, d->recs);
         MGPT_LAUNCH_CHECK();
     }
     const int chunks = cdiv(n_agents, kDsAgentsPerBlock);
     const size_t smem = (size_t)n_agents * 16 + 4 * kDsMaxCand * 4 + 4 * 272;
     ProfScope ps(P_TOKENS, s);
-    hipLaunchKernelGGL(ds_tokens_kernel, dim3(n_steps * chunks), dim3(256), smem, s, d->recs, d->allpairs, n_agents, n_steps, d->H,
-                       d->W, chunks, d_tokens);
+    hipLaunchKernelGGL(ds_tokens_kernel, dim3(n_steps * chunks), dim3(256), smem, s, d->recs, d->allpairs, d_paths, only_obstacles ? 1 : 0,
+                       n_agents, n_steps, d->H, d->W, chunks, d_tokens);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }

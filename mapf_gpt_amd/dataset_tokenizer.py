@@ -8,7 +8,10 @@
 `data[i]` = {"metrics": {"CSR", "made_actions", "init_positions"}, "env_grid_search": {"map_name"}} (the
 toolbox's result records, generate_observations.py:43-66).  Instances with CSR < 1 are skipped (:44-45); the
 all-pairs distance table of a map is built once and reused while consecutive instances share the map (:46-54).
-Not supported: lifelong logs ("global_lifelong_targets_xy", :55-60), the mask_* options, cost2go_radius != 5.
+Lifelong logs ("global_lifelong_targets_xy", :55-60, 143-153) and the `mask_cost2go` ablation (:253-262) are handled on the
+device like the rest; the other three mask_* fields are carried by `InputParameters` but, as in the reference's dataset
+pipeline (whose C++ encoder ignores them), only the python `Encoder.mask` applies them (tokenizer.py:104-138).
+Not supported: cost2go_radius != 5.
 """
 import ctypes
 
@@ -27,8 +30,8 @@ class InputParameters:
                  context_size=256, mask_greed_action=False, mask_actions_history=False, mask_goal=False, mask_cost2go=False):
         if (num_agents, num_previous_actions, agents_radius, cost2go_value_limit, cost2go_radius, context_size) != (13, 5, 5, 20, 5, 256):
             raise NotImplementedError("only the reference's defaults (13, 5, 5, 20, 5, 256) are implemented")
-        if mask_greed_action or mask_actions_history or mask_goal or mask_cost2go:
-            raise NotImplementedError("mask_* options are not implemented")
+        self.mask_greed_action, self.mask_actions_history = bool(mask_greed_action), bool(mask_actions_history)
+        self.mask_goal, self.mask_cost2go = bool(mask_goal), bool(mask_cost2go)
         self.num_agents, self.num_previous_actions, self.agents_radius = num_agents, num_previous_actions, agents_radius
         self.cost2go_value_limit, self.cost2go_radius, self.context_size = cost2go_value_limit, cost2go_radius, context_size
 
@@ -54,13 +57,20 @@ class MapTable:
                 pass
             self._h = None
 
-    def tokenize(self, paths):
-        """paths int16 [n_agents, n_steps, 2] (padded coords) -> uint8 device tensor [n_agents, n_steps, 256]."""
+    def tokenize(self, paths, goals=None, mask_cost2go=False):
+        """paths int16 [n_agents, n_steps, 2] (padded coords) -> uint8 device tensor [n_agents, n_steps, 256].
+        goals (lifelong logs): int16 [n_agents, n_steps, 2], the goal pursued at every timestep; mask_cost2go: the
+        window shows blocked / free only (cost2go.cpp:52-62)."""
         p = torch.as_tensor(np.ascontiguousarray(paths, dtype=np.int16)).to(self.device)
         n, T1 = int(p.shape[0]), int(p.shape[1])
+        g = None
+        if goals is not None:
+            g = torch.as_tensor(np.ascontiguousarray(goals, dtype=np.int16)).to(self.device)
+            assert tuple(g.shape) == (n, T1, 2), "goals must have the shape of paths"
         out = torch.empty((n, T1, 256), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().mgpt_dataset_tokenize(self._h, n, T1, _lib.ptr(p), _lib.ptr(out), _lib.stream_ptr()))
+            _lib.check(_lib.lib().mgpt_dataset_tokenize_ex(self._h, n, T1, _lib.ptr(p), _lib.ptr(g) if g is not None else None,
+                                                           1 if mask_cost2go else 0, _lib.ptr(out), _lib.stream_ptr()))
         return out
 
 
@@ -70,6 +80,20 @@ def agent_paths(init_positions, made_actions):
     steps = MOVES[acts]                                                 # [n, T, 2]
     p0 = np.asarray(init_positions, dtype=np.int32)[:, None, :]
     return np.concatenate([p0, p0 + np.cumsum(steps, axis=1)], axis=1)
+
+
+def goal_positions(paths, targets):
+    """= get_goal_positions (:143-153): the goal at every path cell = the first target of the agent's list it has not stood
+    on yet (standing on it advances the list before the cell's goal is read).  -> int32 [n, T+1, 2].
+    Like the reference, a path that exhausts its list raises IndexError."""
+    out = np.empty_like(np.asarray(paths, dtype=np.int32))
+    for a, (path, tg) in enumerate(zip(paths, targets)):
+        cur = 0
+        for t, pos in enumerate(path):
+            if int(pos[0]) == int(tg[cur][0]) and int(pos[1]) == int(tg[cur][1]):
+                cur += 1
+            out[a, t] = (int(tg[cur][0]), int(tg[cur][1]))
+    return out
 
 
 def gt_actions(made_actions):
@@ -106,13 +130,14 @@ class ObservationGenerator:
             rec = self.data[instance_id]
             if rec["metrics"].get("CSR", 1) < 1:                        # :44-45
                 continue
-            if "global_lifelong_targets_xy" in rec["metrics"]:
-                raise NotImplementedError("lifelong logs are not supported by the device tokenizer")
             name = rec["env_grid_search"]["map_name"]
             if name != self._table_name:                                # :46-54
                 self._table, self._table_name = MapTable(self.get_grid_map(name), self.device), name
             paths = agent_paths(rec["metrics"]["init_positions"], rec["metrics"]["made_actions"])
-            toks = self._table.tokenize(paths).cpu().numpy().astype(np.int8).reshape(-1, 256)
+            goals = None
+            if "global_lifelong_targets_xy" in rec["metrics"]:          # :55-60
+                goals = goal_positions(paths, rec["metrics"]["global_lifelong_targets_xy"])
+            toks = self._table.tokenize(paths, goals, self.cfg.mask_cost2go).cpu().numpy().astype(np.int8).reshape(-1, 256)
             self.inputs.extend(list(toks))
             for g in gt_actions(rec["metrics"]["made_actions"]):
                 self.gt_actions.extend(g)
@@ -122,7 +147,8 @@ class ObservationGenerator:
 class Encoder:
     """Host-side vocabulary helper with the interface of the reference's python `Encoder` (dataset/tokenizer/tokenizer.py:30-185):
     `encode(observation dict) -> list[int]` (positions and goals clamped to +-20, :55-60), `decode(ids) -> observation dict`.
-    Pure Python; useful for inspecting rows produced by the device tokenizers.  The mask_* ablations are not implemented."""
+    `mask(ids)` applies the four mask_* ablations of the config exactly as tokenizer.py:104-138 does (encode and decode call it
+    when any flag is set).  Pure Python; useful for inspecting rows produced by the device tokenizers."""
 
     def __init__(self, cfg=None):
         self.cfg = cfg or InputParameters()
@@ -142,10 +168,40 @@ class Encoder:
                     self.vocab[clamp(a["relative_goal"][0])], self.vocab[clamp(a["relative_goal"][1])]]
             out += [self.vocab[x] for x in a["previous_actions"]] + [self.vocab[a["next_action"]]]
         out += [self.vocab["!"]] * (self.cfg.context_size - len(out))
-        return out
+        return self.mask(out) if self._any_mask() else out
+
+    def _any_mask(self):
+        c = self.cfg
+        return c.mask_actions_history or c.mask_cost2go or c.mask_goal or c.mask_greed_action
+
+    def mask(self, ids):
+        """tokenizer.py:104-138, in place on a list of ids: history slots / goal pair / greedy-bits slot of all 13 records
+        -> '!'; mask_cost2go: every window token that is not the blocked one (-80) -> the token of 0."""
+        c = self.cfg
+        win = (2 * c.cost2go_radius + 1) ** 2
+        per = 5 + c.num_previous_actions
+        pad = self.vocab["!"]
+        if c.mask_actions_history:
+            for i in range(c.num_agents):
+                ids[win + i * per + 4: win + i * per + 4 + c.num_previous_actions] = [pad] * c.num_previous_actions
+        if c.mask_cost2go:
+            free, blocked = self.vocab[0], self.vocab[-c.cost2go_value_limit * 4]
+            for i in range(win):
+                if ids[i] != blocked:
+                    ids[i] = free
+        if c.mask_goal:
+            for i in range(c.num_agents):
+                ids[win + i * per + 2] = pad
+                ids[win + i * per + 3] = pad
+        if c.mask_greed_action:
+            for i in range(c.num_agents):
+                ids[win + i * per + 4 + c.num_previous_actions] = pad
+        return ids
 
     def decode(self, idx):
         idx = [int(i) & 0xff for i in np.asarray(idx).tolist()]
+        if self._any_mask():
+            idx = self.mask(idx)
         side = 2 * self.cfg.cost2go_radius + 1
         per = 4 + self.cfg.num_previous_actions + 1
         agents = []

@@ -7,6 +7,9 @@ It differs from the inference tokenizer (observation_generator.cpp) in three way
   * action history comes from the logged path (executed moves), padded with "n" at the start of an episode and one "w"
     at its last step (:206-229); the goal is the path's last cell (:199);
   * all timesteps of a logged episode are emitted, with the ground-truth action next to every row (:73-90).
+Lifelong logs ("global_lifelong_targets_xy", :55-60, 143-153): the goal of an agent at a timestep is the first target of its
+list it has not stood on yet; the records use it (relative goal, greedy bits) while the cost-to-go window keeps the field
+of the path's LAST cell (:75-78).  mask_cost2go (:253-262, cost2go.cpp:52-62): window cells become 0 / 1 (blocked).
 Token ids and the row layout are the inference tokenizer's (encoder.cpp:52-127).
 """
 import numpy as np
@@ -54,12 +57,27 @@ def agent_paths(init_positions, made_actions):
     return paths
 
 
-def generate_observations(grid, init_positions, made_actions, num_agents=13, npa=5, agents_radius=5, radius=5, limit=20):
+def goal_positions(paths, targets):
+    """= get_goal_positions (:143-153); running past the end of a target list raises IndexError there as well."""
+    out = []
+    for path, tg in zip(paths, targets):
+        cur, gp = 0, []
+        for pos in path:
+            if tuple(pos) == (int(tg[cur][0]), int(tg[cur][1])):
+                cur += 1
+            gp.append((int(tg[cur][0]), int(tg[cur][1])))
+        out.append(gp)
+    return out
+
+
+def generate_observations(grid, init_positions, made_actions, num_agents=13, npa=5, agents_radius=5, radius=5, limit=20,
+                          lifelong_targets=None, mask_cost2go=False):
     """One logged instance -> (inputs int8 [n * (T+1), 256], gt_actions int64 [n * (T+1)]), rows agent-major then time,
     exactly the append order of generate_observations (:73-90)."""
     grid = np.asarray(grid)
     paths = agent_paths(init_positions, made_actions)
     n, L = len(paths), len(paths[0])
+    goals = goal_positions(paths, lifelong_targets) if lifelong_targets is not None else None      # :55-60
     cache = {}
 
     def field(src):
@@ -93,7 +111,9 @@ def generate_observations(grid, init_positions, made_actions, num_agents=13, npa
             for i in range(2 * radius + 1):
                 for jj in range(2 * radius + 1):
                     v = int(dg[me[0] - radius + i, me[1] - radius + jj])
-                    if v >= 0:
+                    if mask_cost2go:                                    # cost2go.cpp:52-62
+                        v = 1 if v < 0 else 0
+                    elif v >= 0:
                         v -= mid
                         v = 2 * limit if v > limit else (-2 * limit if v < -limit else v)
                     else:
@@ -101,7 +121,8 @@ def generate_observations(grid, init_positions, made_actions, num_agents=13, npa
                     toks.append(int_token(v, limit))
             # --- agent records (get_agent_info :179-245, encoder.cpp:88-108) ---
             for _, j in cand[:num_agents]:
-                pj, gj = paths[j][min(t, L - 1)], paths[j][-1]
+                pj = paths[j][min(t, L - 1)]
+                gj = goals[j][min(t, L - 1)] if goals is not None else paths[j][-1]     # :194-199
                 toks += [int_token(pj[0] - me[0], limit), int_token(pj[1] - me[1], limit),
                          int_token(gj[0] - me[0], limit), int_token(gj[1] - me[1], limit)]
                 if t < npa:                                             # :206-214

@@ -35,9 +35,15 @@
 enum { TOK_UNREACH = 41, TOK_NEG = 42, TOK_POS = 43, TOK_N = 44, TOK_BITS0 = 50, TOK_PAD = 66 };
 
 /* cpp:200-286 (+ cpp:134-176 for small grids).  The reference's tiled border/priority-queue
- * machinery yields exactly the 4-connected BFS distance from the goal over free cells and
- * 65535 elsewhere (SURVEY.md finding 4; re-verified in tests/test_oracle_vs_reference.py on
- * >64 grids, where the large-map branch cpp:222-279 is the one that runs). */
+ * machinery yields the 4-connected BFS distance from the goal over free cells and 65535
+ * elsewhere (SURVEY.md finding 4; re-verified in tests/test_oracle_vs_reference.py on
+ * >64 grids, where the large-map branch cpp:222-279 is the one that runs) -- with ONE exception,
+ * restated in orc_gen_generate_observations: the (right, bottom) corner cell of an agent's cached
+ * 129 x 129 partial window is not among the seeded border cells (cpp:178-198: both loops stop one
+ * short of it), so the flood fill gives it min(in-window neighbours) + 1.  It is visible only from
+ * (left + 123, top + 123), reached without a recompute (cpp:469-477); the window origin is
+ * therefore part of the agent state here (`org`).  Pinned by tests/golden/tok_corner_*.npz. */
+#define ORC_STEP 64       /* inf:28 grid_step */
 void orc_bfs(const uint8_t *grid, int H, int W, int gr, int gc, uint16_t *dist)
 {
     int n = H * W;
@@ -86,6 +92,7 @@ typedef struct {
     uint8_t *hist;      /* n*5 tokens, oldest -> newest */
     uint8_t *next;      /* n */
     uint16_t *dist;     /* n*H*W */
+    int32_t *org;       /* n*2: (left_border, top_border) of the agent's cached partial window, cpp:204-207 */
 } orc_gen;
 
 orc_gen *orc_gen_create(const uint8_t *grid, int H, int W)
@@ -103,14 +110,22 @@ void orc_gen_destroy(orc_gen *g)
 {
     if (!g) return;
     free(g->grid); free(g->occ); free(g->pos); free(g->goal);
-    free(g->hist); free(g->next); free(g->dist); free(g);
+    free(g->hist); free(g->next); free(g->dist); free(g->org); free(g);
+}
+
+/* cpp:204-207: origin of the partial window computed for an agent standing at (r, c) */
+static void window_origin(int r, int c, int32_t *org)
+{
+    org[0] = (r - ORC_R > 0 ? r - ORC_R : 0) / ORC_STEP * ORC_STEP;
+    org[1] = (c - ORC_R > 0 ? c - ORC_R : 0) / ORC_STEP * ORC_STEP;
 }
 
 /* cpp:391-410: history = "n" x5, distance field, greedy bits.  Does NOT touch agents_locations. */
 void orc_gen_create_agents(orc_gen *g, int n, const int32_t *pos, const int32_t *goal)
 {
-    free(g->pos); free(g->goal); free(g->hist); free(g->next); free(g->dist);
+    free(g->pos); free(g->goal); free(g->hist); free(g->next); free(g->dist); free(g->org);
     g->n = n;
+    g->org = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n);
     g->pos = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n);
     g->goal = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n);
     g->hist = (uint8_t *)malloc((size_t)n * ORC_NHIST);
@@ -122,6 +137,7 @@ void orc_gen_create_agents(orc_gen *g, int n, const int32_t *pos, const int32_t 
     for (int a = 0; a < n; a++) {
         uint16_t *d = g->dist + (size_t)a * g->H * g->W;
         orc_bfs(g->grid, g->H, g->W, goal[2 * a], goal[2 * a + 1], d);
+        window_origin(pos[2 * a], pos[2 * a + 1], g->org + 2 * a);   /* cpp:408 compute_cost2go_partial */
         g->next[a] = next_action_token(d, g->W, pos[2 * a], pos[2 * a + 1]);
     }
 }
@@ -145,8 +161,16 @@ void orc_gen_update_agents(orc_gen *g, const int32_t *pos, const int32_t *goal, 
             g->goal[2 * a] = goal[2 * a];
             g->goal[2 * a + 1] = goal[2 * a + 1];
             orc_bfs(g->grid, g->H, g->W, goal[2 * a], goal[2 * a + 1], g->dist + (size_t)a * g->H * W);
+            window_origin(pos[2 * a], pos[2 * a + 1], g->org + 2 * a);
+        } else {
+            /* cpp:469-477: the observation window left the cached partial box -> recomputed around the new position.
+             * The full-grid field needs no recompute; only the box origin moves (it decides the corner cell below). */
+            int left = g->org[2 * a], top = g->org[2 * a + 1];
+            int right = left + 2 * ORC_STEP < g->H - 1 ? left + 2 * ORC_STEP : g->H - 1;
+            int bottom = top + 2 * ORC_STEP < W - 1 ? top + 2 * ORC_STEP : W - 1;
+            if (pos[2 * a] - ORC_R < left || pos[2 * a] + ORC_R > right || pos[2 * a + 1] - ORC_R < top || pos[2 * a + 1] + ORC_R > bottom)
+                window_origin(pos[2 * a], pos[2 * a + 1], g->org + 2 * a);
         }
-        /* cpp:469-477 (window left the partial box): a full-grid field never needs it. */
     }
     for (int a = 0; a < n; a++)                               /* cpp:483-484 */
         g->next[a] = next_action_token(g->dist + (size_t)a * g->H * W, W, g->pos[2 * a], g->pos[2 * a + 1]);
@@ -158,16 +182,24 @@ static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v
 void orc_gen_generate_observations(const orc_gen *g, uint8_t *out /* n*256 */)
 {
     int n = g->n, H = g->H, W = g->W;
-    (void)H;
     for (int a = 0; a < n; a++) {
         uint8_t *row = out + (size_t)a * ORC_CTX;
         const uint16_t *d = g->dist + (size_t)a * g->H * W;
         int pr = g->pos[2 * a], pc = g->pos[2 * a + 1];
         memset(row, TOK_PAD, ORC_CTX);                        /* cpp:375-376, 386-387 */
         int mid = d[pr * W + pc];                             /* cpp:297 */
+        /* the unseeded corner of the cached partial window (cpp:178-198), if it exists and is in view */
+        int cr = g->org[2 * a] + 2 * ORC_STEP, cc = g->org[2 * a + 1] + 2 * ORC_STEP;
+        int corner_in_view = cr <= H - 1 && cc <= W - 1 && pr + ORC_R == cr && pc + ORC_R == cc;
         for (int i = 0; i <= 2 * ORC_R; i++)
             for (int j = 0; j <= 2 * ORC_R; j++) {
                 int v = d[(pr - ORC_R + i) * W + (pc - ORC_R + j)];
+                if (corner_in_view && i == 2 * ORC_R && j == 2 * ORC_R && v != ORC_UNREACH && v != 0) {
+                    /* reached only from its two in-window neighbours (exact border seeds): cpp:252-268 */
+                    int n1 = d[(cr - 1) * W + cc], n2 = d[cr * W + cc - 1];
+                    int m = n1 < n2 ? n1 : n2;
+                    v = m == ORC_UNREACH ? ORC_UNREACH : m + 1;
+                }
                 uint8_t t;
                 if (v == ORC_UNREACH) t = TOK_UNREACH;        /* cpp:308-309: -80 -> 41 */
                 else {

@@ -15,11 +15,18 @@ CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 
 @pytest.mark.parametrize("name", CASES)
 def test_dataset_oracle_matches_reference_rows(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    rows, gts = dso.generate_observations(g["grid"], g["init_positions"], g["made_actions"].tolist())
+    rows, gts = dso.generate_observations(g["grid"], g["init_positions"], g["made_actions"].tolist(),
+                                          lifelong_targets=g["lifelong_targets"] if "lifelong_targets" in g else None,
+                                          mask_cost2go="mask_cost2go" in g)
     assert rows.shape == g["inputs"].shape
     assert np.array_equal(rows, g["inputs"])
     assert np.array_equal(gts, g["gt_actions"])
     assert (g["gt_actions"] == 5).any() or name == "ds_short"        # "wait in goal" labels are exercised
+    if "lifelong_targets" in g:                                      # the goal really moves inside the log
+        own_goal = rows[:, 121 + 2: 121 + 4].reshape(len(g["init_positions"]), -1, 2)
+        assert any(len({tuple(v) for v in (own_goal[a] + rows.reshape(len(own_goal), -1, 256)[a, :, 121:123] * 0).tolist()}) > 2 for a in range(len(own_goal)))
+    if "mask_cost2go" in g:
+        assert set(np.unique(rows[:, :121]).tolist()) == {20, 21}
 
 
 def test_history_padding_rules():
@@ -47,3 +54,42 @@ def test_host_encoder_round_trip_on_reference_rows():
         assert obs["agents"][0]["relative_pos"] == (0, 0)                    # slot 0 is the observer
         obs["agents"] = [a for a in obs["agents"] if a["next_action"] != "!"]
         assert enc.encode(obs) == [int(v) for v in row]
+
+
+def test_host_encoder_masks_against_reference_outputs():
+    """Encoder.mask vs outputs of the reference's python Encoder.mask (tests/golden/enc_masks.npz, made by make_golden_dataset.py)."""
+    from mapf_gpt_amd.dataset_tokenizer import Encoder, InputParameters
+    g = np.load(os.path.join(GOLDEN, "enc_masks.npz"))
+    flags = ("mask_actions_history", "mask_goal", "mask_greed_action", "mask_cost2go")
+    for key in flags + ("all",):
+        enc = Encoder(InputParameters(**({f: True for f in flags} if key == "all" else {key: True})))
+        for row, exp in zip(g["rows"], g[key]):
+            assert enc.mask([int(v) for v in row]) == [int(v) for v in exp], key
+
+
+def test_host_encoder_masks_known_answers():
+    """Encoder.mask = tokenizer.py:104-138 (known answers worked out from that code on one golden row)."""
+    from mapf_gpt_amd.dataset_tokenizer import Encoder, InputParameters
+    row = [int(v) for v in np.load(os.path.join(GOLDEN, "ds_random.npz"))["inputs"][40]]
+    base = Encoder().decode(row)
+    for flag in ("mask_actions_history", "mask_goal", "mask_greed_action", "mask_cost2go"):
+        enc = Encoder(InputParameters(**{flag: True}))
+        got = enc.mask(list(row))
+        exp = list(row)
+        for i in range(13):
+            o = 121 + 10 * i
+            if flag == "mask_actions_history":
+                exp[o + 4: o + 9] = [66] * 5
+            if flag == "mask_goal":
+                exp[o + 2] = exp[o + 3] = 66
+            if flag == "mask_greed_action":
+                exp[o + 9] = 66
+        if flag == "mask_cost2go":
+            exp[:121] = [41 if v == 41 else 20 for v in row[:121]]
+        assert got == exp, flag
+        obs = enc.decode(row)                                              # decode masks first (tokenizer.py:141-149)
+        if flag == "mask_goal":
+            assert all(a["relative_goal"] == ("!", "!") for a in obs["agents"])
+        if flag == "mask_cost2go":
+            assert set(np.unique(obs["cost2go"]).tolist()) <= {0, -80}
+        assert obs["agents"][0]["relative_pos"] == base["agents"][0]["relative_pos"]

@@ -21,14 +21,16 @@ def _to_str(obst):
 
 @pytest.mark.parametrize("name", CASES)
 def test_reference_goldens_bit_exact(name):
-    from mapf_gpt_amd.dataset_tokenizer import ObservationGenerator
+    from mapf_gpt_amd.dataset_tokenizer import InputParameters, ObservationGenerator
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     obst = g["grid"][5:-5, 5:-5]
-    data = [{"metrics": {"CSR": 1.0, "made_actions": g["made_actions"].tolist(), "init_positions": g["init_positions"].tolist()},
-             "env_grid_search": {"map_name": "m"}},
+    first = {"CSR": 1.0, "made_actions": g["made_actions"].tolist(), "init_positions": g["init_positions"].tolist()}
+    if "lifelong_targets" in g:                                             # lifelong log (generate_observations.py:55-60)
+        first["global_lifelong_targets_xy"] = g["lifelong_targets"].tolist()
+    data = [{"metrics": first, "env_grid_search": {"map_name": "m"}},
             {"metrics": {"CSR": 0.0, "made_actions": g["made_actions"].tolist(), "init_positions": g["init_positions"].tolist()},
              "env_grid_search": {"map_name": "m"}}]                         # skipped: not solved
-    gen = ObservationGenerator({"m": _to_str(obst)}, data)
+    gen = ObservationGenerator({"m": _to_str(obst)}, data, InputParameters(mask_cost2go="mask_cost2go" in g))
     inputs, gts = gen.generate_observations(0, 2)
     assert np.array_equal(np.stack(inputs), g["inputs"])
     assert np.array_equal(np.array(gts), g["gt_actions"])

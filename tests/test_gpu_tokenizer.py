@@ -198,3 +198,79 @@ def test_long_corridor_needs_16bit_fields():
     tok = _compare_with_oracle(grid, pos, goal, steps=3, seed=9)
     d = tok.distance_fields()
     assert ((d > 253) & (d < 65535)).any()
+
+
+@pytest.mark.parametrize("h,w,central_goals,static_goals", [(140, 140, True, True), (140, 150, True, False), (220, 230, False, False)])
+def test_partial_window_corner_vs_oracle(h, w, central_goals, static_goals):
+    """Maps larger than 128 in both dimensions: the reference's cached partial window leaves its (right, bottom) corner
+    unseeded (observation_generator.cpp:178-198), visible from (left + 123, top + 123) -- the per-agent window origin and the
+    patched cell must follow the pinned oracle (tests/golden/tok_corner_*.npz) on the one-byte fields (central goals: all
+    distances < 254), the 16-bit fields, and both update paths (static goals / goal checks)."""
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    rng = np.random.Generator(np.random.PCG64(h * 1000 + w))
+    n_inst, n = 2, 20
+    grid = maps.pad((rng.random((h, w)) < 0.08).astype(np.uint8))
+    H, W = grid.shape
+    sites = [(cr, cc) for cr in (128, 192) for cc in (128, 192) if cr <= H - 1 and cc <= W - 1]
+    for cr, cc in sites:
+        grid[cr - 9: min(cr + 3, H - 5), cc - 9: min(cc + 3, W - 5)] = 0
+    comp = maps.largest_component(grid == 0)
+    free = np.argwhere(comp)
+    pos = np.zeros((n_inst, n, 2), np.int32)
+    for i in range(n_inst):
+        taken = set()
+        for a in range(n):
+            cr, cc = sites[a % len(sites)]
+            while True:
+                p = (int(cr - 5 - rng.integers(0, 3)), int(cc - 5 - rng.integers(0, 3)))
+                if comp[p] and p not in taken:
+                    taken.add(p)
+                    pos[i, a] = p
+                    break
+    if central_goals:
+        mid = free[np.abs(free - np.array([H // 2, W // 2])).sum(1) < 30]
+        goal = mid[rng.integers(0, len(mid), (n_inst, n))].astype(np.int32)
+    else:
+        goal = free[rng.integers(0, len(free), (n_inst, n))].astype(np.int32)
+        goal[:, :6] = free[np.argsort(-(free.sum(1)))[:6]]                      # beyond every corner
+    first = np.maximum(pos - 45, 5)                                           # created where the window origin is the site's
+    for i in range(n_inst):
+        for a in range(n):
+            first[i, a] = free[np.abs(free - first[i, a]).sum(1).argmin()]
+    gens = [orc.OracleGenerator(grid) for _ in range(n_inst)]
+    tok = BatchedTokenizer(grid, n_inst, n)
+    p, last = first.copy(), np.full((n_inst, n), -1, np.int32)
+    hits = patched = 0
+    for t in range(24):
+        if t == 1:
+            p = pos.copy()
+        if t == 12 and not static_goals:
+            goal[:, 10:] = free[rng.integers(0, len(free), (n_inst, n - 10))]
+        dp, dg, da = _dev(p, torch.int16), _dev(goal, torch.int16), _dev(last, torch.int32)
+        if t == 0:
+            tok.create_agents(dp, dg)
+            for i in range(n_inst):
+                gens[i].create_agents(p[i], goal[i])
+        tok.update_agents(dp, dg, da, goals_may_change=not static_goals)
+        got = tok.generate_observations().cpu().numpy().reshape(n_inst, n, 256)
+        for i in range(n_inst):
+            gens[i].update_agents(p[i], goal[i], last[i])
+            exp = gens[i].generate_observations()
+            assert np.array_equal(got[i], exp), f"step {t} instance {i} rows {np.argwhere((got[i] != exp).any(1)).ravel().tolist()}"
+            d = gens[i].dist()
+            for a in range(n):
+                if any(p[i, a, 0] + 5 == cr and p[i, a, 1] + 5 == cc for cr, cc in sites):
+                    hits += 1
+                    v, m = int(d[a][p[i, a, 0] + 5, p[i, a, 1] + 5]), int(d[a][p[i, a, 0], p[i, a, 1]])
+                    plain = 41 if v == 65535 else (43 if v - m > 20 else 42 if v - m < -20 else v - m + 20)
+                    patched += int(exp[a, 120] != plain)
+        last = rng.integers(0, 5, (n_inst, n)).astype(np.int32)
+        bias = rng.random((n_inst, n)) < 0.5
+        last[bias] = rng.choice([2, 4], int(bias.sum()))
+        for i in range(n_inst):
+            p[i], _ = orc.env_step(grid, p[i], goal[i], last[i])
+    assert hits > 0
+    if not central_goals:
+        assert patched > 0, "the walk never produced a row where the reference differs from the plain BFS distance"
+    fields = tok.distance_fields().cpu().numpy()
+    assert (int(fields[fields != 65535].max()) <= 253) == central_goals       # which of the two field widths the kernel read
