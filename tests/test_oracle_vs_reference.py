@@ -60,11 +60,13 @@ def test_partial_window_corner_walks(seed):
     starts = []
     for k in range(n):                                         # starts inside the windows whose corner is the site
         cr, cc = sites[k % 4]
-        while True:
+        for _ in range(10000):
             p = (int(cr - 5 - rng.integers(0, 4)), int(cc - 5 - rng.integers(0, 4)))
             if comp[p] and p not in starts:
                 starts.append(p)
                 break
+        else:
+            raise AssertionError("no free start cell near the corner site")
     free = np.argwhere(comp)
     goal = free[rng.integers(0, len(free), n)].astype(np.int32)
     goal[:8] = free[np.argsort(-(free.sum(1)))[:8]]            # some goals beyond every corner
