@@ -221,6 +221,10 @@ def test_partial_window_corner_vs_oracle(h, w, central_goals, static_goals):
         taken = set()
         for a in range(n):
             cr, cc = sites[a % len(sites)]
+            if a < len(sites):                                               # one agent exactly on every corner-view spot
+                taken.add((cr - 5, cc - 5))
+                pos[i, a] = (cr - 5, cc - 5)
+                continue
             for _ in range(10000):                                           # bounded: never spin on a full neighbourhood
                 p = (int(cr - 5 - rng.integers(0, 6)), int(cc - 5 - rng.integers(0, 6)))
                 if comp[p] and p not in taken:
@@ -237,8 +241,13 @@ def test_partial_window_corner_vs_oracle(h, w, central_goals, static_goals):
         goal[:, :6] = free[np.argsort(-(free.sum(1)))[:6]]                      # beyond every corner
     first = np.maximum(pos - 45, 5)                                           # created where the window origin is the site's
     for i in range(n_inst):
-        for a in range(n):
-            first[i, a] = free[np.abs(free - first[i, a]).sum(1).argmin()]
+        used = set()
+        for a in range(n):                                                    # nearest free cell nobody else took (the env never
+            for k in np.argsort(np.abs(free - first[i, a]).sum(1)):           # puts two agents on one cell)
+                if tuple(free[k]) not in used:
+                    used.add(tuple(free[k]))
+                    first[i, a] = free[k]
+                    break
     gens = [orc.OracleGenerator(grid) for _ in range(n_inst)]
     tok = BatchedTokenizer(grid, n_inst, n)
     p, last = first.copy(), np.full((n_inst, n), -1, np.int32)
