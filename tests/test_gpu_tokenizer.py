@@ -284,4 +284,5 @@ def test_partial_window_corner_vs_oracle(h, w, central_goals, static_goals):
     if not central_goals:
         assert patched > 0, "the walk never produced a row where the reference differs from the plain BFS distance"
     fields = tok.distance_fields()
-    assert (int(fields[fields != 65535].max()) <= 253) == central_goals       # which of the two field widths the kernel read
+    longest = int(fields[fields != 65535].max())                              # which of the two field widths the kernel read
+    assert longest <= 253 if static_goals else (central_goals or longest > 253)
