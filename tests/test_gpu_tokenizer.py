@@ -239,7 +239,7 @@ def test_partial_window_corner_vs_oracle(h, w, central_goals, static_goals):
     else:
         goal = free[rng.integers(0, len(free), (n_inst, n))].astype(np.int32)
         goal[:, :6] = free[np.argsort(-(free.sum(1)))[:6]]                      # beyond every corner
-    first = np.maximum(pos - 45, 5)                                           # created where the window origin is the site's
+    first = np.maximum(pos - 60, 5)                                           # created where the window origin is the site's
     for i in range(n_inst):
         used = set()
         for a in range(n):                                                    # nearest free cell nobody else took (the env never

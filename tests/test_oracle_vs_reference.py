@@ -70,7 +70,7 @@ def test_partial_window_corner_walks(seed):
     free = np.argwhere(comp)
     goal = free[rng.integers(0, len(free), n)].astype(np.int32)
     goal[:8] = free[np.argsort(-(free.sum(1)))[:8]]            # some goals beyond every corner
-    first = np.array([(p[0] - 40, p[1] - 40) for p in starts], np.int32)     # created with the origin the site belongs to
+    first = np.array([(p[0] - 60, p[1] - 60) for p in starts], np.int32)     # created with the origin the site belongs to
     for k in range(n):
         if not comp[tuple(first[k])]:
             d = np.abs(free - first[k]).sum(1)
