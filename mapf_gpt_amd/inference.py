@@ -136,7 +136,7 @@ class MAPFGPTInference:
         for i in range(0, inputs.shape[0], self.cfg.batch_size):
             chunk = inputs[i:i + self.cfg.batch_size]
             out = self.net.act(chunk, generator=self.torch_generator)
-            out = torch.atleast_1d(out).tolist()
+            out = torch.atleast_1d(torch.squeeze(out)).tolist()      # an injected net may return [B, 1] like model.py:259
             actions.extend(int(a) for a in out)
         return actions
 

@@ -1,5 +1,7 @@
 """End-to-end hot path on the device: adapter bookkeeping (inference.py:127-172) and the batched runner,
 teacher-forced against the oracle step by step."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -146,3 +148,46 @@ def test_lifelong_runner_against_host_restatement():
         assert (done.cpu().numpy() == (2 if t == T - 1 else 0)).all()
     assert np.array_equal(run.env.goals_reached().cpu().numpy(), reached)
     assert reached.sum() > 0
+
+
+def test_adapter_io_captured_from_the_reference():
+    """tests/golden/adapter_io.npz was captured from the reference's own MAPFGPTInference (make_golden_adapter.py): the same
+    observation dicts go into OUR adapter with the same deterministic stand-in policy (injected through `net=`, inference.py:48);
+    the rows it hands to the policy -- chunk by chunk -- and the action lists it returns must be the reference's."""
+    from mapf_gpt_amd.inference import MAPFGPTInference, MAPFGPTInferenceConfig
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "adapter_io.npz"))
+
+    class FakeNet:
+        def __init__(self):
+            self.chunks = []
+
+        def act(self, idx, do_sample=True, generator=None):
+            rows = idx.detach().cpu().to(torch.int64)
+            self.chunks.append(rows.numpy().astype(np.uint8))
+            a = (rows.sum(1) + 3 * torch.arange(rows.shape[0])) % 5
+            return a.reshape(-1, 1).to(idx.device)
+
+    net = FakeNet()
+    algo = MAPFGPTInference(MAPFGPTInferenceConfig(path_to_weights="synthetic:tiny", batch_size=int(g["batch_size"])), net=net)
+    slots = g["slots"].tolist()
+    grids = [g[f"grid{e}"] for e in range(int(g["n_env"]))]
+    n_calls = 0
+    for k in g["sequence"].tolist():
+        if k < 0:
+            algo.reset_states()
+            continue
+        active = g[f"c{k}_active"].tolist()
+        obs = []
+        for j, e in enumerate(active):
+            P, G = g[f"c{k}_pos{j}"], g[f"c{k}_goal{j}"]
+            obs.append([{"global_xy": (int(p[0]), int(p[1])), "global_target_xy": (int(q[0]), int(q[1])), "global_obstacles": grids[e].astype(np.int64)}
+                        for p, q in zip(P, G)])
+        net.chunks = []
+        out = [algo.act(obs[0])] if (len(active) == 1 and k == 5) else algo.act_batch(obs, positions=[slots[e] for e in active])
+        assert len(net.chunks) == int(g[f"c{k}_nchunks"]), f"call {k}: chunking"
+        for j, ch in enumerate(net.chunks):
+            assert np.array_equal(ch, g[f"c{k}_chunk{j}"]), f"call {k} chunk {j}: rows handed to the policy"
+        for j in range(len(active)):
+            assert [int(a) for a in out[j]] == g[f"c{k}_out{j}"].tolist(), f"call {k} env {j}: returned actions"
+        n_calls += 1
+    assert n_calls == 14
