@@ -51,8 +51,9 @@ int mgpt_device_count(int *count);
 /* = struct InputParameters, observation_generator.h:22-40 / ctor args cpp:551.
  * The kernels implement the configuration the reference always passes (inference.py:15-29):
  * limit 20, 13 agents, 5 previous actions, context 256, radii 5; other values -> MGPT_ERR_UNSUPPORTED.
- * grid_step and save_cost2go only steer the reference's CPU caching of distance fields
- * (cpp:43-132) and do not change any token; they are accepted and ignored. */
+ * save_cost2go only steers the reference's CPU caching of distance fields (cpp:43-132) and is ignored.  grid_step (> 0,
+ * and >= max(H, W) / 256) is the side of the reference's cost-to-go tiles: it changes no token except through the one
+ * unseeded corner cell of an agent's cached 2*grid_step + 1 window (cpp:178-198), which is reproduced. */
 typedef struct mgpt_input_parameters {
     int32_t cost2go_value_limit;
     int32_t num_agents;

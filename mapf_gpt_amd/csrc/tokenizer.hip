@@ -36,7 +36,7 @@ constexpr int kR = 5;               // obs_radius == agents_radius == 5 (inferen
 constexpr int kWin = 2 * kR + 1;    // 11
 constexpr int kLimit = 20;          // cost2go_value_limit (inference.py:17)
 constexpr int kSlots = 13;          // num_agents (inference.py:15)
-constexpr int kStep = 64;           // grid_step (inference.py:28)
+constexpr int kDefaultStep = 64;    // grid_step the reference passes (inference.py:28); run-time value: mgpt_tokenizer::step
 constexpr int TOK_UNREACH = 41, TOK_NEG = 42, TOK_POS = 43, TOK_N = 44, TOK_BITS0 = 50, TOK_PAD = 66;
 
 // ---------------------------------------------------------------------------------------------
@@ -121,16 +121,16 @@ __device__ __forceinline__ int next_action_token(const uint16_t *__restrict__ d,
 }
 
 // origin of the partial window the reference computes for an agent standing at (pr, pc), cpp:204-207 (H, W <= 16384: a byte each)
-__device__ __forceinline__ void window_origin(AgentRec &r)
+__device__ __forceinline__ void window_origin(AgentRec &r, int gstep)
 {
-    r.org[0] = (uint8_t)(max(r.pr - kR, 0) / kStep);
-    r.org[1] = (uint8_t)(max(r.pc - kR, 0) / kStep);
+    r.org[0] = (uint8_t)(max(r.pr - kR, 0) / gstep);
+    r.org[1] = (uint8_t)(max(r.pc - kR, 0) / gstep);
 }
 
 // create_agents, cpp:391-410 (history <- "n" x 5)
 __global__ __launch_bounds__(256) void tok_create_kernel(AgentRec *__restrict__ recs, const int16_t *__restrict__ pos,
                                                          const int16_t *__restrict__ goal, int total,
-                                                         int *__restrict__ u8_ok)
+                                                         int *__restrict__ u8_ok, int gstep)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) *u8_ok = 1;          // every field is rebuilt next; bfs_kernel clears it if one does not fit a byte
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void tok_create_kernel(AgentRec *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 5; k++) r.hist[k] = TOK_N;
     r.next = TOK_BITS0;
-    window_origin(r);                                                                               // cpp:408
+    window_origin(r, gstep);                                                                        // cpp:408
     recs[i] = r;
 }
 
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void tok_update_kernel(AgentRec *__restrict__ 
                                                          const int16_t *__restrict__ goal,
                                                          const int32_t *__restrict__ actions, uint8_t *__restrict__ dirty,
                                                          int total, int check_goals, const uint16_t *__restrict__ dist,
-                                                         int H, int W)
+                                                         int H, int W, int gstep)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -169,9 +169,9 @@ __global__ __launch_bounds__(256) void tok_update_kernel(AgentRec *__restrict__ 
     }
     {   // cpp:464-477: the partial window is recomputed around the new position on a goal change or when the observation
         // window leaves it; only its origin matters here (it decides which cell is the unseeded corner)
-        const int left = kStep * r.org[0], top = kStep * r.org[1];
-        const int right = min(left + 2 * kStep, H - 1), bottom = min(top + 2 * kStep, W - 1);
-        if (moved_goal || r.pr - kR < left || r.pr + kR > right || r.pc - kR < top || r.pc + kR > bottom) window_origin(r);
+        const int left = gstep * r.org[0], top = gstep * r.org[1];
+        const int right = min(left + 2 * gstep, H - 1), bottom = min(top + 2 * gstep, W - 1);
+        if (moved_goal || r.pr - kR < left || r.pr + kR > right || r.pc - kR < top || r.pc + kR > bottom) window_origin(r, gstep);
     }
     if (!check_goals) {
         r.next = (uint8_t)next_action_token(dist + (size_t)i * H * W, H, W, r.pr, r.pc);            // cpp:483-484
@@ -249,7 +249,7 @@ __device__ __forceinline__ void emit_record(uint8_t *rw, int rank, uint4 o, uint
 
 template <class DT, int KP, int RPW>
 __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, const DT *__restrict__ dist, int n_agents,
-                                            int H, int W, int chunks_per_inst, uint8_t *__restrict__ tokens, char *smem)
+                                            int H, int W, int chunks_per_inst, uint8_t *__restrict__ tokens, char *smem, int gstep)
 {
     constexpr int UNR = sizeof(DT) == 1 ? 255 : kUnreach;
     constexpr int APB = 4 * RPW;
@@ -287,7 +287,7 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
             const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
             const bool inside = pr >= kR && pr + kR < H && pc >= kR && pc + kR < W;   // whole window inside the frame
             // is the unseeded corner of the agent's cached partial window (cpp:178-198) the window cell (10, 10)?
-            const int cr = kStep * (int)((me.w >> 16) & 0xffu) + 2 * kStep, cc = kStep * (int)(me.w >> 24) + 2 * kStep;
+            const int cr = gstep * (int)((me.w >> 16) & 0xffu) + 2 * gstep, cc = gstep * (int)(me.w >> 24) + 2 * gstep;
             const bool corner = cr <= H - 1 && cc <= W - 1 && pr + kR == cr && pc + kR == cc;
             h = make_int4((int)my0, pr * W + pc, inside ? 1 : 0, corner ? 1 : 0);
         }
@@ -491,13 +491,13 @@ template <int KP, int RPW>
 __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict__ recs, const uint16_t *__restrict__ dist,
                                                      const uint8_t *__restrict__ dist8, const int *__restrict__ u8_ok,
                                                      int n_agents, int H, int W, int chunks_per_inst,
-                                                     uint8_t *__restrict__ tokens)
+                                                     uint8_t *__restrict__ tokens, int gstep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (*u8_ok)                                                         // uniform
-        tokens_body<uint8_t, KP, RPW>(recs, dist8, n_agents, H, W, chunks_per_inst, tokens, smem);
+        tokens_body<uint8_t, KP, RPW>(recs, dist8, n_agents, H, W, chunks_per_inst, tokens, smem, gstep);
     else
-        tokens_body<uint16_t, KP, RPW>(recs, dist, n_agents, H, W, chunks_per_inst, tokens, smem);
+        tokens_body<uint16_t, KP, RPW>(recs, dist, n_agents, H, W, chunks_per_inst, tokens, smem, gstep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -665,6 +665,7 @@ __global__ __launch_bounds__(256) void ds_tokens_kernel(const AgentRec *__restri
 // ---------------------------------------------------------------------------------------------
 struct mgpt_tokenizer {
     int n_inst, n_agents, H, W, n_grids;
+    int step = kDefaultStep;            // grid_step: side of the reference's cost-to-go tiles (decides the unseeded window corner)
     uint8_t *grids = nullptr;
     uint16_t *dist = nullptr;
     uint8_t *dist8 = nullptr;
@@ -684,6 +685,10 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
                      cfg->context_size == MGPT_CONTEXT && cfg->obs_radius == kR && cfg->agents_radius == kR,
                  MGPT_ERR_UNSUPPORTED,
                  "only the reference's InputParameters (20,13,5,256,5,5) are implemented (inference.py:15-29)");
+    MGPT_REQUIRE(cfg->grid_step > 0, MGPT_ERR_ARG, "grid_step=%d", cfg->grid_step);
+    // the per-agent window origin is kept as (row / grid_step, col / grid_step) in one byte each
+    MGPT_REQUIRE((int64_t)256 * cfg->grid_step >= H && (int64_t)256 * cfg->grid_step >= W, MGPT_ERR_UNSUPPORTED,
+                 "grid_step=%d is too small for a %d x %d map (more than 256 tiles per side)", cfg->grid_step, H, W);
     MGPT_REQUIRE(n_agents <= 2048, MGPT_ERR_UNSUPPORTED, "n_agents=%d > 2048", n_agents);
     MGPT_REQUIRE(H <= 16384 && W <= 16384, MGPT_ERR_UNSUPPORTED, "H=%d W=%d beyond 16384", H, W);
     // distances are uint16 as in the reference (h:73); shortest paths must stay below 65534
@@ -691,6 +696,7 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
                  (long long)H * W);
     mgpt_tokenizer *t = new mgpt_tokenizer();
     t->n_inst = n_inst; t->n_agents = n_agents; t->H = H; t->W = W; t->n_grids = n_grids;
+    t->step = cfg->grid_step;
     const size_t cells = (size_t)H * W, total = (size_t)n_inst * n_agents;
     hipError_t e = hipMalloc(&t->grids, (size_t)n_grids * cells);
     if (e == hipSuccess) e = hipMalloc(&t->dist, total * cells * sizeof(uint16_t));
@@ -750,7 +756,7 @@ extern "C" int mgpt_tokenizer_create_agents(mgpt_tokenizer *t, const int16_t *d_
     {
         ProfScope ps(P_TOK_UPDATE, s);
         hipLaunchKernelGGL(tok_create_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, d_pos, d_goal, total,
-                           t->u8_ok);
+                           t->u8_ok, t->step);
         MGPT_LAUNCH_CHECK();
     }
     int rc = launch_bfs(t, nullptr, s);
@@ -774,7 +780,7 @@ extern "C" int mgpt_tokenizer_update_agents(mgpt_tokenizer *t, const int16_t *d_
     {
         ProfScope ps(P_TOK_UPDATE, s);
         hipLaunchKernelGGL(tok_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, d_pos, d_goal, d_actions,
-                           t->dirty, total, goals_may_change ? 1 : 0, t->dist, t->H, t->W);
+                           t->dirty, total, goals_may_change ? 1 : 0, t->dist, t->H, t->W, t->step);
         MGPT_LAUNCH_CHECK();
     }
     if (goals_may_change) {
@@ -805,10 +811,10 @@ extern "C" int mgpt_tokenizer_generate_observations(mgpt_tokenizer *t, uint8_t *
     do {                                                                                                              \
         if (big)                                                                                                      \
             hipLaunchKernelGGL((tokens_kernel<KP_, 16>), dim3(t->n_inst * chunks), dim3(256), smem, s, t->recs, t->dist, \
-                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens);                        \
+                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step);               \
         else                                                                                                          \
             hipLaunchKernelGGL((tokens_kernel<KP_, 4>), dim3(t->n_inst * chunks), dim3(256), smem, s, t->recs, t->dist, \
-                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens);                        \
+                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step);               \
     } while (0)
     switch (kpp) {
     case 1: MGPT_TOKENS(1); break;

@@ -43,7 +43,7 @@ enum { TOK_UNREACH = 41, TOK_NEG = 42, TOK_POS = 43, TOK_N = 44, TOK_BITS0 = 50,
  * short of it), so the flood fill gives it min(in-window neighbours) + 1.  It is visible only from
  * (left + 123, top + 123), reached without a recompute (cpp:469-477); the window origin is
  * therefore part of the agent state here (`org`).  Pinned by tests/golden/tok_corner_*.npz. */
-#define ORC_STEP 64       /* inf:28 grid_step */
+#define ORC_STEP 64       /* inf:28 grid_step: the default; orc_gen_set_grid_step changes it per generator */
 void orc_bfs(const uint8_t *grid, int H, int W, int gr, int gc, uint16_t *dist)
 {
     int n = H * W;
@@ -93,12 +93,14 @@ typedef struct {
     uint8_t *next;      /* n */
     uint16_t *dist;     /* n*H*W */
     int32_t *org;       /* n*2: (left_border, top_border) of the agent's cached partial window, cpp:204-207 */
+    int step;           /* cfg.grid_step, h:38 */
 } orc_gen;
 
 orc_gen *orc_gen_create(const uint8_t *grid, int H, int W)
 {
     orc_gen *g = (orc_gen *)calloc(1, sizeof(orc_gen));
     g->H = H; g->W = W; g->n = 0;
+    g->step = ORC_STEP;
     g->grid = (uint8_t *)malloc((size_t)H * W);
     memcpy(g->grid, grid, (size_t)H * W);
     g->occ = (int32_t *)malloc(sizeof(int32_t) * (size_t)H * W);
@@ -114,11 +116,14 @@ void orc_gen_destroy(orc_gen *g)
 }
 
 /* cpp:204-207: origin of the partial window computed for an agent standing at (r, c) */
-static void window_origin(int r, int c, int32_t *org)
+static void window_origin(int r, int c, int step, int32_t *org)
 {
-    org[0] = (r - ORC_R > 0 ? r - ORC_R : 0) / ORC_STEP * ORC_STEP;
-    org[1] = (c - ORC_R > 0 ? c - ORC_R : 0) / ORC_STEP * ORC_STEP;
+    org[0] = (r - ORC_R > 0 ? r - ORC_R : 0) / step * step;
+    org[1] = (c - ORC_R > 0 ? c - ORC_R : 0) / step * step;
 }
+
+/* InputParameters.grid_step (h:38, cpp:551); call before create_agents */
+void orc_gen_set_grid_step(orc_gen *g, int step) { if (step > 0) g->step = step; }
 
 /* cpp:391-410: history = "n" x5, distance field, greedy bits.  Does NOT touch agents_locations. */
 void orc_gen_create_agents(orc_gen *g, int n, const int32_t *pos, const int32_t *goal)
@@ -137,7 +142,7 @@ void orc_gen_create_agents(orc_gen *g, int n, const int32_t *pos, const int32_t 
     for (int a = 0; a < n; a++) {
         uint16_t *d = g->dist + (size_t)a * g->H * g->W;
         orc_bfs(g->grid, g->H, g->W, goal[2 * a], goal[2 * a + 1], d);
-        window_origin(pos[2 * a], pos[2 * a + 1], g->org + 2 * a);   /* cpp:408 compute_cost2go_partial */
+        window_origin(pos[2 * a], pos[2 * a + 1], g->step, g->org + 2 * a);   /* cpp:408 compute_cost2go_partial */
         g->next[a] = next_action_token(d, g->W, pos[2 * a], pos[2 * a + 1]);
     }
 }
@@ -161,15 +166,15 @@ void orc_gen_update_agents(orc_gen *g, const int32_t *pos, const int32_t *goal, 
             g->goal[2 * a] = goal[2 * a];
             g->goal[2 * a + 1] = goal[2 * a + 1];
             orc_bfs(g->grid, g->H, g->W, goal[2 * a], goal[2 * a + 1], g->dist + (size_t)a * g->H * W);
-            window_origin(pos[2 * a], pos[2 * a + 1], g->org + 2 * a);
+            window_origin(pos[2 * a], pos[2 * a + 1], g->step, g->org + 2 * a);
         } else {
             /* cpp:469-477: the observation window left the cached partial box -> recomputed around the new position.
              * The full-grid field needs no recompute; only the box origin moves (it decides the corner cell below). */
             int left = g->org[2 * a], top = g->org[2 * a + 1];
-            int right = left + 2 * ORC_STEP < g->H - 1 ? left + 2 * ORC_STEP : g->H - 1;
-            int bottom = top + 2 * ORC_STEP < W - 1 ? top + 2 * ORC_STEP : W - 1;
+            int right = left + 2 * g->step < g->H - 1 ? left + 2 * g->step : g->H - 1;
+            int bottom = top + 2 * g->step < W - 1 ? top + 2 * g->step : W - 1;
             if (pos[2 * a] - ORC_R < left || pos[2 * a] + ORC_R > right || pos[2 * a + 1] - ORC_R < top || pos[2 * a + 1] + ORC_R > bottom)
-                window_origin(pos[2 * a], pos[2 * a + 1], g->org + 2 * a);
+                window_origin(pos[2 * a], pos[2 * a + 1], g->step, g->org + 2 * a);
         }
     }
     for (int a = 0; a < n; a++)                               /* cpp:483-484 */
@@ -189,7 +194,7 @@ void orc_gen_generate_observations(const orc_gen *g, uint8_t *out /* n*256 */)
         memset(row, TOK_PAD, ORC_CTX);                        /* cpp:375-376, 386-387 */
         int mid = d[pr * W + pc];                             /* cpp:297 */
         /* the unseeded corner of the cached partial window (cpp:178-198), if it exists and is in view */
-        int cr = g->org[2 * a] + 2 * ORC_STEP, cc = g->org[2 * a + 1] + 2 * ORC_STEP;
+        int cr = g->org[2 * a] + 2 * g->step, cc = g->org[2 * a + 1] + 2 * g->step;
         int corner_in_view = cr <= H - 1 && cc <= W - 1 && pr + ORC_R == cr && pc + ORC_R == cc;
         for (int i = 0; i <= 2 * ORC_R; i++)
             for (int j = 0; j <= 2 * ORC_R; j++) {

@@ -44,6 +44,8 @@ def lib():
         L.orc_gen_create.argtypes = [u8p, i32, i32]
         L.orc_gen_create.restype = vp
         L.orc_gen_destroy.argtypes = [vp]
+        L.orc_gen_set_grid_step.argtypes = [vp, i32]
+        L.orc_gen_set_grid_step.restype = None
         L.orc_gen_create_agents.argtypes = [vp, i32, vp, vp]
         L.orc_gen_update_agents.argtypes = [vp, vp, vp, vp]
         L.orc_gen_generate_observations.argtypes = [vp, vp]
@@ -72,10 +74,11 @@ class OracleGenerator:
     """One env instance; mirrors ObservationGenerator(grid, cfg) with the default InputParameters
     of inference.py:15-29 (the only ones the reference ever passes)."""
 
-    def __init__(self, grid):
+    def __init__(self, grid, grid_step=64):
         self.grid = np.ascontiguousarray(np.asarray(grid) != 0, dtype=np.uint8)
         self.H, self.W = self.grid.shape
         self._h = lib().orc_gen_create(self.grid.ctypes.data, self.H, self.W)
+        lib().orc_gen_set_grid_step(self._h, int(grid_step))          # InputParameters.grid_step (inference.py:28)
         self.n = 0
 
     def __del__(self):

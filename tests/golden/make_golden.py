@@ -37,8 +37,8 @@ def import_reference():
     return og, GPT, GPTConfig
 
 
-def ref_params(og):
-    return og.InputParameters(20, 13, 5, 256, 5, 5, 64, False)   # inference.py:109-118 defaults
+def ref_params(og, grid_step=64):
+    return og.InputParameters(20, 13, 5, 256, 5, 5, grid_step, False)   # inference.py:109-118 defaults
 
 
 def walk(grid, pos, goal, steps, seed, goal_change_at=None, goal_ok=None):
@@ -60,8 +60,8 @@ def walk(grid, pos, goal, steps, seed, goal_change_at=None, goal_ok=None):
         last = act
 
 
-def tokenizer_case(og, name, grid, pos, goal, steps, seed, goal_change_at=None, goal_ok=None, keep=None):
-    gen = og.ObservationGenerator(grid.astype(int).tolist(), ref_params(og))
+def tokenizer_case(og, name, grid, pos, goal, steps, seed, goal_change_at=None, goal_ok=None, keep=None, grid_step=64):
+    gen = og.ObservationGenerator(grid.astype(int).tolist(), ref_params(og, grid_step))
     P, G, A, T = [], [], [], []
     for t, (p, g, a) in enumerate(walk(grid, pos, goal, steps, seed, goal_change_at, goal_ok)):
         pl, gl = [tuple(map(int, x)) for x in p], [tuple(map(int, x)) for x in g]
@@ -77,7 +77,7 @@ def tokenizer_case(og, name, grid, pos, goal, steps, seed, goal_change_at=None, 
         T = T[:, keep]
     np.savez_compressed(os.path.join(OUT, f"tok_{name}.npz"), grid=grid.astype(np.uint8), pos=P, goal=G,
                         actions=A, tokens=T, keep=np.arange(P.shape[1]) if keep is None else np.asarray(keep),
-                        sha256_all_rows=np.array(sha))
+                        sha256_all_rows=np.array(sha), **({} if grid_step == 64 else {"grid_step": np.array(grid_step)}))
     print(f"tok_{name}: grid {grid.shape} agents {P.shape[1]} steps {steps} tokens {T.shape} sha {sha[:16]}")
     return T
 

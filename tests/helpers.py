@@ -22,7 +22,7 @@ def load_tok(name):
 def replay_oracle(case):
     """Run the C oracle over a golden trajectory -> uint8 [S, n, 256] (all agents)."""
     grid, P, G, A = case["grid"], case["pos"], case["goal"], case["actions"]
-    gen = orc.OracleGenerator(grid)
+    gen = orc.OracleGenerator(grid, grid_step=int(case["grid_step"]) if "grid_step" in case else 64)
     out = []
     for t in range(P.shape[0]):
         if t == 0:

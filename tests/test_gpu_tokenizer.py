@@ -17,10 +17,10 @@ def _dev(a, dtype):
 
 
 def replay_gpu(case, n_inst=1, check_dist=False):
-    from mapf_gpt_amd.observation_generator import BatchedTokenizer
+    from mapf_gpt_amd.observation_generator import BatchedTokenizer, InputParameters
     grid, P, G, A = case["grid"], case["pos"], case["goal"], case["actions"]
     S, n = P.shape[0], P.shape[1]
-    tok = BatchedTokenizer(grid, n_inst, n)
+    tok = BatchedTokenizer(grid, n_inst, n, InputParameters(grid_step=int(case["grid_step"]) if "grid_step" in case else 64))
     out = []
     for t in range(S):
         pos = _dev(np.broadcast_to(P[t], (n_inst, n, 2)), torch.int16)
