@@ -119,6 +119,17 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         }
     }
     m->mlp_fused = (C == 160 || C == 64 || C == 256);
+    if (m->mlp_fused) {   // Phi(v) = (1 + erf(v / sqrt 2)) / 2 on [-6, 6) in steps of 1/256, as (value, forward difference) pairs
+        std::vector<float2> lut(fastk::kGeluLutN);
+        auto phi = [](double v) { return 0.5 * (1.0 + erf(v * 0.70710678118654752440)); };
+        for (int i = 0; i < fastk::kGeluLutN; i++) {
+            const double v0 = (i - (double)fastk::kGeluLutBias) / fastk::kGeluLutScale, v1 = (i + 1 - (double)fastk::kGeluLutBias) / fastk::kGeluLutScale;
+            const float f0 = (float)phi(v0);
+            lut[i] = make_float2(f0, (float)(phi(v1) - (double)f0));
+        }
+        MGPT_HIP(hipMalloc(&m->gelu_lut, lut.size() * sizeof(float2)));
+        MGPT_HIP(hipMemcpy(m->gelu_lut, lut.data(), lut.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
     if (C == 256) {
         const size_t n16 = (size_t)fastk::kM256Steps * 8 * NP * 512;
         m->mlp256_pk.assign(g->L, nullptr);
@@ -130,17 +141,6 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, m->mlp256_pk[l], 1.0f / m->fc[l].inv_scale,
                                1.0f / m->proj2[l].inv_scale);
             MGPT_LAUNCH_CHECK();
-        }
-        {   // Phi(v) = (1 + erf(v / sqrt 2)) / 2 on [-6, 6) in steps of 1/256, as (value, forward difference) pairs
-            std::vector<float2> lut(fastk::kGeluLutN);
-            auto phi = [](double v) { return 0.5 * (1.0 + erf(v * 0.70710678118654752440)); };
-            for (int i = 0; i < fastk::kGeluLutN; i++) {
-                const double v0 = (i - (double)fastk::kGeluLutBias) / fastk::kGeluLutScale, v1 = (i + 1 - (double)fastk::kGeluLutBias) / fastk::kGeluLutScale;
-                const float f0 = (float)phi(v0);
-                lut[i] = make_float2(f0, (float)(phi(v1) - (double)f0));
-            }
-            MGPT_HIP(hipMalloc(&m->gelu_lut, lut.size() * sizeof(float2)));
-            MGPT_HIP(hipMemcpy(m->gelu_lut, lut.data(), lut.size() * sizeof(float2), hipMemcpyHostToDevice));
         }
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kM256Lds<NP>));
@@ -171,7 +171,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                1.0f / m->fc[l].inv_scale, 1.0f / m->proj2[l].inv_scale);
             MGPT_LAUNCH_CHECK();
         }
-        const int pkt = (int)(frags * NP * 1024 * 3);
+        const int pkt = (int)(frags * NP * 1024 * 3) + fastk::kGeluLutN * 8;
 #define MGPT_MLP_ATTR(CT_, NW_) \
     MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, CT_, NW_>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt))
         if (C == 160) { MGPT_MLP_ATTR(5, 8); MGPT_MLP_ATTR(5, 4); MGPT_MLP_ATTR(5, 2); }
@@ -459,12 +459,12 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                     if ((rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
                 }
             } else {
-                const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 3;
+                const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 3 + fastk::kGeluLutN * 8;
                 // 32 tokens per wave whatever the block size: small launches (cfg1: 32 rows = 32 blocks of 256 tokens) take
                 // fewer waves per block so that the tokens spread over more CUs; results do not depend on the choice
 #define MGPT_MLP(CT_, NW_)                                                                                                           \
     hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, CT_, NW_>), dim3((unsigned)(mlp_M / (32 * NW_))), dim3(64 * NW_), lds, s, mlp_x, \
-                       P + lo.ln2, m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M)
+                       P + lo.ln2, m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M, m->gelu_lut)
                 const int nw = (mlp_M >= (int64_t)256 * m->n_cu) ? 8 : (mlp_M >= (int64_t)128 * m->n_cu ? 4 : 2);
                 if (C == 160) { if (nw == 8) MGPT_MLP(5, 8); else if (nw == 4) MGPT_MLP(5, 4); else MGPT_MLP(5, 2); }
                 else { if (nw == 8) MGPT_MLP(2, 8); else if (nw == 4) MGPT_MLP(2, 4); else MGPT_MLP(2, 2); }

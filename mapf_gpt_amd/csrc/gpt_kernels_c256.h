@@ -73,13 +73,7 @@ __device__ __forceinline__ void split2p(float v0, float v1, unsigned &hi, unsign
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kM256Steps = 2 + 4 * 32 + 2;     // c_fc(0) | 32 x 4 mixed steps | c_proj(31)
 
-// GELU by table: gelu(v) = v Phi(v), Phi = standard normal CDF = (1 + erf(v / sqrt 2)) / 2 (model.py:86, exact-erf GELU).
-// Phi is tabulated on [-6, 6) in steps of 1/256 as pairs (Phi(v_i), Phi(v_i+1) - Phi(v_i)) and interpolated linearly:
-// |error in Phi| <= h^2 / 8 max|Phi''| = 4.6e-7, i.e. <= 4.6e-7 |v| in gelu (the rational approximation used elsewhere has
-// 1.6e-6); beyond +-6 the end entries apply (Phi = 1e-9 / 1 - 1e-9).  24 KiB: the LDS goes to a deeper weight ring.  8 VALU + one 8-byte LDS gather per value instead of
-// 19 VALU: on this kernel the VALU port, which the MFMAs share, is the scarce resource (section 3 of DESIGN.md).
-constexpr int kGeluLutN = 3072;                // entries (float2 each: 24 KiB of LDS)
-constexpr float kGeluLutScale = 256.0f, kGeluLutBias = 1536.0f;
+// (GELU table: kGeluLut* in gpt_kernels_fast.h)
 
 template <class T, int NP>
 __global__ __launch_bounds__(256) void pack_mlp256_kernel(const float *__restrict__ fc_w, const float *__restrict__ pj_w,

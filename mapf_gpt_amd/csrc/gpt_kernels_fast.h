@@ -277,6 +277,14 @@ __device__ __forceinline__ float gelu_folded(float v)
     return fmaf(hv, e, hv);
 }
 
+// GELU by table: gelu(v) = v Phi(v), Phi = standard normal CDF = (1 + erf(v / sqrt 2)) / 2 (model.py:86, exact-erf GELU).
+// Phi is tabulated on [-6, 6) in steps of 1/256 as pairs (Phi(v_i), Phi(v_i+1) - Phi(v_i)) and interpolated linearly:
+// |error in Phi| <= h^2 / 8 max|Phi''| = 4.6e-7, i.e. <= 4.6e-7 |v| in gelu (the rational approximation used elsewhere has
+// 1.6e-6); beyond +-6 the end entries apply (Phi = 1e-9 / 1 - 1e-9).  24 KiB: the LDS goes to a deeper weight ring.  8 VALU + one 8-byte LDS gather per value instead of
+// 19 VALU: on this kernel the VALU port, which the MFMAs share, is the scarce resource (section 3 of DESIGN.md).
+constexpr int kGeluLutN = 3072;                // entries (float2 each: 24 KiB of LDS)
+constexpr float kGeluLutScale = 256.0f, kGeluLutBias = 1536.0f;
+
 // gelu_folded on two values with packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32): the same operations in the same order,
 // so the same results.  Pays in the one-wave-per-SIMD GEMM epilogue, where an instruction costs ~5 cycles whatever it does
 // (tools/probe_pk.hip); the register-tight fused kernels keep the scalar form (its constants are inline literals).
@@ -971,9 +979,12 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
 template <class T, int NP, int CT, int NW = 8, int NBUF = 3, int NCH = 2>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                             const uint16_t *__restrict__ wpk, float inv1, float inv2,
-                                                            float2 *__restrict__ stats_out, int M)
+                                                            float2 *__restrict__ stats_out, int M,
+                                                            const float2 *__restrict__ gelu_lut)
 {
     constexpr int C = CT * 32, KS = C / 16, NT = 4 * CT;
+    constexpr int LUT_BYTES = kGeluLutN * 8;               // the Phi table sits behind the ring: [NBUF][PKT][LUT]
+    static_assert((LUT_BYTES / 1024) % NW == 0, "every wave stages the same number of table pieces");
     constexpr int FRAGS = KS + 2 * CT;                     // fragments per hidden tile
     constexpr int PKT = FRAGS * NP * 1024;                 // bytes per hidden-tile packet
     constexpr int PER_WAVE = (FRAGS * NP + NW - 1) / NW;   // DMA instructions a wave issues per packet
@@ -996,8 +1007,19 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
                                              (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
         }
     };
+    // GELU table -> LDS by the same direct loads; older than every ring piece, so the first counted wait covers it
+    {
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(gelu_lut);
+        unsigned char *dst = smem + (size_t)NBUF * PKT;
+#pragma unroll
+        for (int i = 0; i < LUT_BYTES / 1024 / NW; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)(wave + NW * i) * 1024 + lane * 16),
+                                             (lds_void_t *)(dst + (size_t)(wave + NW * i) * 1024), 16, 0, 0);
+    }
     issue(0);
     if (NBUF > 2) issue(1);
+    const unsigned lut_addr = (unsigned)(size_t)(smem + (size_t)NBUF * PKT);
+    const float lut_scale = inv1 * kGeluLutScale;
 
     // ---- load the 32 x C row block in swapped layout, LayerNorm in-lane ----
     f32x16 acc[CT];                                        // x now, output accumulator later
@@ -1093,14 +1115,29 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
         for (int c = 1; c < NCH; c++)
 #pragma unroll
             for (int g = 0; g < 16; g++) hacc[g] += hch[c][g];
+        // GELU by table (8 VALU + one 8-byte LDS gather per value; the rational form costs 17): all 16 gathers of the tile
+        // go out first (asm: invisible to hipcc's LDS-DMA ordering), one wait, then interpolate
+        float gv[16], gf[16];
+        f32x2 gt[16];
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const float hv = hacc[g];
+            gv[g] = hv * inv1;
+            const float tt = __builtin_amdgcn_fmed3f(fmaf(hv, lut_scale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.002f);
+            gf[g] = __builtin_amdgcn_fractf(tt);
+            asm volatile("ds_read_b64 %0, %1" : "=v"(gt[g]) : "v"(lut_addr + (unsigned)tt * 8u) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 16; g++) asm volatile("" : "+v"(gt[g]));
         u32x4 hf[2][2];                                    // [kk][plane]: B operand of c_proj
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             float v0[4], v1[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                v0[e] = gelu_folded(hacc[8 * kk + e] * inv1);
-                v1[e] = gelu_folded(hacc[8 * kk + 4 + e] * inv1);
+                v0[e] = gv[8 * kk + e] * fmaf(gf[8 * kk + e], gt[8 * kk + e][1], gt[8 * kk + e][0]);
+                v1[e] = gv[8 * kk + 4 + e] * fmaf(gf[8 * kk + 4 + e], gt[8 * kk + 4 + e][1], gt[8 * kk + 4 + e][0]);
             }
             u32x2 h0, l0, h1, l1;
             split4<T, NP>(v0, h0, l0);
