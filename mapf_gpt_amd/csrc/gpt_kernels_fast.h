@@ -252,6 +252,18 @@ __device__ __forceinline__ float erf_fast(float x)
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
 
+// value of the other half-wave's lane (r <-> r + 32) combined with this lane's: v_permlane32_swap is a VALU instruction; the
+// __shfl_xor(v, 32) it replaces compiles to ds_bpermute_b32, which joins the K / V fragment reads in lgkmcnt and waits for
+// them.  Inline asm: the builtin's second result comes back as a copy of the first with this hipcc; s_nop 1 = the two wait
+// states between a VALU write and v_permlane*_swap reading it.
+__device__ __forceinline__ void half_swap32(float v, float &lower, float &upper)
+{
+    lower = v; upper = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lower), "+v"(upper));
+}
+__device__ __forceinline__ float half_max32(float v) { float a, b; half_swap32(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float half_sum32(float v) { float a, b; half_swap32(v, a, b); return a + b; }
+
 // GELU with the 1/sqrt(2) and the powers of two folded into the rational's coefficients:
 // gelu(v) = hv + hv * erf(v / sqrt 2), hv = v / 2, erf(u / sqrt 2) ~= u N(u^2) / D(u^2) for |u| <= 4 sqrt 2 (1 beyond).
 // max abs error 1.6e-6 over [-9, 9] in fp32 arithmetic; 17 VALU instructions.
@@ -858,7 +870,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_kernel(const uint16_t *__restr
             float mx = s[0];
 #pragma unroll
             for (int g = 1; g < 16; g++) mx = fmaxf(mx, s[g]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = half_max32(mx);
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
             float psum = 0.f;
@@ -867,7 +879,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_kernel(const uint16_t *__restr
                 s[g] = __builtin_amdgcn_exp2f((s[g] - m_new) * scale_log2e);
                 psum += s[g];
             }
-            psum += __shfl_xor(psum, 32);
+            psum = half_sum32(psum);
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
@@ -1481,7 +1493,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
             float mx = sc[0];
 #pragma unroll
             for (int g = 1; g < 16; g++) mx = fmaxf(mx, sc[g]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = half_max32(mx);
             if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {            // some query's running max moved: rescale (wave-uniform branch)
                 const float m_new = fmaxf(m_run, mx);
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
@@ -1497,7 +1509,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
                 sc[g] = __builtin_amdgcn_exp2f(fmaf(sc[g], sc2, nm));
                 psum += sc[g];
             }
-            psum += __shfl_xor(psum, 32);
+            psum = half_sum32(psum);
             l_run += psum;
 #pragma unroll
             for (int mm = 0; mm < 2; mm++) {
