@@ -300,7 +300,7 @@ def tokenizer_cfg4_launch(local_rank, reps=20):
             "note": "cfg4 per-GPU shard: 512 instances x 128 agents on per-instance 50 x 50 padded maps"}
 
 
-def build_workload(name, precision, rank, world, local_rank, instances=0, use_graph=True):
+def build_workload(name, precision, rank, world, local_rank, instances=0, use_graph=True, chunk_rows=0):
     """-> dict(run, pos, goal, grid, s_ok, g_ok, rows, n_total, ...) for this rank's shard of workload `name`."""
     from mapf_gpt_amd import maps
     from mapf_gpt_amd.model import build_model
@@ -311,7 +311,7 @@ def build_workload(name, precision, rank, world, local_rank, instances=0, use_gr
     n_total = inst_per_gpu * world
     lo, hi = shard_range(n_total, rank, world)
     rows = (hi - lo) * n_agents
-    chunk = min(rows, 4096 if model != "85M" else 1024)
+    chunk = min(rows, chunk_rows or (4096 if model != "85M" else 1024))
     net = build_model(model, seed=0, max_rows=chunk, precision=precision, device=f"cuda:{local_rank}")
     if name == "cfg4":                     # one map per instance, seeded by the global instance id
         grid, pos, goal = cfg4_instances(lo, hi, n_agents)
@@ -400,6 +400,7 @@ def main():
                     help="default: cfg3 at --gpus 1, cfg4 (its per-GPU shard) at --gpus N > 1")
     ap.add_argument("--precision", default=os.environ.get("MGPT_BENCH_PRECISION", "f16x3"), choices=["f32", "f16x3", "bf16"])
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default: the workload's)")
+    ap.add_argument("--chunk-rows", type=int, default=0, help="rows per forward launch (default 4096; 1024 for the 85M shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tokenizer-leg", action="store_true", help="skip the >=1e5-row tokenizer roofline launch")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg2 run reported under 'secondary'")
@@ -430,7 +431,7 @@ def main():
     from mapf_gpt_amd.runner import gather_metrics
 
     name = a.workload or ("cfg3" if world == 1 else "cfg4")
-    w = build_workload(name, a.precision, rank, world, local_rank, a.instances)
+    w = build_workload(name, a.precision, rank, world, local_rank, a.instances, chunk_rows=a.chunk_rows)
     use_prof = not a.no_prof
     dt, prof = timed_steps(w, a.steps, a.warmup, world, use_prof, coll_dev)
     metrics = gather_metrics(w["run"].metrics().to(coll_dev), w["n_total"], rank, world)       # the job's one collective
