@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
     };
     issue_qkv(0);
 
-    // ---- LayerNorm of this lane's token, operand planes in registers (as ln_qkv_kernel) ----
+    // ---- LayerNorm of this lane's token, operand planes in registers ----
     u32x4 xn[KS][2];
     {
         f32x16 xv[CT];
