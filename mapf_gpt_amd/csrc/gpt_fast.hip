@@ -119,7 +119,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         }
     }
     m->mlp_fused = (C == 160 || C == 64 || C == 256);
-    if (m->mlp_fused) {   // Phi(v) = (1 + erf(v / sqrt 2)) / 2 on [-6, 6) in steps of 1/256, as (value, forward difference) pairs
+    {   // Phi(v) = (1 + erf(v / sqrt 2)) / 2 on [-6, 6) in steps of 1/256, as (value, forward difference) pairs
         std::vector<float2> lut(fastk::kGeluLutN);
         auto phi = [](double v) { return 0.5 * (1.0 + erf(v * 0.70710678118654752440)); };
         for (int i = 0; i < fastk::kGeluLutN; i++) {
@@ -233,7 +233,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     lds + fastk::kGeluLutN * 8));
         MGPT_HIP(hipMalloc(&m->apk, (size_t)g->max_rows * kT * C * NP * sizeof(uint16_t)));
     }
     {
@@ -309,8 +310,9 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
                  "gemm_pk shape M=%d N=%d K=%d", a.M, a.N, a.K);
     a.n_tiles_n = a.N / 256;
     if (EPI == fastk::EPI_RESID) a.stats_out = nullptr;               // rows span two waves: stats come from row_stats_kernel
+    const bool lut = EPI == fastk::EPI_GELU && a.gelu_lut != nullptr;
     hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
-                       (size_t)NST * 16 * NP * 1024, s, a);
+                       (size_t)NST * 16 * NP * 1024 + (lut ? fastk::kGeluLutN * 8 : 0), s, a);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
@@ -478,7 +480,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if ((rc = launch_ln_pack<T, NP>(mlp_x, P + lo.ln2, m->apk, mlp_M, C, s)) != MGPT_OK) return rc;
             a.M = (int)mlp_M;
             a.a_hi = m->apk; a.K = C; a.N = 4 * C; a.w_hi = m->fc_pk2[l]; a.out_scale = m->fc[l].inv_scale;
-            a.o_hi = m->hbuf[0]; a.o_pk = 1;
+            a.o_hi = m->hbuf[0]; a.o_pk = 1; a.gelu_lut = m->gelu_lut;
             {
                 ProfScope ps(P_GEMM_FC, s);
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_GELU>(a, s)) != MGPT_OK) return rc;

@@ -212,6 +212,14 @@ __global__ __launch_bounds__(256) void gather_last_kernel(const float *__restric
 enum { PRO_LN = 0, PRO_PLANES = 1 };
 enum { EPI_QK = 0, EPI_VT = 1, EPI_RESID = 2, EPI_GELU = 3 };
 
+// GELU by table: gelu(v) = v Phi(v), Phi = standard normal CDF = (1 + erf(v / sqrt 2)) / 2 (model.py:86, exact-erf GELU).
+// Phi is tabulated on [-6, 6) in steps of 1/256 as pairs (Phi(v_i), Phi(v_i+1) - Phi(v_i)) and interpolated linearly:
+// |error in Phi| <= h^2 / 8 max|Phi''| = 4.6e-7, i.e. <= 4.6e-7 |v| in gelu (the rational approximation used elsewhere has
+// 1.6e-6); beyond +-6 the end entries apply (Phi = 1e-9 / 1 - 1e-9).  24 KiB: the LDS goes to a deeper weight ring.  8 VALU + one 8-byte LDS gather per value instead of
+// 19 VALU: on this kernel the VALU port, which the MFMAs share, is the scarce resource (section 3 of DESIGN.md).
+constexpr int kGeluLutN = 3072;                // entries (float2 each: 24 KiB of LDS)
+constexpr float kGeluLutScale = 256.0f, kGeluLutBias = 1536.0f;
+
 struct GemmArgs {
     // A
     const float *x; const float2 *stats; const float *gain;         // PRO_LN
@@ -227,6 +235,7 @@ struct GemmArgs {
     int64_t plane;                                                   // EPI_QK: elements between the q and the k plane (= M*C)
     int o_pk;                                                        // EPI_GELU: write the hidden planes in PK layout (o_hi = base)
     int chunk_major;                                                 // EPI_QK / EPI_VT: chunk-major q|k and v^T planes (below)
+    const float2 *gelu_lut;                                          // EPI_GELU in gemm_pk_kernel: the Phi table (kGeluLutN pairs) or NULL
 };
 
 // erf(x) ~= x P(x^2) / Q(x^2) on [-4, 4] (|erf| = 1 - 1.5e-8 beyond): max abs error 4.5e-7 in fp32 arithmetic
@@ -289,13 +298,6 @@ __device__ __forceinline__ float gelu_folded(float v)
     return fmaf(hv, e, hv);
 }
 
-// GELU by table: gelu(v) = v Phi(v), Phi = standard normal CDF = (1 + erf(v / sqrt 2)) / 2 (model.py:86, exact-erf GELU).
-// Phi is tabulated on [-6, 6) in steps of 1/256 as pairs (Phi(v_i), Phi(v_i+1) - Phi(v_i)) and interpolated linearly:
-// |error in Phi| <= h^2 / 8 max|Phi''| = 4.6e-7, i.e. <= 4.6e-7 |v| in gelu (the rational approximation used elsewhere has
-// 1.6e-6); beyond +-6 the end entries apply (Phi = 1e-9 / 1 - 1e-9).  24 KiB: the LDS goes to a deeper weight ring.  8 VALU + one 8-byte LDS gather per value instead of
-// 19 VALU: on this kernel the VALU port, which the MFMAs share, is the scarce resource (section 3 of DESIGN.md).
-constexpr int kGeluLutN = 3072;                // entries (float2 each: 24 KiB of LDS)
-constexpr float kGeluLutScale = 256.0f, kGeluLutBias = 1536.0f;
 
 // gelu_folded on two values with packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32): the same operations in the same order,
 // so the same results.  Pays in the one-wave-per-SIMD GEMM epilogue, where an instruction costs ~5 cycles whatever it does
@@ -336,7 +338,7 @@ __device__ __forceinline__ size_t pk_off(int64_t m, int k, int pl, int KS, int N
 // tile wn*TN+j) of the block; swapped orientation (EPI != EPI_VT): lane = token, registers = output columns.
 template <class T, int NP, int EPI, int TM, int TN, int WN>
 __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn,
-                                                int r, int h)
+                                                int r, int h, unsigned lut_addr = 0u)
 {
     const float os = p.out_scale;
     if (EPI == EPI_VT) {
@@ -388,7 +390,22 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
                         acc[i][j][4 * gq + 2] = cur[2]; acc[i][j][4 * gq + 3] = cur[3];
                         rsum[i] += (cur[0] + cur[1]) + (cur[2] + cur[3]);
                     } else if (EPI == EPI_GELU) {
-                        if (TM * TN >= 16) {                 // one-wave-per-SIMD kernel: packed math
+                        if (lut_addr != 0u) {                // Phi table in LDS (gemm_pk_kernel): 8 VALU + one gather per value
+                            float fr[4];
+                            f32x2 tb[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float tt = __builtin_amdgcn_fmed3f(fmaf(v[e], kGeluLutScale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.002f);
+                                fr[e] = __builtin_amdgcn_fractf(tt);
+                                asm volatile("ds_read_b64 %0, %1" : "=v"(tb[e]) : "v"(lut_addr + (unsigned)tt * 8u) : "memory");
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                asm volatile("" : "+v"(tb[e]));
+                                v[e] *= fmaf(fr[e], tb[e][1], tb[e][0]);
+                            }
+                        } else if (TM * TN >= 16) {          // one-wave-per-SIMD kernel: packed math
                             const f32x2 g0 = gelu_folded2((f32x2){v[0], v[1]}), g1 = gelu_folded2((f32x2){v[2], v[3]});
                             v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
                         } else {
@@ -714,6 +731,16 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
         }
     };
+    unsigned lut_addr = 0u;
+    if (EPI == EPI_GELU && p.gelu_lut != nullptr) {        // (uniform) Phi table behind the ring, older than every ring piece
+        unsigned char *dst = smem + (size_t)NST * STAGE;
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(p.gelu_lut);
+#pragma unroll
+        for (int i = 0; i < kGeluLutN * 8 / 1024 / NWV; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)(wave + NWV * i) * 1024 + lane * 16),
+                                             (lds_void_t *)(dst + (size_t)(wave + NWV * i) * 1024), 16, 0, 0);
+        lut_addr = (unsigned)(size_t)dst;
+    }
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; s_++) issue(s_);        // K >= 16 * NST is checked by the launcher
 
@@ -771,7 +798,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
         step(s_, 0);
         step(s_ + 1, 1);
     }
-    gemm16_epilogue<T, NP, EPI, TM, TN, 2>(p, acc, (int64_t)mt * 256, nt * 256, wm, wn, r, h);
+    gemm16_epilogue<T, NP, EPI, TM, TN, 2>(p, acc, (int64_t)mt * 256, nt * 256, wm, wn, r, h, lut_addr);
 }
 
 // ---------------------------------------------------------------------------------------------
