@@ -75,6 +75,18 @@ constexpr int kM256Steps = 2 + 4 * 32 + 2;     // c_fc(0) | 32 x 4 mixed steps |
 
 // (GELU table: kGeluLut* in gpt_kernels_fast.h)
 
+// one 1-KiB direct global->LDS piece at byte offset 1024 * i from (src, dst): the instruction's immediate offset applies to
+// the global and to the LDS address alike, so the PW pieces of a step share one 64-bit address and one M0 value
+__device__ __forceinline__ void dma_piece(const unsigned char *src, unsigned char *dst, std::integral_constant<int, 0>, int i)
+{
+    switch (i) {                                            // i is a compile-time constant after unrolling
+    case 0: __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)dst, 16, 0, 0); break;
+    case 1: __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)dst, 16, 1024, 0); break;
+    case 2: __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)dst, 16, 2048, 0); break;
+    default: __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)dst, 16, 3072, 0); break;
+    }
+}
+
 template <class T, int NP>
 __global__ __launch_bounds__(256) void pack_mlp256_kernel(const float *__restrict__ fc_w, const float *__restrict__ pj_w,
                                                           uint16_t *__restrict__ out, float scale1, float scale2)
@@ -161,8 +173,8 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
         const unsigned char *src = wbase + (size_t)src_step * STEP;                                              // scalar address math
         unsigned char *dst = smem + (size_t)slot * STEP + (size_t)(wave * PW) * 1024;
 #pragma unroll
-        for (int i = 0; i < PW; i++)
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024 + lane16), (lds_void_t *)(dst + i * 1024), 16, 0, 0);
+        for (int i = 0; i < PW; i++)                         // one address pair and one M0 value per step: the pieces of a wave are
+            dma_piece(src + lane16, dst, std::integral_constant<int, 0>{}, i);   // contiguous on both sides (immediate offsets)
     };
 #pragma unroll
     for (int s_ = 0; s_ < NSLOT - 1; s_++) issue(s_, s_);
@@ -487,8 +499,8 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
         const unsigned char *src = wbase + (size_t)G * STEP;
         unsigned char *dst = smem + (size_t)(G % NSLOT) * STEP + (size_t)(wave * PW) * 1024;
 #pragma unroll
-        for (int i = 0; i < PW; i++)
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024 + lane16), (lds_void_t *)(dst + i * 1024), 16, 0, 0);
+        for (int i = 0; i < PW; i++)                         // one address pair and one M0 value per step: the pieces of a wave are
+            dma_piece(src + lane16, dst, std::integral_constant<int, 0>{}, i);   // contiguous on both sides (immediate offsets)
     };
 #pragma unroll
     for (int G = 0; G < NSLOT - 1; G++) issue(G);
