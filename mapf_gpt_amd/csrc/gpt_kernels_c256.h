@@ -495,15 +495,18 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
     const bool full = !LAST || wave == NW - 1;             // wave-uniform: does this wave run the attention?
     int gstep = 0;
 
-    auto issue = [&](int G) {                              // global step G -> slot G % NSLOT
+    // NSLOT = 5 is not a power of two: the ring position is carried in two scalars (slot of the step about to run, and of
+    // the one before it = the slot that is refilled) instead of three `% NSLOT` per step (PMC: 0.9 SALU per MFMA before)
+    int slot_cur = 0, slot_prev = NSLOT - 1;
+    auto issue = [&](int G, int slot) {                    // global step G -> slot G % NSLOT (passed in)
         const unsigned char *src = wbase + (size_t)G * STEP;
-        unsigned char *dst = smem + (size_t)(G % NSLOT) * STEP + (size_t)(wave * PW) * 1024;
+        unsigned char *dst = smem + (size_t)slot * STEP + (size_t)(wave * PW) * 1024;
 #pragma unroll
         for (int i = 0; i < PW; i++)                         // one address pair and one M0 value per step: the pieces of a wave are
             dma_piece(src + lane16, dst, std::integral_constant<int, 0>{}, i);   // contiguous on both sides (immediate offsets)
     };
 #pragma unroll
-    for (int G = 0; G < NSLOT - 1; G++) issue(G);
+    for (int G = 0; G < NSLOT - 1; G++) issue(G, G);
 
     // ---- LayerNorm of this lane's token; operand planes in registers ----
     u32x4 xn[KS][2];
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
         if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3) + NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3)) : "memory");
         if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
-        if (!(ABL & 1) && gstep + NSLOT - 1 < NSTEP) issue(gstep + NSLOT - 1);
+        if (!(ABL & 1) && gstep + NSLOT - 1 < NSTEP) issue(gstep + NSLOT - 1, slot_prev);   // (gstep + NSLOT - 1) % NSLOT
         gstep++;
     };
     // (all asm destinations are arch VGPRs here: with no "a" constraint in the kernel hipcc gives the whole 256-register
@@ -572,9 +575,12 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
     };
     unsigned cur_addr = 0, nxt_addr = 0;
     auto step_begin = [&](bool stores_younger) {
-        sync(stores_younger);
-        cur_addr = lds0 + (unsigned)((gstep - 1) % NSLOT) * STEP;
-        nxt_addr = lds0 + (unsigned)(gstep % NSLOT) * STEP;
+        sync(stores_younger);                              // the step that runs now is gstep - 1, in slot_cur
+        const int slot_next = slot_cur + 1 == NSLOT ? 0 : slot_cur + 1;
+        cur_addr = lds0 + (unsigned)slot_cur * STEP;
+        nxt_addr = lds0 + (unsigned)slot_next * STEP;
+        slot_prev = slot_cur;
+        slot_cur = slot_next;
     };
     // chunk c of a step uses pairs 2c, 2c+1 (set c & 1), requested one chunk earlier; it requests the pairs of the next chunk
     auto chunk_begin = [&](auto c_c, bool has_next) {
