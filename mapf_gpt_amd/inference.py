@@ -144,17 +144,54 @@ class MAPFGPTInference:
         return self.act_batch([observations])[0]                                             # inference.py:148-149
 
     def act_batch(self, observations_list, positions=None):
-        """= inference.py:151-172: rows of many envs -> one forward -> split back per env."""
+        """= inference.py:151-172: rows of many envs -> one forward -> split back per env.
+        Host side of the reference-shaped call: the positions, goals and fed-back actions of ALL environments of the call
+        travel in ONE host-to-device copy, and every environment's tokenizer writes its rows straight into its slice of one
+        [total_rows, 256] tensor (no per-environment copies, no concatenation)."""
         if positions is None:
             positions = list(range(len(observations_list)))
-        all_inputs, env_agent_counts = [], []
-        for pos, observations in zip(positions, observations_list):
-            inputs = self._prepare_inputs(pos, observations)
-            all_inputs.append(inputs)
-            env_agent_counts.append(int(inputs.shape[0]))
-        all_actions = self._forward_batch(torch.cat(all_inputs, dim=0))
+        counts = [len(o) for o in observations_list]
+        total = sum(counts)
+        tokens = torch.empty((total, 256), dtype=torch.uint8, device=self.cfg.device)
+        is_env = [len(o) > 0 and isinstance(o[0], dict) for o in observations_list]
+        n_dict = sum(c for c, e in zip(counts, is_env) if e)
+        if n_dict:
+            # staging buffer: [actions int32 | positions int16 x2 | goals int16 x2] of every dict-observation env, in call order
+            buf = np.empty(12 * n_dict, dtype=np.uint8)
+            acts, xy, gxy = buf[:4 * n_dict].view(np.int32), buf[4 * n_dict:8 * n_dict].view(np.int16), buf[8 * n_dict:].view(np.int16)
+            o = 0
+            for pos, observations, n, env in zip(positions, observations_list, counts, is_env):
+                if not env:
+                    continue
+                xy[2 * o:2 * (o + n)] = np.asarray([obs["global_xy"] for obs in observations], dtype=np.int16).reshape(-1)
+                gxy[2 * o:2 * (o + n)] = np.asarray([obs["global_target_xy"] for obs in observations], dtype=np.int16).reshape(-1)
+                acts[o:o + n] = self._last_actions[pos] if pos in self._obs_generators else -1      # inference.py:140
+                o += n
+            dev = torch.from_numpy(buf).to(self.cfg.device)
+            d_act = dev[:4 * n_dict].view(torch.int32)
+            d_xy = dev[4 * n_dict:8 * n_dict].view(torch.int16).view(n_dict, 2)
+            d_gxy = dev[8 * n_dict:].view(torch.int16).view(n_dict, 2)
+        row, o = 0, 0
+        for pos, observations, n, env in zip(positions, observations_list, counts, is_env):
+            out = tokens[row:row + n]
+            if env:
+                p, g, a = d_xy[o:o + n].view(1, n, 2), d_gxy[o:o + n].view(1, n, 2), d_act[o:o + n].view(1, n)
+                if pos not in self._obs_generators:                                               # inference.py:133-140
+                    grid = np.asarray(observations[0]["global_obstacles"]).copy().astype(int)
+                    gen = BatchedTokenizer(grid, 1, n, self.input_parameters, device=self.cfg.device)
+                    gen.create_agents(p, g)
+                    self._obs_generators[pos] = gen
+                    self._last_actions[pos] = [-1] * n
+                gen = self._obs_generators[pos]
+                gen.update_agents(p, g, a, goals_may_change=True)                                 # inference.py:142-144
+                gen.generate_observations(out)                                                    # inference.py:145
+                o += n
+            elif n:
+                out.copy_(self._prepare_inputs(pos, observations))                                # inference.py:146 (pre-tokenised)
+            row += n
+        all_actions = self._forward_batch(tokens)
         results, offset = [], 0
-        for pos, count in zip(positions, env_agent_counts):
+        for pos, count in zip(positions, counts):
             env_actions = all_actions[offset:offset + count]
             self._last_actions[pos] = list(env_actions)                                      # inference.py:168
             results.append(env_actions)
