@@ -56,7 +56,7 @@ class BatchedTokenizer:
         self.n_inst, self.n_agents = int(n_inst), int(n_agents)
         self._h = ctypes.c_void_p()
         st = cfg._struct()
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             _lib.check(_lib.lib().mgpt_tokenizer_create(ctypes.byref(self._h), ctypes.byref(st), self.n_inst,
                                                         self.n_agents, self.H, self.W, self.n_grids))
             _lib.check(_lib.lib().mgpt_tokenizer_set_grids(self._h, _lib.ptr(self.grids), _lib.stream_ptr()))
@@ -78,7 +78,7 @@ class BatchedTokenizer:
     def create_agents(self, pos, goal):
         shp = (self.n_inst, self.n_agents, 2)
         pos, goal = self._chk(pos, torch.int16, shp), self._chk(goal, torch.int16, shp)
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             _lib.check(_lib.lib().mgpt_tokenizer_create_agents(self._h, _lib.ptr(pos), _lib.ptr(goal), _lib.stream_ptr()))
 
     def update_agents(self, pos, goal, actions, goals_may_change=True):
@@ -86,7 +86,7 @@ class BatchedTokenizer:
         pos = self._chk(pos, torch.int16, shp)
         goal = self._chk(goal, torch.int16, shp)
         actions = self._chk(actions, torch.int32, (self.n_inst, self.n_agents))
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             _lib.check(_lib.lib().mgpt_tokenizer_update_agents(self._h, _lib.ptr(pos), _lib.ptr(goal), _lib.ptr(actions),
                                                                1 if goals_may_change else 0, _lib.stream_ptr()))
 
@@ -96,21 +96,21 @@ class BatchedTokenizer:
             out = torch.empty((self.rows, 256), dtype=torch.uint8, device=self.device)
         else:
             out = self._chk(out, torch.uint8, (self.rows, 256))
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             _lib.check(_lib.lib().mgpt_tokenizer_generate_observations(self._h, _lib.ptr(out), _lib.stream_ptr()))
         return out
 
     def distance_fields(self):
         """debug/test read-back: uint16 [n_inst, n_agents, H, W] (numpy, host)."""
         out = torch.empty(self.rows * self.H * self.W, dtype=torch.int16, device=self.device)
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             _lib.check(_lib.lib().mgpt_tokenizer_copy_state(self._h, _lib.ptr(out), None, _lib.stream_ptr()))
         return out.cpu().numpy().view(np.uint16).reshape(self.n_inst, self.n_agents, self.H, self.W)
 
     def records(self):
         """debug/test read-back of the 16-byte agent records -> dict of numpy arrays [n_inst, n_agents, ...]."""
         out = torch.empty(self.rows * 16, dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             _lib.check(_lib.lib().mgpt_tokenizer_copy_state(self._h, None, _lib.ptr(out), _lib.stream_ptr()))
         raw = out.cpu().numpy().reshape(self.n_inst, self.n_agents, 16)
         xy = raw[..., :8].copy().view(np.int16)

@@ -102,7 +102,7 @@ class BatchedRunner:
 
     def step(self):
         """update_agents -> generate_observations -> act -> env.step in ONE library call (mgpt_step_run)."""
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             _lib.check(_lib.lib().mgpt_step_run(self._step, _lib.ptr(self.tokens), _lib.ptr(self.actions.view(-1)),
                                                 1 if self.env.lifelong else 0, 1 if self.use_graph else 0, _lib.stream_ptr()))
         self.t += 1
