@@ -49,6 +49,20 @@ int main()
         run<0>("mlp256_kernel  (4 waves x 32 tokens, 1 wave/SIMD)", x, gain, ws, lut, M);
         run<1>("mlp256w_kernel (8 waves x 16 tokens, 2 waves/SIMD)", x, gain, ws, lut, M);
     }
+    {   // the same kernels on constant operands (every token row and every weight fragment identical): same instruction stream,
+        // far fewer bits toggling -- separates "issue bound" from "what the chip sustains under load"
+        std::vector<float> hc((size_t)M * 256);
+        for (size_t i = 0; i < hc.size(); i++) hc[i] = (float)(i & 255) / 256.f - 0.5f;        // every row the same ramp
+        hipMemcpy(x, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
+        std::vector<uint16_t> hwc(n16, (uint16_t)0x2e66);                                         // 0.1 in fp16 everywhere
+        hipMemcpy(ws, hwc.data(), n16 * 2, hipMemcpyHostToDevice);
+        run<0>("mlp256_kernel,  constant rows and weights", x, gain, ws, lut, M);
+        run<1>("mlp256w_kernel, constant rows and weights", x, gain, ws, lut, M);
+        run<0>("mlp256_kernel,  constant rows and weights", x, gain, ws, lut, M);
+        run<1>("mlp256w_kernel, constant rows and weights", x, gain, ws, lut, M);
+        hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(ws, hw.data(), n16 * 2, hipMemcpyHostToDevice);
+    }
     run<1, 1>("mlp256w: no table gathers", x, gain, ws, lut, M);
     run<1, 2>("mlp256w: MFMA / VALU order left to hipcc", x, gain, ws, lut, M);
     run<1, 4>("mlp256w: no GELU arithmetic", x, gain, ws, lut, M);
