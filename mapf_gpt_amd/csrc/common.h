@@ -12,6 +12,12 @@ namespace mgpt {
 
 void set_error(const char *fmt, ...);
 
+// Library-wide allocation generation: bumped whenever a context frees or re-allocates device memory that a captured step
+// graph may have baked in (weight planes and workspaces at finalize / lazy mode build, lifelong goal queues).  mgpt_step
+// compares it with the value it saw at its last step and, on a change, drops its graph and runs one eager step first.
+uint64_t alloc_generation();
+void bump_alloc_generation();
+
 #define MGPT_HIP(call)                                                                     \
     do {                                                                                   \
         hipError_t e__ = (call);                                                           \

@@ -314,6 +314,7 @@ extern "C" int mgpt_env_set_lifelong(mgpt_env *e, const int16_t *d_goal_queue, i
 {
     MGPT_REQUIRE(e, MGPT_ERR_ARG, "NULL argument");
     hipStream_t s = (hipStream_t)stream;
+    bump_alloc_generation();                             // a captured step graph holds the queue pointers (or their absence)
     (void)hipFree(e->goal_queue); (void)hipFree(e->qnext); (void)hipFree(e->reached);
     e->goal_queue = nullptr; e->qnext = nullptr; e->reached = nullptr; e->queue_len = 0;
     if (d_goal_queue == nullptr || queue_len <= 0) return MGPT_OK;          // back to on_target = "nothing"

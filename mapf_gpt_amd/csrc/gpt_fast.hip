@@ -97,6 +97,7 @@ template <class T, int NP>
 int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
 {
     const size_t C = g->C;
+    bump_alloc_generation();                             // a step graph captured before this build must not be replayed as is
     std::vector<float> host(g->n_params);
     MGPT_HIP(hipMemcpy(host.data(), g->params, g->n_params * sizeof(float), hipMemcpyDeviceToHost));
     m->np = NP;
@@ -262,6 +263,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
 
 void free_mode(ModeState *m)
 {
+    if (m->built) bump_alloc_generation();               // captured step graphs hold these pointers
     auto fr = [](std::vector<PlaneSet> &v) { for (auto &p : v) { (void)hipFree(p.hi); (void)hipFree(p.lo); } v.clear(); };
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
     for (auto *p : m->mlp_pk) (void)hipFree(p);

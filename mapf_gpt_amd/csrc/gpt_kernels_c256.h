@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void pack_mlp256_kernel(const float *__restric
 }
 
 // ABL (tools/probe_mlp256.hip only; the library instantiates ABL = 0): 1 no weight DMA in the loop, 2 no GELU table gather,
-// 4 no barrier, 8 no MFMAs, 16 no fragment reads in the loop -- results are wrong unless ABL == 0.
+// 4 no barrier, 8 no MFMAs, 16 no fragment reads in the loop -- results are wrong unless ABL == 0.  32: wave 0 of every
+// block leaves (s_memtime, s_memrealtime) at kernel entry / first ring step / after the last step / exit in stamps[block][8].
 //
 // Register plan (one wave per SIMD, 512 registers): operand planes xn 128 + hidden planes 2 x 16 + GELU temporaries in the
 // arch VGPRs; output accumulators 128 + pre-activation accumulators 2 x 16 + weight fragments 32 in the accumulator file.
@@ -144,9 +145,12 @@ __global__ __launch_bounds__(256) void pack_mlp256_kernel(const float *__restric
 template <class T, int NP, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                         const uint16_t *__restrict__ wstream, float inv1, float inv2,
-                                                        const float2 *__restrict__ gelu_lut)
+                                                        const float2 *__restrict__ gelu_lut, unsigned long long *stamps = nullptr)
 {
     constexpr int C = 256, CT = 8, KS = 16, NT = 32;
+    unsigned long long tstamp[8];
+    auto stamp = [&](int i) { if constexpr ((ABL & 32) != 0) { tstamp[2 * i] = __builtin_readcyclecounter(); tstamp[2 * i + 1] = wall_clock64(); } };
+    stamp(0);
     constexpr int MS = 8;                                  // fragment pairs per step
     constexpr int STEP = MS * NP * 1024;                   // bytes per step
     constexpr int NSLOT = 8;
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
         };
         chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
     };
+    stamp(1);
     step_fc0(0, true);
     step_fc0(1, false);
 #pragma unroll
@@ -390,6 +395,7 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
     };
     step_pj31(2 + 4 * NT, false);
     step_pj31(2 + 4 * NT + 1, true);
+    stamp(2);
 
     // ---- residual add and store ----
 #pragma unroll
@@ -402,6 +408,13 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
             for (int e = 0; e < 4; e++) cur[e] += acc[j][4 * gq + e] * inv2;
             *dst = cur;
         }
+    if constexpr ((ABL & 32) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3);
+        if (tid == 0)
+#pragma unroll
+            for (int i = 0; i < 8; i++) stamps[(size_t)blockIdx.x * 8 + i] = tstamp[i];
+    }
 }
 
 // (Fusing the attention out-projection in front of this kernel -- 16 more stream steps on the y operand planes, new residual

@@ -1,6 +1,7 @@
 // prof.hip -- error string, ABI version, device count and the event-timing hooks.
 #include <stdarg.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -17,6 +18,10 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+static std::atomic<uint64_t> g_alloc_generation{1};
+uint64_t alloc_generation() { return g_alloc_generation.load(std::memory_order_acquire); }
+void bump_alloc_generation() { g_alloc_generation.fetch_add(1, std::memory_order_acq_rel); }
 
 static const char *kProfNames[P_COUNT] = {
     "bfs_distance_field", "tok_update_agents", "tok_next_action", "tok_generate_observations",

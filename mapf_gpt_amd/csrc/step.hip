@@ -36,6 +36,7 @@ struct mgpt_step {
     const int32_t *cap_actions = nullptr;
     int cap_gmc = -1;
     bool capture_failed = false;
+    uint64_t seen_gen = 0;                      // mgpt::alloc_generation() after our last step (0: never ran)
 };
 
 namespace {
@@ -110,10 +111,19 @@ extern "C" int mgpt_step_run(mgpt_step *st, uint8_t *d_tokens, int32_t *d_action
     MGPT_REQUIRE(st && d_tokens && d_actions, MGPT_ERR_ARG, "NULL argument");
     hipStream_t s = (hipStream_t)stream;
     const int gmc = goals_may_change ? 1 : 0;
+    // a context re-allocated or freed device memory since our last step (weights reloaded -> planes freed and rebuilt lazily,
+    // goal queues replaced): the graph holds dead pointers, and the rebuild (hipMalloc, synchronous copies, null-stream pack
+    // kernels) must not happen inside a capture -> drop the graph and run one eager step first
+    if (alloc_generation() != st->seen_gen) {
+        drop_graph(st);
+        st->eager_runs = 0;
+    }
     // eager: first step (lazy weight-plane build allocates), timing hooks on (their events belong to the eager stream), opt-out
     if (!use_graph || st->capture_failed || st->eager_runs < 1 || prof_is_enabled()) {
         st->eager_runs++;
-        return step_body(st, d_tokens, d_actions, gmc, s);
+        const int rc = step_body(st, d_tokens, d_actions, gmc, s);
+        st->seen_gen = alloc_generation();     // (the lazy build inside this step bumped it)
+        return rc;
     }
     if (!st->exec || st->cap_tokens != d_tokens || st->cap_actions != d_actions || st->cap_gmc != gmc) {
         drop_graph(st);

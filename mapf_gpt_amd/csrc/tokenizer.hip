@@ -335,7 +335,8 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
                 // in-window neighbours, whose values are exact border seeds (cpp:252-268)
                 const int n1 = (int)d[(uint32_t)(centre + off1 - W)], n2 = (int)d[(uint32_t)(centre + off1 - 1)];
                 const int m = min(n1, n2);
-                if (w1[q] != UNR && w1[q] != 0) w1[q] = (m == UNR) ? UNR : m + 1;
+                // (one-byte field: UNR = 255, so m + 1 is kept below the sentinel; any value > centre + 20 encodes the same token)
+                if (w1[q] != UNR && w1[q] != 0) w1[q] = (m == UNR) ? UNR : min(m + 1, UNR - 1);
             }
         } else if (st == 0) {                                           // out-of-frame cells read as walls
             const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);

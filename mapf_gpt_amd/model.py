@@ -150,8 +150,11 @@ class GPT:
             probs = torch.softmax(logits[:, :5], dim=-1)                       # model.py:250-254
             nxt = torch.multinomial(probs, num_samples=1, generator=generator)  # model.py:257
             return nxt.squeeze()
-        if do_sample and self._act_calls == 0:
-            self._act_seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # follows torch.manual_seed
+        if do_sample and (not hasattr(self, "_act_seed") or self._act_torch_seed != torch.initial_seed()):
+            # drawn lazily at the first SAMPLED call (a greedy first call must not pin seed 0) and re-drawn whenever
+            # torch.manual_seed was called since: the reference's multinomial follows the global RNG in both cases
+            self._act_torch_seed = torch.initial_seed()
+            self._act_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         step = self._act_calls
         self._act_calls += 1
         return self.act_tokens(tokens, do_sample=do_sample, seed=getattr(self, "_act_seed", 0), step=step).to(torch.int64).squeeze()

@@ -3,17 +3,103 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
+#include <algorithm>
 #include <vector>
 #include "../mapf_gpt_amd/csrc/gpt_kernels_c256.h"
 namespace mgpt { void set_error(const char *, ...) {} }
 using namespace mgpt::fastk;
 
+static float2 *phi_table()
+{
+    static float2 *lut = nullptr;
+    if (lut) return lut;
+    std::vector<float2> h(kGeluLutN);
+    auto phi = [](double v) { return 0.5 * (1.0 + erf(v * 0.70710678118654752440)); };
+    for (int i = 0; i < kGeluLutN; i++) {
+        const double v0 = (i - (double)kGeluLutBias) / kGeluLutScale, v1 = (i + 1 - (double)kGeluLutBias) / kGeluLutScale;
+        const float f0 = (float)phi(v0);
+        h[i] = make_float2(f0, (float)(phi(v1) - (double)f0));
+    }
+    hipMalloc(&lut, kGeluLutN * 8);
+    hipMemcpy(lut, h.data(), kGeluLutN * 8, hipMemcpyHostToDevice);
+    return lut;
+}
+
+// where a block spends its cycles: s_memtime / s_memrealtime stamps of wave 0 (entry, first ring step, after the last step, exit)
+void run_stamps(float *x, const float *gain, const uint16_t *ws, int M)
+{
+    const size_t lds = 8 * 8 * 2 * 1024 + kGeluLutN * 8;
+    const int grid = M / 128;
+    unsigned long long *st; hipMalloc(&st, (size_t)grid * 64);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256_kernel<F16T, 2, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int it = 0; it < 3; it++) mlp256_kernel<F16T, 2, 32><<<grid, 256, lds>>>(x, gain, ws, 1e-3f, 1e-3f, phi_table(), st);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+    double pro = 0, loop = 0, epi = 0, tot = 0, rt = 0;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int b = 0; b < grid; b++) {
+        const unsigned long long *s = &h[(size_t)b * 8];
+        pro += (double)(s[2] - s[0]); loop += (double)(s[4] - s[2]); epi += (double)(s[6] - s[4]); tot += (double)(s[6] - s[0]); rt += (double)(s[7] - s[1]);
+        t0 = std::min(t0, s[1]); t1 = std::max(t1, s[7]);
+    }
+    printf("stamps (mean over %d blocks, shader cycles): prologue %.0f  ring loop %.0f (%.1f per step)  epilogue %.0f  total %.0f;  "
+           "block wall %.2f us (100 MHz ticks) -> shader clock %.3f GHz;  kernel span %.3f ms\n", grid, pro / grid, loop / grid, loop / grid / kM256Steps,
+           epi / grid, tot / grid, rt / grid / 100.0, (tot / grid) / (rt / grid / 100.0) / 1e3, (double)(t1 - t0) / 1e5);
+}
+
+// sustained: n launches back to back, one event per `every` launches -> does the launch time drift as the chip settles at its power limit?
+void run_sustained(const char *tag, float *x, const float *gain, const uint16_t *ws, int M, int n, int every)
+{
+    const size_t lds = 8 * 8 * 2 * 1024 + kGeluLutN * 8;
+    const int grid = M / 128;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256_kernel<F16T, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::vector<hipEvent_t> ev(n / every + 1);
+    for (auto &e : ev) hipEventCreate(&e);
+    hipEventRecord(ev[0]);
+    for (int i = 0; i < n; i++) {
+        mlp256_kernel<F16T, 2, 0><<<grid, 256, lds>>>(x, gain, ws, 1e-3f, 1e-3f, phi_table());
+        if ((i + 1) % every == 0) hipEventRecord(ev[(i + 1) / every]);
+    }
+    hipDeviceSynchronize();
+    printf("sustained %s: ms per launch over consecutive groups of %d:", tag, every);
+    for (int k = 1; k <= n / every; k++) { float ms; hipEventElapsedTime(&ms, ev[k - 1], ev[k]); printf(" %.3f", ms / every); }
+    printf("\n");
+}
+
+// ABL variant on whatever operands are resident: 100 launches timed, then one stamped launch (ABL | 32) for cycles and clock
+template <int ABL>
+void run_real(const char *tag, float *x, const float *gain, const uint16_t *ws, int M, float i1, float i2)
+{
+    const size_t lds = 8 * 8 * 2 * 1024 + kGeluLutN * 8;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256_kernel<F16T, 2, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256_kernel<F16T, 2, ABL | 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 40; i++) mlp256_kernel<F16T, 2, ABL><<<M / 128, 256, lds>>>(x, gain, ws, i1, i2, phi_table());
+    hipEventRecord(e0);
+    for (int i = 0; i < 100; i++) mlp256_kernel<F16T, 2, ABL><<<M / 128, 256, lds>>>(x, gain, ws, i1, i2, phi_table());
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    static unsigned long long *stp = nullptr;
+    if (!stp) hipMalloc(&stp, (size_t)(M / 128) * 64);
+    mlp256_kernel<F16T, 2, ABL | 32><<<M / 128, 256, lds>>>(x, gain, ws, i1, i2, phi_table(), stp);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)(M / 128) * 8);
+    hipMemcpy(h.data(), stp, h.size() * 8, hipMemcpyDeviceToHost);
+    double tot = 0, rt = 0, pro = 0, epi = 0;
+    const int nb = M / 128;
+    for (int b = 0; b < nb; b++) { tot += (double)(h[8 * b + 6] - h[8 * b]); rt += (double)(h[8 * b + 7] - h[8 * b + 1]); pro += (double)(h[8 * b + 2] - h[8 * b]); epi += (double)(h[8 * b + 6] - h[8 * b + 4]); }
+    printf("real operands  %-36s %.3f ms/launch (100 launches)  %7.0f cycles/block (prologue %5.0f, loop %6.0f, epilogue %5.0f)  clock %.3f GHz\n", tag, ms / 100,
+           tot / nb, pro / nb, (tot - pro - epi) / nb, epi / nb, tot / rt / 10.0);
+    (void)hipGetLastError();
+}
+
 template <int ABL>
 void run(const char *tag, float *x, const float *gain, const uint16_t *ws, int M, int grid = 0)
 {
     const size_t lds = 8 * 8 * 2 * 1024 + kGeluLutN * 8;
-    static float2 *lut = nullptr;
-    if (!lut) { hipMalloc(&lut, kGeluLutN * 8); hipMemset(lut, 0, kGeluLutN * 8); }
+    float2 *lut = phi_table();
     if (grid == 0) grid = M / 128;
     hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256_kernel<F16T, 2, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -51,5 +137,51 @@ int main()
     run<23>("no DMA/barrier/GELU/reads (MFMA only)", x, gain, ws, M);
     run<8>("no MFMAs", x, gain, ws, M);
     run<0>("product again", x, gain, ws, M);
+    run_stamps(x, gain, ws, M);
+    run_sustained("pseudo-random rows", x, gain, ws, M, 400, 20);
+    run_stamps(x, gain, ws, M);
+    {   // realistic operands: N(0, 1) residual rows, c_fc / c_proj ~ N(0, 0.02) split into hi / lo planes by the library's packer
+        auto gauss = [](uint64_t &st) {
+            auto u = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)((st >> 11) + 1) / 9007199254740993.0; };
+            return (float)(sqrt(-2.0 * log(u())) * cos(6.283185307179586 * u()));
+        };
+        uint64_t st = 12345;
+        for (size_t i = 0; i < hx.size(); i++) hx[i] = gauss(st);
+        hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+        std::vector<float> w1((size_t)1024 * 256), w2((size_t)256 * 1024);
+        float mx1 = 0, mx2 = 0;
+        for (auto &v : w1) { v = 0.02f * gauss(st); mx1 = std::max(mx1, fabsf(v)); }
+        for (auto &v : w2) { v = 0.02f * gauss(st); mx2 = std::max(mx2, fabsf(v)); }
+        const float sc1 = ldexpf(1.f, (int)floorf(log2f(4096.f / mx1))), sc2 = ldexpf(1.f, (int)floorf(log2f(4096.f / mx2)));
+        float *d1, *d2; hipMalloc(&d1, w1.size() * 4); hipMalloc(&d2, w2.size() * 4);
+        hipMemcpy(d1, w1.data(), w1.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice);
+        pack_mlp256_kernel<F16T, 2><<<(kM256Steps * 8 * 64 + 255) / 256, 256>>>(d1, d2, ws, sc1, sc2);
+        hipDeviceSynchronize();
+        const size_t lds = 8 * 8 * 2 * 1024 + kGeluLutN * 8;
+        // (inv scales as the library passes them; x is overwritten by x + mlp(x) every launch: rows drift, LayerNorm renormalises)
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int rep = 0; rep < 4; rep++) {
+            hipEventRecord(e0);
+            for (int i = 0; i < 100; i++) mlp256_kernel<F16T, 2, 0><<<M / 128, 256, lds>>>(x, gain, ws, 1.f / sc1, 1.f / sc2, phi_table());
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("realistic operands (N(0,1) rows, N(0,0.02) weights through pack_mlp256_kernel): %.3f ms per launch over 100 launches\n", ms / 100);
+        }
+        run_real<0>("product", x, gain, ws, M, 1.f / sc1, 1.f / sc2);
+        run_real<23>("MFMA only (no DMA/barrier/GELU/reads)", x, gain, ws, M, 1.f / sc1, 1.f / sc2);
+        run_real<8>("no MFMAs", x, gain, ws, M, 1.f / sc1, 1.f / sc2);
+        run_real<2>("no GELU", x, gain, ws, M, 1.f / sc1, 1.f / sc2);
+        run_real<16>("no fragment reads", x, gain, ws, M, 1.f / sc1, 1.f / sc2);
+        run_real<5>("no DMA, no barrier", x, gain, ws, M, 1.f / sc1, 1.f / sc2);
+        run_real<0>("product again", x, gain, ws, M, 1.f / sc1, 1.f / sc2);
+        unsigned long long *stp; hipMalloc(&stp, (size_t)(M / 128) * 64);
+        mlp256_kernel<F16T, 2, 32><<<M / 128, 256, lds>>>(x, gain, ws, 1.f / sc1, 1.f / sc2, phi_table(), stp);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)(M / 128) * 8);
+        hipMemcpy(h.data(), stp, h.size() * 8, hipMemcpyDeviceToHost);
+        double tot = 0, rt = 0, pro = 0, epi = 0;
+        for (int b = 0; b < M / 128; b++) { tot += (double)(h[8 * b + 6] - h[8 * b]); rt += (double)(h[8 * b + 7] - h[8 * b + 1]); pro += (double)(h[8 * b + 2] - h[8 * b]); epi += (double)(h[8 * b + 6] - h[8 * b + 4]); }
+        printf("realistic operands, stamps: %.0f cycles per block (prologue %.0f, epilogue %.0f), shader clock %.3f GHz\n", tot / (M / 128), pro / (M / 128), epi / (M / 128), tot / rt / 10.0);
+    }
     return 0;
 }
