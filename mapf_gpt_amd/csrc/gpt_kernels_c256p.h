@@ -10,16 +10,17 @@
 //     producer p (waves 0-3)   owns the operand planes of 32 tokens (128 registers): LayerNorm, c_fc MFMAs, GELU, and hands
 //                              the hidden planes of every 32-unit tile to its consumer through LDS (4 KiB per tile);
 //     consumer p (waves 4-7)   owns the 32 x 256 output accumulators (128 registers): c_proj MFMAs, residual add and store.
-// Both roles read the SAME weight stream (one 16-KiB step = 4 c_fc fragment pairs + 4 c_proj fragment pairs, consumption
-// order, LayerNorm gain folded into c_fc) from one 6-slot LDS ring filled by direct global->LDS loads, one s_barrier per step.
-// The stream is CYCLIC with period 136 steps per block: the consumer runs 8 steps (two hidden tiles) behind the producer, so
-// the c_proj of a block's last two tiles and its residual write-back overlap the LayerNorm and the first c_fc tiles of the
-// next block:
-//     period step r   producer                                     consumer
-//     0 ..   7        GELU(tile 31 of the previous block);         c_proj(tiles 30, 31 of the previous block)
+// Both roles read the SAME weight stream (one 32-KiB step = 8 c_fc fragment pairs + 8 c_proj fragment pairs = half a hidden
+// tile of each, consumption order, LayerNorm gain folded into c_fc) from one 3-slot LDS ring filled by direct global->LDS
+// loads, one s_barrier per step (24 MFMAs per wave: measured with 16-KiB steps, the two waves of a SIMD lose ~25 % of a step
+// around every barrier).  The stream is CYCLIC with period 68 steps per block: the consumer runs 4 steps (two hidden tiles)
+// behind the producer, so the c_proj of a block's last two tiles and its residual write-back overlap the LayerNorm and the
+// first c_fc tiles of the next block:
+//     period step R   producer                                     consumer
+//     0 ..  3         GELU(tile 31 of the previous block);         c_proj(tiles 30, 31 of the previous block)
 //                     x rows of this block in, LayerNorm, split
-//     8 ..  15        c_fc(tiles 0, 1)                              residual add + store of the previous block, acc = 0
-//     16 .. 135       c_fc(tile t = (r - 8) / 4), GELU(t - 1)       c_proj(tile t - 2)
+//     4 ..  7         c_fc(tiles 0, 1), GELU(tile 0)                residual add + store of the previous block, acc = 0
+//     8 .. 67         c_fc(tile t = (R - 4) / 2), GELU(t - 1)       c_proj(tile t - 2)
 // so per SIMD the matrix pipe always has one wave issuing MFMAs while the other wave does its loads / VALU work.
 // Every LDS / global access inside the block loop is inline asm with hand-counted s_waitcnt (a compiler-visible access makes
 // hipcc drain the LDS-DMA ring with vmcnt(0), gpt_kernels_c256.h); vector-memory operations retire in issue order, so
@@ -31,14 +32,14 @@
 namespace mgpt {
 namespace fastk {
 
-constexpr int kMPPause = 8;                     // steps per block in which a role has no MFMAs (see the table above)
-constexpr int kMPPeriod = 128 + kMPPause;       // stream steps per block
-constexpr int kMPSlots = 6;                     // LDS ring depth (steps)
+constexpr int kMPPause = 4;                     // steps per block in which a role has no MFMAs (see the table above)
+constexpr int kMPPeriod = 64 + kMPPause;        // stream steps per block
+constexpr int kMPSlots = 3;                     // LDS ring depth (steps)
 
 template <int NP>
-constexpr int kMPLds = kMPSlots * 8 * NP * 1024 + kGeluLutN * 8 + 4 * 2 * 2 * NP * 1024;   // ring | Phi table | hidden hand-off
+constexpr int kMPLds = kMPSlots * 16 * NP * 1024 + kGeluLutN * 8 + 4 * 2 * 2 * NP * 1024;   // ring | Phi table | hidden hand-off
 
-// weight stream: [period step r][pair ms][plane][lane][8]; pairs 0-3 = c_fc (gain folded in), 4-7 = c_proj
+// weight stream: [period step R][pair ms][plane][lane][8]; pairs 0-7 = c_fc (gain folded in), 8-15 = c_proj
 template <class T, int NP>
 __global__ __launch_bounds__(256) void pack_mlp256p_kernel(const float *__restrict__ fc_w, const float *__restrict__ pj_w,
                                                            const float *__restrict__ gain, uint16_t *__restrict__ out,
@@ -46,15 +47,15 @@ __global__ __launch_bounds__(256) void pack_mlp256p_kernel(const float *__restri
 {
     constexpr int C = 256;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (step, pair, lane)
-    if (gid >= (int64_t)kMPPeriod * 8 * 64) return;
-    const int lane = (int)(gid & 63), ms = (int)((gid >> 6) & 7), r = (int)(gid >> 9);
+    if (gid >= (int64_t)kMPPeriod * 16 * 64) return;
+    const int lane = (int)(gid & 63), ms = (int)((gid >> 6) & 15), R = (int)(gid >> 10);
     const int i = lane & 31, h = lane >> 5;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = 0.f;
-    if (ms < 4) {                                                         // c_fc(tile t): A rows = hidden units, k-slots = features
-        if (r >= kMPPause) {
-            const int rr = r - kMPPause, t = rr >> 2, ks = 4 * (rr & 3) + ms;
+    if (ms < 8) {                                                         // c_fc(tile t): A rows = hidden units, k-slots = features
+        if (R >= kMPPause) {
+            const int rr = R - kMPPause, t = rr >> 1, ks = 8 * (rr & 1) + ms;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int g = 8 * (ks & 1) + e;
@@ -62,12 +63,12 @@ __global__ __launch_bounds__(256) void pack_mlp256p_kernel(const float *__restri
                 v[e] = fc_w[(size_t)(32 * t + i) * C + feat] * gain[feat] * scale1;   // LayerNorm weight folded in (model.py:19-20, 86)
             }
         }
-    } else {                                                              // c_proj(tile t): A rows = output features of tile j
-        int t = -1, q = 0;
-        if (r < 8) { t = 30 + (r >> 2); q = r & 3; }                      // the previous block's last two tiles
-        else if (r >= kMPPause + 8) { t = (r - kMPPause - 8) >> 2; q = (r - kMPPause - 8) & 3; }
+    } else {                                                              // c_proj(tile t), k-step kk: A rows = output features of tile j
+        int t = -1, kk = 0;
+        if (R < 4) { t = 30 + (R >> 1); kk = R & 1; }                     // the previous block's last two tiles
+        else if (R >= kMPPause + 4) { t = (R - kMPPause - 4) >> 1; kk = (R - kMPPause - 4) & 1; }
         if (t >= 0) {
-            const int idx = 4 * q + (ms - 4), kk = idx >> 3, j = idx & 7;
+            const int j = ms - 8;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int g = 8 * kk + e;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void pack_mlp256p_kernel(const float *__restri
     u32x4 hi, lo;
     hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
     lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
-    uint16_t *dst = out + (((size_t)r * 8 + ms) * NP) * 512 + (size_t)lane * 8;
+    uint16_t *dst = out + (((size_t)R * 16 + ms) * NP) * 512 + (size_t)lane * 8;
     *reinterpret_cast<u32x4 *>(dst) = hi;
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
 }
@@ -94,20 +95,21 @@ __device__ __forceinline__ void vm_wait()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// STAMPS (tools/probe_mlp256p.hip only): wave 0 and wave 4 of every workgroup leave s_memtime / s_memrealtime at entry and exit.
+// STAMPS (tools/check_mlp256p.hip only): 1 = wave 0 and wave 4 of every workgroup leave s_memtime / s_memrealtime at entry and
+// exit; 2 = cycles spent in wait + barrier instead of the exit wall clock.
 template <class T, int NP, int STAMPS = 0>
 __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv1,
                                                          float inv2, const float2 *__restrict__ gelu_lut, int n_blocks,
                                                          unsigned long long *stamps = nullptr)
 {
     constexpr int C = 256;
-    constexpr int MS = 8;
+    constexpr int MS = 16;                                 // fragment pairs per step
     constexpr int STEP = MS * NP * 1024;                   // bytes per stream step
     constexpr int NSLOT = kMPSlots;
     constexpr int PW = MS * NP / 8;                        // direct-to-LDS pieces per wave per step
     constexpr int LUT_BYTES = kGeluLutN * 8;
-    constexpr int RW = 3 * PW;                             // ring wait: pieces of the three youngest steps may still fly
     constexpr int NM = (NP == 2 ? 6 : 2);                  // MFMAs per chunk (two fragment pairs)
+    static_assert(NSLOT == 3, "the counted waits below assume that exactly the next step's pieces are in flight");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,11 +122,14 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     const unsigned hand0 = lut_addr + LUT_BYTES + (unsigned)pair * (2 * 2 * NP * 1024) + lane16;    // this pair's hand-off, this lane
     const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(wave * PW) * 1024 + lane16;
     const int n_mine = n_blocks > (int)blockIdx.x ? (n_blocks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    unsigned long long t_in[2] = {0, 0};
+    unsigned long long t_in[2] = {0, 0}, t_sync = 0;
     if constexpr (STAMPS != 0) { t_in[0] = __builtin_readcyclecounter(); t_in[1] = wall_clock64(); }
     if (n_mine == 0) return;
 
-    // ---- ring ----
+    // ---- ring: slot of step R = R % 3.  Top of step R: this wave's pieces of step R + 1 (issued in step R - 1) have landed,
+    //      every LDS access of this wave is done, barrier; then the slot of step R - 1 is refilled with step R + 2.
+    //      PENDING = vector-memory operations of this wave other than ring pieces issued since (they are younger than the pieces
+    //      waited for, and vector-memory operations retire in issue order). ----
     int r_issue = 0;                                       // stream step (mod period) of the next DMA
     int slot_cur = 0, slot_prev = NSLOT - 1;
     unsigned cur_addr = 0, nxt_addr = 0;
@@ -141,20 +146,21 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
         for (int i = 0; i < LUT_BYTES / 8192; i++)
             __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024), (lds_void_t *)(smem + NSLOT * STEP + wave * (LUT_BYTES / 8) + i * 1024), 16, 0, 0);
     }
-#pragma unroll
-    for (int s_ = 0; s_ < NSLOT - 1; s_++) issue(s_);
+    issue(0);
+    issue(1);
     if (!producer) {                                       // hidden hand-off starts as zeros (the first block has no predecessor)
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < 2 * 2 * NP; i++) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(hand0), "v"(z), "n"(i * 1024) : "memory");
     }
-    // top of step G: own pieces of step G + 1 landed (EXTRA = vector-memory operations other than ring pieces issued since),
-    // every LDS write of this wave done, barrier, refill the slot of step G - 1 with step G + NSLOT - 1
-    auto sync = [&](auto extra_c) {
-        vm_wait<RW + decltype(extra_c)::value>();
+    auto sync = [&](auto pending_c) {
+        unsigned long long t0 = 0;
+        if constexpr (STAMPS == 2) t0 = __builtin_readcyclecounter();
+        vm_wait<decltype(pending_c)::value>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        issue(slot_prev);                                  // always: the stream is cyclic, and the counted waits assume three younger steps in flight
+        if constexpr (STAMPS == 2) t_sync += __builtin_readcyclecounter() - t0;
+        issue(slot_prev);                                  // always: the stream is cyclic
         const int slot_next = slot_cur + 1 == NSLOT ? 0 : slot_cur + 1;
         cur_addr = lds0 + (unsigned)slot_cur * STEP;
         nxt_addr = lds0 + (unsigned)slot_next * STEP;
@@ -167,12 +173,22 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
 
-    u32x4 wb[2][2][2];                                     // weight fragments [set = chunk][pair of the chunk][plane]
+    u32x4 wb[2][2][2];                                     // weight fragments [set = chunk & 1][pair of the chunk][plane]
     auto lds_pair = [&](unsigned slot_addr, auto ms_c, u32x4 (&dst)[2]) {
         constexpr int ms = decltype(ms_c)::value;
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(slot_addr), "n"(ms * NP * 1024) : "memory");
         if (NP == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(slot_addr), "n"((ms * NP + 1) * 1024) : "memory");
         else dst[1] = dst[0];
+    };
+    // chunk c (0 .. 3) of a step works on pairs MB + 2c, MB + 2c + 1 (set c & 1), requested one chunk earlier; it requests the
+    // pairs of the next chunk (chunk 3: the first pairs of the next step, whose slot has landed) in front of its MFMAs
+    auto chunk_begin = [&](auto mb_c, auto c_c, bool next_step_has_work) {
+        constexpr int MB = decltype(mb_c)::value, c = decltype(c_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (c < 3) { lds_pair(cur_addr, std::integral_constant<int, MB + 2 * c + 2>{}, wb[(c + 1) & 1][0]); lds_pair(cur_addr, std::integral_constant<int, MB + 2 * c + 3>{}, wb[(c + 1) & 1][1]); }
+        else if (next_step_has_work) { lds_pair(nxt_addr, std::integral_constant<int, MB>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, MB + 1>{}, wb[0][1]); }
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto pin = [&](auto n_valu_c) {
         constexpr int n_valu = decltype(n_valu_c)::value;
@@ -186,22 +202,13 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
 
     if (producer) {
         // =============================================== producer ===============================================
-        constexpr int MB = 0;                              // first pair of this role in a step
+        using MB = std::integral_constant<int, 0>;         // first pair of this role in a step
         u32x4 xn[16][2];                                   // operand planes of this lane's token: [k-step][plane]
         f32x16 hA, hB;                                     // pre-activations of the even / odd hidden tile
         const float lut_scale = inv1 * kGeluLutScale;
         float gvv[4], gfr[4];
         f32x2 gtab[4];
         unsigned hw[2][4];                                 // hidden words of one k-step: [plane][word]
-        // chunk c of an fc step: pairs MB + 2c, MB + 2c + 1 = k-steps ks0, ks0 + 1 -> one accumulator chain
-        auto chunk_begin = [&](auto c_c, bool next_step_has_fc) {
-            constexpr int c = decltype(c_c)::value;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (c == 0) { lds_pair(cur_addr, std::integral_constant<int, MB + 2>{}, wb[1][0]); lds_pair(cur_addr, std::integral_constant<int, MB + 3>{}, wb[1][1]); }
-            else if (next_step_has_fc) { lds_pair(nxt_addr, std::integral_constant<int, MB>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, MB + 1>{}, wb[0][1]); }
-            __builtin_amdgcn_sched_barrier(0);
-        };
         auto fc_mma = [&](const u32x4 (&wa)[2], const u32x4 (&xa)[2], const u32x4 (&wc)[2], const u32x4 (&xc)[2], f32x16 &hd) {
             if (NP == 2) {
                 hd = T::mfma(wa[1], xa[0], hd); hd = T::mfma(wc[1], xc[0], hd);
@@ -247,49 +254,61 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
                 }
             }
         };
-        // one fc step: k-steps 4q .. 4q+3 of the tile accumulating in hdst; GELU(q) of hsrc rides in the MFMA shadows
-        auto step_fc = [&](auto q_c, f32x16 &hdst, const f32x16 &hsrc, int par, bool with_gelu, bool next_step_has_fc) {
-            constexpr int q = decltype(q_c)::value;
+        // one fc step: k-steps 8 half .. 8 half + 7 of the tile accumulating in hdst; the GELU of k-step `half` of hsrc's hidden
+        // planes (pre-activations 8 half .. + 7) rides in the MFMA shadows
+        auto step_fc = [&](auto half_c, f32x16 &hdst, const f32x16 &hsrc, int par, bool with_gelu, bool next_step_has_fc) {
+            constexpr int half = decltype(half_c)::value;
+            using VN = std::integral_constant<int, (NP == 2 ? 4 : 12)>;
             sync(E0{});
-            chunk_begin(I0{}, true);
-            if (with_gelu) gelu0(q_c, hsrc);
-            fc_mma(wb[0][0], xn[4 * q], wb[0][1], xn[4 * q + 1], hdst);
-            pin(std::integral_constant<int, (NP == 2 ? 4 : 12)>{});
-            chunk_begin(I1{}, next_step_has_fc);
-            if (with_gelu) gelu1(q_c, par);
-            fc_mma(wb[1][0], xn[4 * q + 2], wb[1][1], xn[4 * q + 3], hdst);
-            pin(std::integral_constant<int, (NP == 2 ? 4 : 12)>{});
+            chunk_begin(MB{}, I0{}, true);
+            if (with_gelu) gelu0(std::integral_constant<int, 2 * half>{}, hsrc);
+            fc_mma(wb[0][0], xn[8 * half], wb[0][1], xn[8 * half + 1], hdst);
+            pin(VN{});
+            chunk_begin(MB{}, I1{}, true);
+            if (with_gelu) gelu1(std::integral_constant<int, 2 * half>{}, par);
+            fc_mma(wb[1][0], xn[8 * half + 2], wb[1][1], xn[8 * half + 3], hdst);
+            pin(VN{});
+            chunk_begin(MB{}, I2{}, true);
+            if (with_gelu) gelu0(std::integral_constant<int, 2 * half + 1>{}, hsrc);
+            fc_mma(wb[0][0], xn[8 * half + 4], wb[0][1], xn[8 * half + 5], hdst);
+            pin(VN{});
+            chunk_begin(MB{}, I3{}, next_step_has_fc);
+            if (with_gelu) gelu1(std::integral_constant<int, 2 * half + 1>{}, par);
+            fc_mma(wb[1][0], xn[8 * half + 6], wb[1][1], xn[8 * half + 7], hdst);
+            pin(VN{});
         };
         auto tile_fc = [&](f32x16 &hdst, const f32x16 &hsrc, int par, bool with_gelu, bool last_of_block) {
 #pragma unroll
             for (int g = 0; g < 16; g++) hdst[g] = 0.f;
             step_fc(I0{}, hdst, hsrc, par, with_gelu, true);
-            step_fc(I1{}, hdst, hsrc, par, with_gelu, true);
-            step_fc(I2{}, hdst, hsrc, par, with_gelu, true);
-            step_fc(I3{}, hdst, hsrc, par, with_gelu, !last_of_block);
+            step_fc(I1{}, hdst, hsrc, par, with_gelu, !last_of_block);
         };
-        // a step without MFMAs: GELU part of the previous block's last tile (q < 4) and a slice of the prologue
-        auto gelu_only = [&](auto q_c, const f32x16 &hsrc, int par) {
-            gelu0(q_c, hsrc);
+        // GELU of one k-step of hidden planes in a step without MFMAs
+        auto gelu_only = [&](auto half_c, const f32x16 &hsrc, int par) {
+            constexpr int half = decltype(half_c)::value;
+            gelu0(std::integral_constant<int, 2 * half>{}, hsrc);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            gelu1(q_c, par);
+            gelu1(std::integral_constant<int, 2 * half>{}, par);
+            gelu0(std::integral_constant<int, 2 * half + 1>{}, hsrc);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gelu1(std::integral_constant<int, 2 * half + 1>{}, par);
         };
 #pragma unroll
         for (int g = 0; g < 16; g++) { hA[g] = 0.f; hB[g] = 0.f; }
 
 #pragma unroll 1
         for (int k = 0; k < n_mine; k++) {
-            // (k == 0: hB is zero, its GELU writes zero hidden planes -- what the consumer's first 8 steps expect)
+            // (k == 0: hB is zero, its GELU writes zero hidden planes -- what the consumer's first steps expect)
             const int64_t blk = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
             const float *xrow = x + (blk * 128 + pair * 32 + r) * C + 4 * h;   // this lane's token, its half of every octet
             f32x4 xr[32];                                  // raw row pieces: xr[4 j + gq] = features 32 j + 8 gq + 4 h .. + 3
-            // ---- step 0: GELU(tile 31) part 0; row loads ----
+            // ---- step 0: GELU(tile 31), first k-step; row loads ----
             sync(E0{});
             gelu_only(I0{}, hB, 1);
 #pragma unroll
             for (int i = 0; i < 32; i++)
                 asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xr[i]) : "v"(xrow), "n"((32 * (i >> 2) + 8 * (i & 3)) * 4) : "memory");
-            // ---- step 1: rows landed; LayerNorm statistics (two-pass, model.py:19-20) ----
+            // ---- step 1: GELU(tile 31), second k-step; rows landed; LayerNorm statistics (two-pass, model.py:19-20) ----
             sync(std::integral_constant<int, 32>{});
             gelu_only(I1{}, hB, 1);
             asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) : [n] "n"(PW) : "memory");
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
                 qv = a + b;
             }
             const float rstd = rsqrtf(qv * (1.0f / (float)C) + 1e-5f);
-            // ---- steps 2 .. 7: normalise and split k-steps (3, 3, 3, 3, 2, 2); GELU(tile 31) parts 2, 3 ----
+            // ---- steps 2, 3: normalise and split the 16 k-steps ----
             auto norm = [&](auto ks_c) {
                 constexpr int ks = decltype(ks_c)::value;
                 float v0[4], v1[4];
@@ -328,25 +347,17 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
                 xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
                 xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
             };
-            sync(std::integral_constant<int, 32>{});                                     // step 2
-            gelu_only(I2{}, hB, 1);
-            norm(std::integral_constant<int, 0>{}); norm(std::integral_constant<int, 1>{}); norm(std::integral_constant<int, 2>{});
-            sync(std::integral_constant<int, 32>{});                                     // step 3
-            gelu_only(I3{}, hB, 1);
-            norm(std::integral_constant<int, 3>{}); norm(std::integral_constant<int, 4>{}); norm(std::integral_constant<int, 5>{});
-            sync(std::integral_constant<int, 32>{});                                     // step 4
-            norm(std::integral_constant<int, 6>{}); norm(std::integral_constant<int, 7>{}); norm(std::integral_constant<int, 8>{});
-            sync(E0{});                                                                  // step 5
-            norm(std::integral_constant<int, 9>{}); norm(std::integral_constant<int, 10>{}); norm(std::integral_constant<int, 11>{});
-            sync(E0{});                                                                  // step 6
-            norm(std::integral_constant<int, 12>{}); norm(std::integral_constant<int, 13>{});
-            sync(E0{});                                                                  // step 7
-            norm(std::integral_constant<int, 14>{}); norm(std::integral_constant<int, 15>{});
-            // the first fragments of step 8 (its slot has landed for every wave: step 7's barrier)
-            lds_pair(nxt_addr, std::integral_constant<int, MB>{}, wb[0][0]);
-            lds_pair(nxt_addr, std::integral_constant<int, MB + 1>{}, wb[0][1]);
-            // ---- steps 8 .. 135: c_fc of tiles 0 .. 31, GELU one tile behind ----
-            tile_fc(hA, hB, 1, false, false);              // tile 0 (tile 31's GELU ran in steps 0 .. 3)
+            sync(E0{});                                                                  // step 2
+            norm(std::integral_constant<int, 0>{}); norm(std::integral_constant<int, 1>{}); norm(std::integral_constant<int, 2>{}); norm(std::integral_constant<int, 3>{});
+            norm(std::integral_constant<int, 4>{}); norm(std::integral_constant<int, 5>{}); norm(std::integral_constant<int, 6>{}); norm(std::integral_constant<int, 7>{});
+            sync(E0{});                                                                  // step 3
+            norm(std::integral_constant<int, 8>{}); norm(std::integral_constant<int, 9>{}); norm(std::integral_constant<int, 10>{}); norm(std::integral_constant<int, 11>{});
+            norm(std::integral_constant<int, 12>{}); norm(std::integral_constant<int, 13>{}); norm(std::integral_constant<int, 14>{}); norm(std::integral_constant<int, 15>{});
+            // the first fragments of step 4 (its slot has landed for every wave: step 3's barrier)
+            lds_pair(nxt_addr, std::integral_constant<int, 0>{}, wb[0][0]);
+            lds_pair(nxt_addr, std::integral_constant<int, 1>{}, wb[0][1]);
+            // ---- steps 4 .. 67: c_fc of tiles 0 .. 31, GELU one tile behind ----
+            tile_fc(hA, hB, 1, false, false);              // tile 0 (tile 31's GELU ran in steps 0, 1)
             tile_fc(hB, hA, 0, true, false);               // tile 1, GELU(tile 0) -> parity 0
 #pragma unroll 1
             for (int t = 2; t < 32; t += 2) {
@@ -354,19 +365,17 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
                 tile_fc(hB, hA, 0, true, t == 30);         // odd tile, GELU(even tile) -> parity 0
             }
         }
-        // ---- drain: GELU of the last block's tile 31 (steps 0 .. 3); the consumer finishes during steps 4 .. 15 ----
+        // ---- drain: GELU of the last block's tile 31 (steps 0, 1); the consumer finishes during steps 2 .. 7 ----
         sync(E0{}); gelu_only(I0{}, hB, 1);
         sync(E0{}); gelu_only(I1{}, hB, 1);
-        sync(E0{}); gelu_only(I2{}, hB, 1);
-        sync(E0{}); gelu_only(I3{}, hB, 1);
 #pragma unroll 1
-        for (int s_ = 4; s_ < 2 * kMPPause; s_++) sync(E0{});
+        for (int s_ = 2; s_ < 2 * kMPPause; s_++) sync(E0{});
     } else {
         // =============================================== consumer ===============================================
-        constexpr int MB = 4;
+        using MB = std::integral_constant<int, 8>;
         f32x16 acc[8];                                     // 32 tokens x 256 output features, swapped layout
-        u32x4 hf[2][2];                                    // hidden planes of the tile in work: [k-step kk][plane]
-        f32x4 xs[3][4];                                    // residual row pieces in flight (epilogue)
+        u32x4 hf[2][2];                                    // hidden planes: [k-step kk][plane]
+        f32x4 xs[4][4];                                    // residual row pieces in flight (write-back)
 #pragma unroll
         for (int j = 0; j < 8; j++)
 #pragma unroll
@@ -375,14 +384,6 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int b = 0; b < 2; b++) { hf[a][b] = (u32x4){0u, 0u, 0u, 0u}; wb[0][a][b] = (u32x4){0u, 0u, 0u, 0u}; }   // (the very first chunk runs on these)
-        auto chunk_begin = [&](auto c_c, bool next_step_has_pj) {
-            constexpr int c = decltype(c_c)::value;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (c == 0) { lds_pair(cur_addr, std::integral_constant<int, MB + 2>{}, wb[1][0]); lds_pair(cur_addr, std::integral_constant<int, MB + 3>{}, wb[1][1]); }
-            else if (next_step_has_pj) { lds_pair(nxt_addr, std::integral_constant<int, MB>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, MB + 1>{}, wb[0][1]); }
-            __builtin_amdgcn_sched_barrier(0);
-        };
         auto pj_mma = [&](const u32x4 (&wa)[2], const u32x4 (&wc)[2], const u32x4 (&hb)[2], f32x16 &ca, f32x16 &cb) {
             if (NP == 2) {
                 ca = T::mfma(wa[1], hb[0], ca); cb = T::mfma(wc[1], hb[0], cb);
@@ -399,105 +400,100 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
             if (NP == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hk[1]) : "v"(a), "n"(kk * NP * 1024 + 1024) : "memory");
             else hk[1] = hk[0];
         };
-        // one c_proj step q of the tile with parity par: groups 4q .. 4q+3 = (k-step kk = q >> 1, output tiles 4 (q & 1) .. + 3).
-        // q = 1 requests the tile's second k-step of hidden planes, q = 3 the first k-step of the NEXT tile (both are complete
-        // and visible by then, see the timing table in the header comment); EXTRA as in sync
-        auto step_pj = [&](auto q_c, int par, bool next_step_has_pj, bool prefetch_next_tile, auto extra_c) {
-            constexpr int q = decltype(q_c)::value;
-            constexpr int kk = q >> 1, j0 = 4 * (q & 1);
-            sync(extra_c);
-            chunk_begin(I0{}, true);
-            if (q == 1) load_hidden(I1{}, par);
-            if (q == 3 && prefetch_next_tile) load_hidden(I0{}, par ^ 1);
-            pj_mma(wb[0][0], wb[0][1], hf[kk], acc[j0], acc[j0 + 1]);
+        // one c_proj step: k-step kk of the hidden tile with parity par against all 8 output tiles (2 per chunk).
+        // The kk = 0 step requests the tile's second k-step of hidden planes, the kk = 1 step the first k-step of the NEXT tile
+        // (both are complete and visible by then: written one step earlier, a barrier in between)
+        auto step_pj = [&](auto kk_c, int par, bool next_step_has_pj, bool prefetch_next_tile, auto pending_c) {
+            constexpr int kk = decltype(kk_c)::value;
+            sync(pending_c);
+            chunk_begin(MB{}, I0{}, true);
+            if (kk == 0) load_hidden(I1{}, par);
+            if (kk == 1 && prefetch_next_tile) load_hidden(I0{}, par ^ 1);
+            pj_mma(wb[0][0], wb[0][1], hf[kk], acc[0], acc[1]);
             pin(E0{});
-            chunk_begin(I1{}, next_step_has_pj);
-            pj_mma(wb[1][0], wb[1][1], hf[kk], acc[j0 + 2], acc[j0 + 3]);
+            chunk_begin(MB{}, I1{}, true);
+            pj_mma(wb[1][0], wb[1][1], hf[kk], acc[2], acc[3]);
+            pin(E0{});
+            chunk_begin(MB{}, I2{}, true);
+            pj_mma(wb[0][0], wb[0][1], hf[kk], acc[4], acc[5]);
+            pin(E0{});
+            chunk_begin(MB{}, I3{}, next_step_has_pj);
+            pj_mma(wb[1][0], wb[1][1], hf[kk], acc[6], acc[7]);
             pin(E0{});
         };
 
-        // steps 0 .. 15 of a period for the consumer: the block blk_prev is finished (c_proj of its tiles 30, 31, then the
+        // steps 0 .. 7 of a period for the consumer: the block blk_prev is finished (c_proj of its tiles 30, 31, then the
         // residual add + store, acc = 0)
         auto finish_block = [&](int64_t blk_prev) {
             float *xrow = x + (blk_prev * 128 + pair * 32 + r) * C + 4 * h;
-        auto ld = [&](auto j_c) {                      // residual pieces of output tile j -> xs[j % 3]
-            constexpr int j = decltype(j_c)::value;
-            f32x4 (&xj)[4] = xs[j % 3];
-            float *xp = xrow;
+            auto ld = [&](auto j_c) {                      // residual pieces of output tile j -> xs[j % 4]
+                constexpr int j = decltype(j_c)::value;
+                f32x4 (&xj)[4] = xs[j % 4];
+                float *xp = xrow;
 #pragma unroll
-            for (int gq = 0; gq < 4; gq++)
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xj[gq]) : "v"(xp), "n"((32 * j + 8 * gq) * 4) : "memory");
-        };
-        auto st = [&](auto j_c, auto younger_c) {      // x = x + acc[j] * inv2 for output tile j; YOUNGER = operations issued after its loads
-            constexpr int j = decltype(j_c)::value;
-            f32x4 (&xj)[4] = xs[j % 3];
-            float *xp = xrow;
-            asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(xj[0]), "+v"(xj[1]), "+v"(xj[2]), "+v"(xj[3]) : [n] "n"(decltype(younger_c)::value) : "memory");
+                for (int gq = 0; gq < 4; gq++)
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xj[gq]) : "v"(xp), "n"((32 * j + 8 * gq) * 4) : "memory");
+            };
+            auto st = [&](auto j_c, auto younger_c) {      // x = x + acc[j] * inv2 for output tile j; YOUNGER = operations issued after its loads
+                constexpr int j = decltype(j_c)::value;
+                f32x4 (&xj)[4] = xs[j % 4];
+                float *xp = xrow;
+                asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(xj[0]), "+v"(xj[1]), "+v"(xj[2]), "+v"(xj[3]) : [n] "n"(decltype(younger_c)::value) : "memory");
 #pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                f32x4 o;
+                for (int gq = 0; gq < 4; gq++) {
+                    f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; e++) o[e] = fmaf(acc[j][4 * gq + e], inv2, xj[gq][e]);
-                // (s_nop: a store of more than 8 bytes reads its data registers after issue; hipcc pads a VALU write of them for
-                //  its own stores, but it cannot see through inline asm -- without this the next piece's FMAs clobbered the data)
-                asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" ::"v"(xp), "v"(o), "n"((32 * j + 8 * gq) * 4) : "memory");
-            }
+                    for (int e = 0; e < 4; e++) o[e] = fmaf(acc[j][4 * gq + e], inv2, xj[gq][e]);
+                    // (s_nop: a store of more than 8 bytes reads its data registers after issue; hipcc pads a VALU write of them for
+                    //  its own stores, but it cannot see through inline asm -- without this the next piece's FMAs clobbered the data)
+                    asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" ::"v"(xp), "v"(o), "n"((32 * j + 8 * gq) * 4) : "memory");
+                }
 #pragma unroll
-            for (int g = 0; g < 16; g++) acc[j][g] = 0.f;
-        };
-            // ---- steps 0 .. 7: c_proj of the previous block's tiles 30 (parity 0) and 31 (parity 1) ----
-            // (their first fragments were requested at step 135 / the first k-step of tile 30's planes as well)
+                for (int g = 0; g < 16; g++) acc[j][g] = 0.f;
+            };
+            using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+            using J4 = std::integral_constant<int, 4>; using J5 = std::integral_constant<int, 5>; using J6 = std::integral_constant<int, 6>; using J7 = std::integral_constant<int, 7>;
+            // ---- steps 0 .. 3: c_proj of the previous block's tiles 30 (parity 0) and 31 (parity 1) ----
+            // (the first fragments and the first k-step of tile 30's planes were requested in step 67)
             step_pj(I0{}, 0, true, false, E0{});
-            step_pj(I1{}, 0, true, false, E0{});
-            step_pj(I2{}, 0, true, false, E0{});
-            step_pj(I3{}, 0, true, true, E0{});
+            step_pj(I1{}, 0, true, true, E0{});
             step_pj(I0{}, 1, true, false, E0{});
-            step_pj(I1{}, 1, true, false, E0{});
-            step_pj(I2{}, 1, true, false, E0{});       // step 6: output tiles 0 .. 3 are final after it
-            ld(std::integral_constant<int, 0>{});
-            step_pj(I3{}, 1, false, false, std::integral_constant<int, 4>{});   // step 7 (L0 is younger than the pieces waited for)
-            ld(std::integral_constant<int, 1>{});
-            // ---- steps 8 .. 15: residual add + store, one output tile per step, loads two steps ahead ----
-            // operations per step: PW ring pieces | 4 loads (tile j + 2) | 4 stores (tile j)
-            sync(std::integral_constant<int, 8>{});                                                     // step 8:  L0 L1
-            ld(std::integral_constant<int, 2>{}); st(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * PW + 8>{});
-            sync(std::integral_constant<int, 16>{});                                                    // step 9:  L0 L1 | L2 S0
-            ld(std::integral_constant<int, 3>{}); st(std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * PW + 12>{});
-            sync(std::integral_constant<int, 24>{});                                                    // step 10: L0 L1 | L2 S0 | L3 S1
-            ld(std::integral_constant<int, 4>{}); st(std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * PW + 16>{});
-            sync(std::integral_constant<int, 28>{});                                                    // step 11: L1 | L2 S0 | L3 S1 | L4 S2
-            ld(std::integral_constant<int, 5>{}); st(std::integral_constant<int, 3>{}, std::integral_constant<int, 2 * PW + 16>{});
-            sync(std::integral_constant<int, 32>{});                                                    // step 12
-            ld(std::integral_constant<int, 6>{}); st(std::integral_constant<int, 4>{}, std::integral_constant<int, 2 * PW + 16>{});
-            sync(std::integral_constant<int, 32>{});                                                    // step 13
-            ld(std::integral_constant<int, 7>{}); st(std::integral_constant<int, 5>{}, std::integral_constant<int, 2 * PW + 16>{});
-            sync(std::integral_constant<int, 32>{});                                                    // step 14: L4 S2 | L5 S3 | L6 S4 | L7 S5
-            st(std::integral_constant<int, 6>{}, std::integral_constant<int, 2 * PW + 12>{});
-            sync(std::integral_constant<int, 28>{});                                                    // step 15: L5 S3 | L6 S4 | L7 S5 | S6
-            st(std::integral_constant<int, 7>{}, std::integral_constant<int, 2 * PW + 8>{});
+            step_pj(I1{}, 1, false, false, E0{});          // step 3: every output tile is final after it
+            ld(J0{}); ld(J1{});
+            // ---- steps 4 .. 7: residual add + store, two output tiles per step, loads one step ahead ----
+            // vector-memory operations per step: PW ring pieces | 8 loads (two tiles) | 8 stores (two tiles)
+            sync(std::integral_constant<int, 8>{});                                       // step 4 (pending: L0 L1)
+            ld(J2{}); ld(J3{});
+            st(J0{}, std::integral_constant<int, PW + 8>{}); st(J1{}, std::integral_constant<int, PW + 8 + 4>{});
+            sync(std::integral_constant<int, 16>{});                                      // step 5 (pending: L2 L3 S0 S1)
+            ld(J4{}); ld(J5{});
+            st(J2{}, std::integral_constant<int, 8 + PW + 8>{}); st(J3{}, std::integral_constant<int, 8 + PW + 8 + 4>{});
+            sync(std::integral_constant<int, 16>{});                                      // step 6
+            ld(J6{}); ld(J7{});
+            st(J4{}, std::integral_constant<int, 8 + PW + 8>{}); st(J5{}, std::integral_constant<int, 8 + PW + 8 + 4>{});
+            sync(std::integral_constant<int, 16>{});                                      // step 7 (pending: L6 L7 S4 S5)
+            st(J6{}, std::integral_constant<int, 8 + PW>{}); st(J7{}, std::integral_constant<int, 8 + PW + 4>{});
         };
 #pragma unroll 1
         for (int k = 0; k < n_mine; k++) {
             // k == 0: nothing to finish -- the same sequence runs on this block's own rows with acc == 0 and zero hidden planes
             // (x + 0 is written back unchanged), which keeps the loop free of branches and the step / wait counts uniform
             finish_block((int64_t)blockIdx.x + (int64_t)(k > 0 ? k - 1 : 0) * gridDim.x);
-            // the first fragments of step 16 and the first k-step of tile 0's hidden planes (complete since step 14)
-            lds_pair(nxt_addr, std::integral_constant<int, MB>{}, wb[0][0]);
-            lds_pair(nxt_addr, std::integral_constant<int, MB + 1>{}, wb[0][1]);
+            // the first fragments of step 8 and the first k-step of tile 0's hidden planes (complete since step 6)
+            lds_pair(nxt_addr, std::integral_constant<int, 8>{}, wb[0][0]);
+            lds_pair(nxt_addr, std::integral_constant<int, 9>{}, wb[0][1]);
             load_hidden(I0{}, 0);
-            // ---- steps 16 .. 135: c_proj of tiles 0 .. 29 ----
-            // (the stores of steps 12 .. 15 are younger than the pieces waited for in steps 16 .. 19: waiting without the
-            //  extra count over-waits, i.e. it also waits for those stores -- harmless)
+            // ---- steps 8 .. 67: c_proj of tiles 0 .. 29 ----
+            step_pj(I0{}, 0, true, false, std::integral_constant<int, 8>{});             // step 8 (pending: S6 S7)
+            step_pj(I1{}, 0, true, true, E0{});
+            step_pj(I0{}, 1, true, false, E0{});
+            step_pj(I1{}, 1, true, true, E0{});
 #pragma unroll 1
-            for (int t = 0; t < 30; t += 2) {
+            for (int t = 2; t < 30; t += 2) {
                 step_pj(I0{}, 0, true, false, E0{});
-                step_pj(I1{}, 0, true, false, E0{});
-                step_pj(I2{}, 0, true, false, E0{});
-                step_pj(I3{}, 0, true, true, E0{});
+                step_pj(I1{}, 0, true, true, E0{});
                 step_pj(I0{}, 1, true, false, E0{});
-                step_pj(I1{}, 1, true, false, E0{});
-                step_pj(I2{}, 1, true, false, E0{});
-                step_pj(I3{}, 1, true, true, E0{});        // t + 1 == 29: the next tile is tile 30, worked on in the next period
+                step_pj(I1{}, 1, true, true, E0{});        // t + 1 == 29: the next tile is tile 30, worked on in the next period
             }
         }
         finish_block((int64_t)blockIdx.x + (int64_t)(n_mine - 1) * gridDim.x);      // drain
@@ -506,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     if constexpr (STAMPS != 0) {
         if ((wave == 0 || wave == 4) && lane == 0) {
             unsigned long long *o = stamps + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 4;
-            o[0] = t_in[0]; o[1] = t_in[1]; o[2] = __builtin_readcyclecounter(); o[3] = wall_clock64();
+            o[0] = t_in[0]; o[1] = t_in[1]; o[2] = __builtin_readcyclecounter(); o[3] = STAMPS == 2 ? t_sync : wall_clock64();
         }
     }
 }

@@ -32,8 +32,8 @@ int main(int argc, char **argv)
     hipMemcpy(g, hg.data(), C * 4, hipMemcpyHostToDevice); hipMemcpy(fc, hfc.data(), hfc.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(pj, hpj.data(), hpj.size() * 4, hipMemcpyHostToDevice);
     uint16_t *pkp, *pko;
-    hipMalloc(&pkp, (size_t)kMPPeriod * 8 * 2 * 512 * 2); hipMalloc(&pko, (size_t)kM256Steps * 8 * 2 * 512 * 2);
-    pack_mlp256p_kernel<F16T, 2><<<(kMPPeriod * 8 * 64 + 255) / 256, 256>>>(fc, pj, g, pkp, sc1, sc2);
+    hipMalloc(&pkp, (size_t)kMPPeriod * 16 * 2 * 512 * 2); hipMalloc(&pko, (size_t)kM256Steps * 8 * 2 * 512 * 2);
+    pack_mlp256p_kernel<F16T, 2><<<(kMPPeriod * 16 * 64 + 255) / 256, 256>>>(fc, pj, g, pkp, sc1, sc2);
     float mxo = 0; for (auto v : hfc) mxo = fmaxf(mxo, fabsf(v));
     const float sco = ldexpf(1.f, (int)floorf(log2f(4096.f / mxo)));
     pack_mlp256_kernel<F16T, 2><<<(kM256Steps * 8 * 64 + 255) / 256, 256>>>(fc, pj, pko, sco, sc2);
@@ -159,7 +159,17 @@ int main(int argc, char **argv)
     hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
     double cyc = 0, rt = 0;
     for (int w = 0; w < ncu; w++) { cyc += (double)(h[8 * w + 2] - h[8 * w]); rt += (double)(h[8 * w + 3] - h[8 * w + 1]); }
-    printf("mlp256p stamps: %.0f shader cycles per workgroup = %.0f per block = %.1f per stream step; shader clock %.3f GHz\n", cyc / ncu,
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256p_kernel<F16T, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    mlp256p_kernel<F16T, 2, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb, st);
+    hipDeviceSynchronize();
+    {
+        std::vector<unsigned long long> h2((size_t)ncu * 8);
+        hipMemcpy(h2.data(), st, h2.size() * 8, hipMemcpyDeviceToHost);
+        double tp = 0, sp = 0, tc = 0, sc = 0;
+        for (int w = 0; w < ncu; w++) { tp += (double)(h2[8 * w + 2] - h2[8 * w]); sp += (double)h2[8 * w + 3]; tc += (double)(h2[8 * w + 6] - h2[8 * w + 4]); sc += (double)h2[8 * w + 7]; }
+        printf("mlp256p (instrumented): producer wave 0 spends %.1f %% of its cycles in wait + barrier, consumer wave 4 %.1f %%\n", 100 * sp / tp, 100 * sc / tc);
+    }
+    printf("mlp256p stamps: %.0f shader cycles per workgroup = %.0f per block = %.1f per 32-KiB stream step (24 MFMAs per wave); shader clock %.3f GHz\n", cyc / ncu,
            cyc / ncu / (nb / (double)ncu), cyc / ncu / (nb / (double)ncu) / kMPPeriod, cyc / rt / 10.0);
     return rc;
 }
