@@ -12,6 +12,7 @@
 #include "gpt_ctx.h"
 #include "gpt_kernels_fast.h"
 #include "gpt_kernels_c256.h"
+#include "gpt_kernels_c256p.h"
 
 using namespace mgpt;
 
@@ -39,9 +40,11 @@ struct ModeState {          // one precision mode
     // fused MLP (C = 64 / 160): per layer one packed stream [hidden tile][fragment][plane][lane][8]
     std::vector<uint16_t *> mlp_pk;
     bool mlp_fused = false;
-    // C = 256 (6M): mlp256_kernel's weight stream in consumption order, per layer [step][micro-step][plane][lane][8]
+    // C = 256 (6M): mlp256p_kernel's cyclic weight stream in consumption order (LayerNorm gain folded into c_fc), per layer
+    // [period step][pair][plane][lane][8], and the scale c_fc * gain was packed with
     std::vector<uint16_t *> mlp256_pk;
-    float2 *gelu_lut = nullptr;                // mlp256_kernel's Phi table (kGeluLutN pairs)
+    std::vector<float> mlp256_inv1;
+    float2 *gelu_lut = nullptr;                // the Phi table of the fused MLP kernels (kGeluLutN pairs)
     // C = 256, head size 32 (6M): attn256_kernel's c_attn stream in consumption order, per layer
     std::vector<uint16_t *> attn256_pk;
     bool attn256 = false;
@@ -90,8 +93,6 @@ float pick_scale(const float *h_w, size_t n, bool f16)
 
 template <int NP>
 constexpr int kA256Lds = 5 * 8 * NP * 1024 + NP * (256 * 80 + 32 * 528);    // attn256_kernel: 5-slot weight ring + K and V^T planes of a head
-template <int NP>
-constexpr int kM256Lds = 8 * 8 * NP * 1024 + fastk::kGeluLutN * 8;      // mlp256_kernel: 8-slot weight ring + GELU table
 
 template <class T, int NP>
 int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
@@ -132,19 +133,25 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         MGPT_HIP(hipMemcpy(m->gelu_lut, lut.data(), lut.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
     if (C == 256) {
-        const size_t n16 = (size_t)fastk::kM256Steps * 8 * NP * 512;
+        const size_t n16 = (size_t)fastk::kMPPeriod * 16 * NP * 512;
         m->mlp256_pk.assign(g->L, nullptr);
+        m->mlp256_inv1.assign(g->L, 1.f);
         for (int l = 0; l < g->L; l++) {
             MGPT_HIP(hipMalloc(&m->mlp256_pk[l], n16 * sizeof(uint16_t)));
             const LayerOff &lo = g->layers[l];
+            // the stream carries c_fc.weight * ln_2.weight (model.py:19-20, 86): its own power-of-two scale
+            std::vector<float> wg(4 * C * C);
+            for (size_t i = 0; i < wg.size(); i++) wg[i] = host[lo.fc_w + i] * host[lo.ln2 + i % C];
+            const float sc1 = pick_scale(wg.data(), wg.size(), f16);
+            m->mlp256_inv1[l] = 1.0f / sc1;
             ProfScope ps(P_PACK, nullptr);
-            hipLaunchKernelGGL((fastk::pack_mlp256_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)fastk::kM256Steps * 8 * 64, 256)), dim3(256), 0,
-                               nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, m->mlp256_pk[l], 1.0f / m->fc[l].inv_scale,
+            hipLaunchKernelGGL((fastk::pack_mlp256p_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)fastk::kMPPeriod * 16 * 64, 256)), dim3(256), 0,
+                               nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, g->params + lo.ln2, m->mlp256_pk[l], sc1,
                                1.0f / m->proj2[l].inv_scale);
             MGPT_LAUNCH_CHECK();
         }
-        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     kM256Lds<NP>));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256p_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     fastk::kMPLds<NP>));
         m->attn256 = (g->hs == 32 && g->nh == 8);
         if (m->attn256) {
             const size_t n16 = (size_t)8 * fastk::kA256StepsPerHead * 8 * NP * 512;
@@ -455,9 +462,10 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             // ---- whole MLP block in one kernel (hidden stays in registers) ----
             ProfScope ps(P_MLP_FUSED, s);
             if (C == 256) {
+                // persistent: one workgroup per CU walks the 128-token blocks round-robin (results do not depend on the grid)
                 const int n_blocks = (int)(mlp_M / 128);
-                hipLaunchKernelGGL((fastk::mlp256_kernel<T, NP>), dim3((unsigned)n_blocks), dim3(256), (size_t)kM256Lds<NP>, s,
-                                   mlp_x, P + lo.ln2, m->mlp256_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, m->gelu_lut);
+                hipLaunchKernelGGL((fastk::mlp256p_kernel<T, NP>), dim3((unsigned)std::min(n_blocks, m->n_cu)), dim3(512), (size_t)fastk::kMPLds<NP>, s,
+                                   mlp_x, m->mlp256_pk[l], m->mlp256_inv1[l], m->proj2[l].inv_scale, m->gelu_lut, n_blocks, (unsigned long long *)nullptr);
                 if (!m->pk_gemm && l + 1 < g->L) {                       // this kernel leaves no LayerNorm statistics behind
                     MGPT_LAUNCH_CHECK();
                     if ((rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
