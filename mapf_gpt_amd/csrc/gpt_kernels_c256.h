@@ -479,13 +479,20 @@ __global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restri
 }
 
 // ABL (tools/probe_attn256.hip only; the library instantiates ABL = 0): 1 no weight DMA in the loop, 2 no softmax arithmetic,
-// 4 no attention phase, 8 no projection MFMAs, 16 no ring barriers -- results are wrong unless ABL == 0.
+// 4 no attention phase, 8 no projection MFMAs, 16 no ring barriers -- results are wrong unless ABL == 0.  32: wave 0 of every
+// block leaves stamps[block][8] = {entry cycles, entry 100-MHz ticks, cycles after LayerNorm, exit cycles, exit ticks,
+// cycles in the q|k|v projection steps, cycles waiting at the head's k / v barrier, cycles in the attention phase}.
 template <class T, int NP, bool LAST, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict__ x, const float *__restrict__ gain,
                                                          const uint16_t *__restrict__ wstream, float inv_scale, float scale_log2e,
-                                                         uint16_t *__restrict__ y)
+                                                         uint16_t *__restrict__ y, unsigned long long *stamps = nullptr)
 {
     constexpr int C = 256, CT = 8, KS = 16, NH = 8, HS = 32, NW = 8;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = 0;
+    auto phase = [&](int i) {                              // ABL & 32: cycles since the previous call go to ts[i]
+        if constexpr ((ABL & 32) != 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); ts[i] += t - t_mark; t_mark = t; }
+    };
+    if constexpr ((ABL & 32) != 0) { ts[0] = __builtin_readcyclecounter(); ts[1] = wall_clock64(); }
     constexpr int MS = 8;                                  // fragment pairs per step
     constexpr int STEP = MS * NP * 1024;
     constexpr int NSLOT = 5;
@@ -645,6 +652,7 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
     step_begin(false);
     lds_pair(cur_addr, I0{}, wb[0][0]);
     lds_pair(cur_addr, I1{}, wb[0][1]);
+    if constexpr ((ABL & 32) != 0) { ts[2] = __builtin_readcyclecounter(); t_mark = ts[2]; }
 
 #pragma unroll 1
     for (int hd = 0; hd < NH; hd++) {
@@ -723,7 +731,9 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
                 for (int pl = 0; pl < NP; pl++) lds_write(vw_addr + (unsigned)(pl * HS * VROW + mm * 32), vp[mm][pl]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        phase(5);
         __builtin_amdgcn_s_barrier();                      // k, v^T of the head complete
+        phase(6);
 
         // ---- attention of this wave's 32 queries against the 256 keys of the head ----
         f32x16 o;
@@ -815,8 +825,15 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
                 }
             }
         }
+        phase(7);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr ((ABL & 32) != 0) {
+        ts[3] = __builtin_readcyclecounter(); ts[4] = wall_clock64();
+        if (tid == 0)
+#pragma unroll
+            for (int i = 0; i < 8; i++) stamps[(size_t)blockIdx.x * 8 + i] = ts[i];
+    }
 }
 
 }  // namespace fastk
