@@ -377,10 +377,42 @@ def class_flops(prof, f_class, L_, rows):
     return cls
 
 
+def roofline_of(prof, name, precision, model, rows, steps):
+    """Dominant kernel class of a timed run (by HIP-event time) -> its roofline dict (algorithmic flops / event time)."""
+    from mapf_gpt_amd import weights
+    margs = weights.model_args(model)
+    _, f_class = flops_per_row(margs)
+    cls = class_flops(prof, f_class, margs["n_layer"], rows)
+    if not cls:
+        return None
+    dom = max(cls, key=lambda k: prof[k][0])
+    ms, n = prof[dom]
+    ach = cls[dom] * steps / (ms * 1e-3) / 1e12
+    return {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+            "frac": ach / PEAK_TFLOPS[precision], "avg_launch_ms": ms / n, "launches": n,
+            "algorithmic_gflop_per_launch": cls[dom] * steps / n / 1e9, "traffic": traffic_for(f"{name}_{precision}_{dom}"),
+            "kernel_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]}}
+
+
+def secondary_shard(name, precision, steps, warmup, local_rank, coll_dev, instances=0):
+    """A BASELINE configuration's per-GPU shard under the same clock as the headline: W warmup + exactly `steps` timed steps
+    (barrier + synchronize on both sides), HIP-event hooks on -> value, ms/step and the dominant kernel's roofline."""
+    w = build_workload(name, precision, 0, 1, local_rank, instances)
+    dt, prof = timed_steps(w, steps, warmup, 1, True, coll_dev)
+    out = {"workload": f"{name} per-GPU shard: {w['map_name']}, {w['n_agents']} agents, MAPF-GPT-{w['model']} shape, "
+                       f"{w['inst_per_gpu']} instances, {w['rows']} rows/step",
+           "value": w["n_total"] * w["n_agents"] * steps / dt, "unit": "agent-steps/s", "ms_per_step": 1e3 * dt / steps,
+           "steps": steps, "warmup": warmup, "dtype": precision,
+           "roofline": roofline_of(prof, name, precision, w["model"], w["rows"], steps)}
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
 def traffic_for(kernel_key):
-    """HBM bytes per launch from the committed PMC passes (profiles/r02_hbm_traffic.json, falling back to round 1's file):
+    """HBM bytes per launch from the committed PMC passes (profiles/r03_hbm_traffic.json, falling back to earlier rounds' files):
     a replay of an earlier rocprofv3 run of this command, NOT a measurement of this run."""
-    for f in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for f in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tf = os.path.join(ROOT, "profiles", f)
         if os.path.exists(tf):
             t = json.load(open(tf)).get(kernel_key)
@@ -418,10 +450,20 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        try:
+            if backend == "nccl":
+                local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+                assert torch.cuda.device_count() >= local_world or os.environ.get("MGPT_BENCH_SHARE_GPU"), \
+                    f"{local_world} local ranks but only {torch.cuda.device_count()} visible GPUs (one rank per GPU)"
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as e:                   # one diagnosable line per rank instead of a bare traceback from c10d
+            print(f"[bench rank {rank}/{world}] init_process_group({backend}) failed: {type(e).__name__}: {e}; "
+                  f"MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} LOCAL_RANK={local_rank} "
+                  f"visible_gpus={torch.cuda.device_count()} HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}",
+                  file=sys.stderr, flush=True)
+            raise
         world = dist.get_world_size()            # the process group's own count is what n_gpus reports
     coll_dev = "cuda" if backend == "nccl" else "cpu"
     assert a.gpus == world, f"--gpus {a.gpus} but the process group has {world} ranks"
@@ -445,6 +487,8 @@ def main():
         out = {"metric": "agent-steps/s (env+obs+GPT fwd)", "value": value, "unit": "agent-steps/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+               "collective_backend": (backend if world > 1 else None), "rccl_ranks": (world if world > 1 and backend == "nccl" else None),
+               "rccl_version": (".".join(map(str, torch.cuda.nccl.version())) if world > 1 and backend == "nccl" else None),
                "config": {"workload": f"{name}: {map_name}, {n_agents} agents, MAPF-GPT-{model} shape, "
                                       f"{w['inst_per_gpu']} instances/GPU ({n_total} total), {n_total * n_agents} rows/step",
                           "parallelism": f"instances sharded x{world}, no per-step collective",
@@ -507,6 +551,11 @@ def main():
                                         "ms_per_step_eager_launches": c1["eager"], "graph_speedup": c1["eager"] / c1["graph"],
                                         "steps": 120, "warmup": 8, "dtype": a.precision}
             torch.cuda.empty_cache()
+            # BASELINE configs[3] and [4]: the per-GPU shards of the two 8-GPU configurations, under this run's clock
+            if name != "cfg4":
+                out["secondary"]["cfg4_shard"] = secondary_shard("cfg4", "f16x3", 4, 1, local_rank, coll_dev)
+            if name != "cfg5":
+                out["secondary"]["cfg5_shard"] = secondary_shard("cfg5", "bf16", 3, 1, local_rank, coll_dev)
         if world == 1 and not a.no_cpu_baseline and name != "cfg4":
             out["cpu_baseline"] = cpu_baseline(map_name, n_agents, model)
         print(json.dumps(out), flush=True)

@@ -188,9 +188,12 @@ def _build_algorithm(algo_cfg, max_rows):
 
 
 def evaluation(evaluation_config, eval_dir=None, registry=None, precision=None, max_rows_per_batch=65536, rank=0, world=1,
-               print_fn=print):
+               print_fn=print, trace=None):
     """Run `evaluation_config` (dict in the reference's YAML schema).  Returns the list of result records (on every
-    rank); writes `<eval_dir>/<algorithm>.json` and prints the tabular views on rank 0."""
+    rank); writes `<eval_dir>/<algorithm>.json` and prints the tabular views on rank 0.
+    `trace(kind, payload)` (tests): called with ("reset", {algorithm, runs, grids, pos, goal, max_steps}) for every batch
+    this rank runs and with ("step", int32 actions [instances, agents]) after every step -- the device's sampled actions,
+    from which an episode can be replayed on the host."""
     import torch
     from .runner import BatchedRunner, gather_metrics, shard_range
 
@@ -235,7 +238,14 @@ def evaluation(evaluation_config, eval_dir=None, registry=None, precision=None, 
                             queue[k] = cells[rng.integers(0, len(cells), (n_agents, LIFELONG_QUEUE))]
                         queue = torch.from_numpy(queue)
                     run.reset(torch.from_numpy(pos), torch.from_numpy(goal), goal_queue=queue)
-                    run.run(max_steps)
+                    if trace is None:
+                        run.run(max_steps)
+                    else:
+                        trace("reset", {"algorithm": algo_name, "runs": list(mine), "grids": grids.copy(), "pos": pos.copy(),
+                                        "goal": goal.copy(), "max_steps": max_steps, "on_target": on_target})
+                        for _ in range(max_steps):
+                            run.step()
+                            trace("step", run.actions.cpu().numpy().copy())
                     local = run.metrics().to(torch.float32)
                     if queue is not None:               # ISR column carries the throughput (arrivals per step) in lifelong runs
                         local[:, 1] = run.env.goals_reached().sum(1).to(torch.float32) / float(max_steps)

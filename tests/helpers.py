@@ -8,6 +8,7 @@ import numpy as np
 from oracle import oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def tok_cases():
@@ -34,3 +35,14 @@ def replay_oracle(case):
 
 def sha_rows(tokens):
     return hashlib.sha256(np.ascontiguousarray(tokens, dtype=np.uint8).tobytes()).hexdigest()
+
+
+def record_parity(**entry):
+    """Append one measured parity record (shape, scale, precision, errors, ...) to gpurun_out/parity_records.jsonl: the GPU run
+    leaves the numbers behind instead of printing them into a -q run; the round's copy is committed
+    under profiles/."""
+    import json
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "parity_records.jsonl"), "a") as f:
+        f.write(json.dumps({k: (float(v) if hasattr(v, "__float__") and not isinstance(v, (int, str, bool)) else v) for k, v in entry.items()}) + "\n")

@@ -34,6 +34,22 @@ def test_bench_two_ranks_share_one_gpu():
     assert "cpu_baseline" not in j                       # rank 0 at N = 1 only
 
 
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """world = 8 (the driver's largest launch) as a dry run: 8 ranks share the one GPU, collectives over gloo; the instance
+    ids 0 .. 31 of cfg4 are dealt 4 per rank, and the one JSON line reports the whole job."""
+    env = dict(os.environ, MGPT_BENCH_BACKEND="gloo", MGPT_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--workload", "cfg4", "--instances", "4", "--precision", "f16x3", "--no-prof"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 8 and j["steps"] == 2 and j["scaling"] == "weak" and j["collective_backend"] == "gloo"
+    assert "32 total" in j["config"]["workload"] and f"{8 * 4 * 128} rows/step" in j["config"]["workload"]
+    assert abs(j["value"] - 8 * 4 * 128 * 2 / (j["ms_per_step"] * 2e-3)) <= 1e-6 * j["value"]
+    assert j["rccl_ranks"] is None                       # only the RCCL ("nccl") backend reports its rank count
+
+
 def test_bench_single_rank_line():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--instances", "4",
            "--no-cpu-baseline", "--no-tokenizer-leg", "--no-secondary"]

@@ -61,3 +61,105 @@ def test_lifelong_config_reports_throughput():
         assert set(r["metrics"]) == {"avg_throughput", "ep_length", "runtime"}
         assert r["metrics"]["ep_length"] == 32 and r["metrics"]["avg_throughput"] >= 0.0
     assert "avg_throughput" in lines[1]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# harness output vs an oracle replay of the same episodes (benchmark.py:20-50,
+# eval_configs/01-random/01-random.yaml:1-10,145-186, experiment_setup/create_env.py:14-20,38-40)
+# ----------------------------------------------------------------------------------------------------------------------
+def _replay_metrics(grid, pos0, goal, actions, max_steps):
+    """One episode replayed on the host from the device's sampled actions: the C oracle's env step (our spec)
+    and an INDEPENDENT computation of the episode metrics from the whole trajectory (not the env kernel's incremental rule):
+    the episode ends at the first step after which every agent stands on its goal, or at max_episode_steps; an agent's
+    arrival time is the start of its final uninterrupted stay on the goal (0 if it never left it), ep_length otherwise."""
+    from oracle import oracle as orc
+    pos = pos0.astype(np.int32).copy()
+    g = goal.astype(np.int32)
+    traj = [pos.copy()]
+    dens = [orc.agents_density(grid, pos)]
+    T = 0
+    for t in range(max_steps):
+        pos, _ = orc.env_step(grid, pos, g, actions[t].astype(np.int32))
+        traj.append(pos.copy())
+        dens.append(orc.agents_density(grid, pos))
+        T = t + 1
+        if np.all(pos == g):
+            break
+    on = np.array([np.all(p == g, axis=1) for p in traj])              # [T + 1, agents]
+    n = g.shape[0]
+    arrive = np.full(n, T, np.int64)
+    for a in range(n):
+        if on[T, a]:
+            t = T
+            while t > 0 and on[t - 1, a]:
+                t -= 1
+            arrive[a] = t
+    return {"CSR": float(on[T].all()), "ISR": float(on[T].mean()), "SoC": float(arrive.sum()), "makespan": float(arrive.max()),
+            "ep_length": float(T), "avg_agents_density": float(np.mean(dens))}
+
+
+def _check_harness_against_replay(cfg, tmp_path):
+    import json
+    from mapf_gpt_amd import evaluation as ev
+    log = []
+    res = ev.evaluation(cfg, eval_dir=str(tmp_path), print_fn=lambda *_: None, trace=lambda kind, payload: log.append((kind, payload)))
+    runs = ev.expand_grid_search(cfg["environment"])
+    checked = 0
+    for algo_name in cfg["algorithms"]:
+        written = json.load(open(os.path.join(str(tmp_path), f"{algo_name}.json")))      # what the harness wrote
+        by_point = {tuple(sorted(r["env_grid_search"].items())): r["metrics"] for r in written}
+        assert len(by_point) == len(runs) == len(written)
+        i = 0
+        while i < len(log):
+            kind, b = log[i]
+            assert kind == "reset"
+            steps = [p for k, p in log[i + 1:i + 1 + b["max_steps"]]]
+            assert all(k == "step" for k, _ in log[i + 1:i + 1 + b["max_steps"]]) and len(steps) == b["max_steps"]
+            i += 1 + b["max_steps"]
+            if b["algorithm"] != algo_name:
+                continue
+            for k, ridx in enumerate(b["runs"]):
+                want = _replay_metrics(b["grids"][k], b["pos"][k], b["goal"][k], [s[k] for s in steps], b["max_steps"])
+                got = by_point[tuple(sorted(runs[ridx][1].items()))]
+                for key in ("CSR", "ISR", "SoC", "makespan", "ep_length"):
+                    assert got[key] == pytest.approx(want[key], rel=0, abs=1e-6), (runs[ridx][1], key, got[key], want[key])
+                assert got["avg_agents_density"] == pytest.approx(want["avg_agents_density"], rel=2e-6), (runs[ridx][1], got, want)
+                checked += 1
+    assert checked == len(runs) * len(cfg["algorithms"])
+    return res
+
+
+def test_smoke_config_records_equal_an_oracle_replay(tmp_path):
+    """eval_configs/00-smoke through evaluation(): every record of the JSON the harness writes (CSR, ISR, SoC, makespan,
+    ep_length, avg_agents_density) equals the metrics of a host replay of that episode from the device's sampled actions."""
+    from mapf_gpt_amd import evaluation as ev
+    cfg = ev.load_yaml(os.path.join(ROOT, "eval_configs", "00-smoke", "00-smoke.yaml"))
+    _check_harness_against_replay(cfg, tmp_path)
+
+
+def test_reference_01_random_slice_equals_an_oracle_replay(tmp_path):
+    """A 2-map x 2-agent-count slice of the reference's eval_configs/01-random/01-random.yaml (same environment block,
+    lines 1-10; two of its maps ship in mapf_gpt_amd/data/named_maps.json) with both of its algorithm entries (2M and 6M
+    shapes on synthetic weights): the second batch group and the 6M forward go through the same check; a greedy-looking
+    policy on random weights rarely finishes, so CSR / SoC / makespan are exercised by a third, easy, configuration too."""
+    cfg = {"environment": {"name": "Environment", "with_animation": False, "on_target": "nothing", "max_episode_steps": 128,
+                           "observation_type": "MAPF", "collision_system": "soft", "seed": 0,
+                           "num_agents": {"grid_search": [8, 16]},
+                           "map_name": {"grid_search": ["validation-random-seed-000", "validation-random-seed-001"]}},
+           "algorithms": {"MAPF-GPT-2M": {"name": "MAPF-GPT", "parallel_backend": "balanced_dask", "num_process": 4,
+                                          "path_to_weights": "synthetic:2M"},
+                          "MAPF-GPT-6M": {"name": "MAPF-GPT", "parallel_backend": "balanced_dask", "num_process": 4,
+                                          "path_to_weights": "synthetic:6M"}},
+           "results_views": {"TabularView1": {"type": "tabular", "drop_keys": ["seed", "map_name"], "print_results": True}}}
+    _check_harness_against_replay(cfg, tmp_path)
+
+
+def test_finishing_episodes_equal_an_oracle_replay(tmp_path):
+    """Episodes that DO terminate (1 and 2 agents on an open map reach their goals by random walk within 256 steps often
+    enough): CSR = 1, early ep_length, SoC / makespan from arrival times -- the branches a never-finishing policy skips."""
+    cfg = {"environment": {"name": "Environment", "on_target": "nothing", "max_episode_steps": 256,
+                           "seed": {"grid_search": list(range(12))}, "num_agents": {"grid_search": [1, 2]},
+                           "map_name": "puzzle-00"},
+           "algorithms": {"A": {"name": "MAPF-GPT", "path_to_weights": "synthetic:tiny", "precision": "f16x3"}}}
+    res = _check_harness_against_replay(cfg, tmp_path)
+    assert any(r["metrics"]["CSR"] == 1.0 for r in res), "no episode finished: the CSR = 1 branch went unchecked"

@@ -15,7 +15,7 @@ import torch
 from mapf_gpt_amd import maps, weights
 from oracle import gpt_oracle
 from oracle import oracle as orc
-from tests.helpers import GOLDEN
+from tests.helpers import GOLDEN, record_parity
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5            # BASELINE.json north_star: logits within 1e-5 of the reference PyTorch forward
@@ -126,10 +126,14 @@ def _big(shape, scale):
 @pytest.mark.parametrize("shape,scale", [("2M", 1), ("2M", 4), ("6M", 1), ("6M", 4), ("85M", 1), ("85M", 4)])
 def test_256_real_rows_within_1e5_of_reference(shape, scale, precision):
     """The north star's bar on every released shape, x1 and x4 (trained-magnitude) weights, 256 real observation rows:
-    |ours - reference fp32 forward| <= 1e-5 and |ours - reference fp64| <= 1e-5.  The fp32 reference itself sits
-    e_ref = 7e-7 .. 4.4e-6 away from its own fp64 run on five of the six sets; on 85M x4 (|logit| up to 8.2) it is 3.6e-5
-    away, so no implementation can be within 1e-5 of both there: the bars are max(1e-5, 2 e_ref) against both (same
-    error class as the reference's own fp32 run; measured on the GPU: f16x3 3.5e-5 / f32 5.5e-5 against fp64)."""
+    |ours - reference fp32 forward| <= 1e-5.  The fp32 reference itself sits e_ref = 7e-7 .. 4.4e-6 away from its own fp64 run
+    on five of the six sets; on 85M x4 (|logit| up to 8.2) it is 3.6e-5 away, so no implementation can be within 1e-5 of both
+    there.  The bar: e32 <= 1e-5, OR as close to fp64 as the reference's own fp32 run (e64 <= 1.05 e_ref:
+    measured on the GPU in round 3, the headline f16x3 mode is 3.77e-5 from fp64 on that set against the reference's 3.64e-5,
+    i.e. inside 4 % of the reference's own distance; round 2's docstring said 3.5e-5, which no record backed).  The f32 mode
+    (v_mfma_f32_32x32x2_f32, a different accumulation order from the reference's CPU kernels) meets the strict bar on five
+    sets and is held to its measured class (2 e_ref against both yardsticks) on 85M x4.  Every measured number goes to
+    gpurun_out/parity_records.jsonl; the round's copy is profiles/r03_parity_records.jsonl."""
     from mapf_gpt_amd.model import build_model
     g = _big(shape, scale)
     net = build_model(shape, seed=0, scale=float(scale), max_rows=64 if shape == "85M" else 128, precision=precision)
@@ -137,9 +141,34 @@ def test_256_real_rows_within_1e5_of_reference(shape, scale, precision):
     e_ref = np.abs(g["logits_f32"].astype(np.float64) - g["logits_f64"]).max()
     e32 = np.abs(logits - g["logits_f32"]).max()
     e64 = np.abs(logits - g["logits_f64"]).max()
-    print(f"{shape} x{scale} {precision}: vs fp32 ref {e32:.3e}, vs fp64 ref {e64:.3e}, ref fp32 vs fp64 {e_ref:.3e}, max|logit| {np.abs(g['logits_f64']).max():.2f}")
-    assert e64 <= max(TOL, 2 * e_ref) and e32 <= max(TOL, 2 * e_ref), \
-        f"{shape} x{scale} {precision}: vs fp32 ref {e32:.3e}, vs fp64 ref {e64:.3e} (reference fp32 vs fp64 {e_ref:.3e})"
+    record_parity(test="256_real_rows", shape=shape, scale=scale, precision=precision, e32=e32, e64=e64, e_ref=e_ref,
+                  max_abs_logit=np.abs(g["logits_f64"]).max(), rows=int(g["tokens"].shape[0]))
+    msg = f"{shape} x{scale} {precision}: vs fp32 ref {e32:.3e}, vs fp64 ref {e64:.3e} (reference fp32 vs fp64 {e_ref:.3e})"
+    if precision == "f32" and (shape, scale) == ("85M", 4):
+        assert e64 <= 2 * e_ref and e32 <= 2 * e_ref, msg
+    else:
+        assert e32 <= TOL or e64 <= 1.05 * e_ref, msg
+        assert e64 <= max(TOL, 1.05 * e_ref), msg
+
+
+@pytest.mark.parametrize("shape", ["2M", "6M"])
+def test_heavy_tailed_weights_x20(shape):
+    """Headroom outside the goldens' N(0, 0.02) weights (tools/check_heavy_tails.py, now in the suite): 1 % of every 2-D weight
+    multiplied by 20; f16x3 against our exact-fp32-MFMA path on 256 random rows stays inside the 1e-5 bar (measured 5.5e-6 for
+    2M, 7.4e-6 for 6M at |logits| <= 5).  (With x100 outliers -- |logits| ~ 25 -- it is 1e-4 .. 1e-3: the absolute bar holds for
+    weight distributions like the released models', not for arbitrarily heavy tails; bench.py's note says so.)"""
+    from mapf_gpt_amd.model import build_model
+    sd = weights.synthetic_state_dict(shape, seed=3)
+    rng = np.random.Generator(np.random.PCG64(5))
+    for k, v in sd.items():
+        if v.ndim == 2 and "wte" not in k and "wpe" not in k:
+            v[rng.random(v.shape) < 0.01] *= 20.0
+    tok = torch.from_numpy(rng.integers(0, 67, (256, 256)).astype(np.uint8)).cuda()
+    a = build_model(shape, precision="f32", max_rows=256, state_dict=sd).logits_tokens(tok).cpu().numpy()
+    b = build_model(shape, precision="f16x3", max_rows=256, state_dict=sd).logits_tokens(tok).cpu().numpy()
+    err = float(np.abs(a - b).max())
+    record_parity(test="heavy_tails_x20", shape=shape, precision="f16x3 vs f32", err=err, max_abs_logit=float(np.abs(a).max()))
+    assert err <= TOL, f"{shape}: max |f16x3 - f32| = {err:.3e} at |logits| <= {np.abs(a).max():.2f}"
 
 
 @pytest.mark.parametrize("shape,scale", [("2M", 1), ("2M", 4), ("6M", 1), ("6M", 4), ("85M", 1), ("85M", 4)])
@@ -156,6 +185,8 @@ def test_bf16_mode_vs_reference_autocast(shape, scale):
     e_ref = np.abs(g["logits_bf16"] - g["logits_f64"]).max()
     e_ours = np.abs(logits - g["logits_f64"]).max()
     e_mut = np.abs(logits - g["logits_bf16"]).max()
+    record_parity(test="bf16_vs_autocast", shape=shape, scale=scale, precision="bf16", e_ours_vs_fp64=e_ours, e_ours_vs_autocast=e_mut,
+                  e_ref_autocast_vs_fp64=e_ref, max_abs_logit=np.abs(g["logits_f64"]).max())
     assert e_ours <= 1.5 * e_ref + 2e-3, f"{shape} x{scale}: ours-fp64 {e_ours:.3e} vs reference autocast-fp64 {e_ref:.3e}"
     assert e_mut <= 2.5 * e_ref + 2e-3, f"{shape} x{scale}: ours-autocast {e_mut:.3e} (reference autocast-fp64 {e_ref:.3e})"
     assert e_ours > 1e-6, "this must be the reduced-precision path"
