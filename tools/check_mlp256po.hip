@@ -1,0 +1,171 @@
+// tools/check_mlp256po.hip -- mlp256po_kernel (attention out-projection + MLP block, persistent) against an fp64 host computation of
+//     x1 = x + y Wo^T;   out = x1 + c_proj(GELU_erf(c_fc(LayerNorm(x1))))        (model.py:71, 84-89, 102-103)
+// with several blocks per workgroup (grid independence bit for bit); then its time per 4096-row launch on realistic operands next to
+// gemm-free mlp256p_kernel (same process): the difference is what the fused out-projection costs inside the kernel.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include "../mapf_gpt_amd/csrc/gpt_kernels_c256po.h"
+namespace mgpt { void set_error(const char *, ...) {} }
+using namespace mgpt::fastk;
+static float gauss(uint64_t &st)
+{
+    auto u = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)((st >> 11) + 1) / 9007199254740993.0; };
+    return (float)(sqrt(-2.0 * log(u())) * cos(6.283185307179586 * u()));
+}
+static size_t pk_host(int64_t m, int k, int pl, int KS, int NP)
+{
+    return ((((size_t)(m >> 5) * KS + (k >> 4)) * NP + pl) << 9) + ((size_t)((m & 31) + ((k & 8) << 2)) << 3) + (k & 7);
+}
+// y [M][256] fp32 -> hi / lo fp16 planes in the packed-fragment layout; yrep = the value the planes represent
+static void pack_y(const std::vector<float> &y, int M, std::vector<uint16_t> &pk, std::vector<double> &yrep)
+{
+    pk.assign((size_t)M * 256 * 2, 0); yrep.resize((size_t)M * 256);
+    for (int m = 0; m < M; m++)
+        for (int k = 0; k < 256; k++) {
+            const float v = y[(size_t)m * 256 + k];
+            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            pk[pk_host(m, k, 0, 16, 2)] = __builtin_bit_cast(uint16_t, hi);
+            pk[pk_host(m, k, 1, 16, 2)] = __builtin_bit_cast(uint16_t, lo);
+            yrep[(size_t)m * 256 + k] = (double)(float)hi + (double)(float)lo;
+        }
+}
+int main(int argc, char **argv)
+{
+    const int C = 256;
+    uint64_t seed = 7;
+    std::vector<float> hg(C), hfc((size_t)4 * C * C), hpj((size_t)4 * C * C), hao((size_t)C * C);
+    float mx1 = 0, mx2 = 0, mxo = 0;
+    for (auto &v : hg) v = 1.f + 0.1f * gauss(seed);
+    for (auto &v : hfc) v = 0.02f * gauss(seed);
+    for (auto &v : hpj) v = 0.02f * gauss(seed);
+    for (auto &v : hao) { v = 0.02f * gauss(seed); mxo = fmaxf(mxo, fabsf(v)); }
+    for (size_t i = 0; i < hfc.size(); i++) mx1 = fmaxf(mx1, fabsf(hfc[i] * hg[i % C]));
+    for (auto v : hpj) mx2 = fmaxf(mx2, fabsf(v));
+    const float sc1 = ldexpf(1.f, (int)floorf(log2f(4096.f / mx1))), sc2 = ldexpf(1.f, (int)floorf(log2f(4096.f / mx2)));
+    const float sco = ldexpf(1.f, (int)floorf(log2f(4096.f / mxo)));
+    float *g, *fc, *pj, *ao;
+    hipMalloc(&g, C * 4); hipMalloc(&fc, hfc.size() * 4); hipMalloc(&pj, hpj.size() * 4); hipMalloc(&ao, hao.size() * 4);
+    hipMemcpy(g, hg.data(), C * 4, hipMemcpyHostToDevice); hipMemcpy(fc, hfc.data(), hfc.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(pj, hpj.data(), hpj.size() * 4, hipMemcpyHostToDevice); hipMemcpy(ao, hao.data(), hao.size() * 4, hipMemcpyHostToDevice);
+    uint16_t *pkq, *pkp;
+    hipMalloc(&pkq, (size_t)kMQPeriod * 16 * 2 * 512 * 2); hipMalloc(&pkp, (size_t)kMPPeriod * 16 * 2 * 512 * 2);
+    pack_mlp256po_kernel<F16T, 2><<<(kMQPeriod * 16 * 64 + 255) / 256, 256>>>(ao, fc, pj, g, pkq, sco, sc1, sc2);
+    pack_mlp256p_kernel<F16T, 2><<<(kMPPeriod * 16 * 64 + 255) / 256, 256>>>(fc, pj, g, pkp, sc1, sc2);
+    std::vector<float2> lut(kGeluLutN);
+    for (int i = 0; i < kGeluLutN; i++) {
+        const double v0 = (i - (double)kGeluLutBias) / kGeluLutScale, v1 = (i + 1 - (double)kGeluLutBias) / kGeluLutScale;
+        const float f0 = (float)(0.5 * (1.0 + erf(v0 * 0.70710678118654752440)));
+        lut[i] = make_float2(f0, (float)(0.5 * (1.0 + erf(v1 * 0.70710678118654752440)) - (double)f0));
+    }
+    constexpr int LDSQ = kMQLds<2>, LDSP = kMPLds<2>;
+    float2 *dl; hipMalloc(&dl, lut.size() * 8); hipMemcpy(dl, lut.data(), lut.size() * 8, hipMemcpyHostToDevice);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256po_kernel<F16T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSQ);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256po_kernel<F16T, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSQ);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256p_kernel<F16T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    int rc = 0;
+    std::vector<float> first;
+    for (int grid : {1, 2, 3, 7}) {
+        const int nb = 7, M = nb * 128;
+        std::vector<float> hx((size_t)M * C), hy((size_t)M * C), b(hx.size());
+        uint64_t s2 = 99;
+        for (auto &v : hx) v = gauss(s2) + 0.3f;
+        for (auto &v : hy) v = 0.7f * gauss(s2);
+        std::vector<uint16_t> ypk; std::vector<double> yrep;
+        pack_y(hy, M, ypk, yrep);
+        float *x; uint16_t *y;
+        hipMalloc(&x, hx.size() * 4); hipMalloc(&y, ypk.size() * 2);
+        hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice); hipMemcpy(y, ypk.data(), ypk.size() * 2, hipMemcpyHostToDevice);
+        mlp256po_kernel<F16T, 2><<<grid, 512, LDSQ>>>(x, y, pkq, 1.f / sco, 1.f / sc1, 1.f / sc2, dl, nb);
+        hipError_t e = hipDeviceSynchronize();
+        printf("grid %d: launch status: %s / %s\n", grid, hipGetErrorString(hipGetLastError()), hipGetErrorString(e));
+        hipMemcpy(b.data(), x, b.size() * 4, hipMemcpyDeviceToHost);
+        double mxd = 0, mx = 0, mxop = 0; int worst = -1; long nan_count = 0;
+        std::vector<double> x1(C), xn(C), hid(4 * C);
+        for (int m = 0; m < M; m++) {
+            for (int o = 0; o < C; o++) {
+                double a = 0;
+                for (int c = 0; c < C; c++) a += yrep[(size_t)m * C + c] * hao[(size_t)o * C + c];
+                mxop = fmax(mxop, fabs(a));
+                x1[o] = (double)(float)(hx[(size_t)m * C + o] + a);          // the kernel keeps x1 in fp32 (as the unfused path does)
+            }
+            double mean = 0, var = 0;
+            for (int c = 0; c < C; c++) mean += x1[c];
+            mean /= C;
+            for (int c = 0; c < C; c++) { const double d = x1[c] - mean; var += d * d; }
+            const double rstd = 1.0 / sqrt(var / C + 1e-5);
+            for (int c = 0; c < C; c++) xn[c] = (x1[c] - mean) * rstd * hg[c];
+            for (int u = 0; u < 4 * C; u++) {
+                double a = 0;
+                for (int c = 0; c < C; c++) a += xn[c] * hfc[(size_t)u * C + c];
+                hid[u] = 0.5 * a * (1.0 + erf(a * 0.70710678118654752440));
+            }
+            for (int o = 0; o < C; o++) {
+                double a = 0;
+                for (int u = 0; u < 4 * C; u++) a += hid[u] * hpj[(size_t)o * 4 * C + u];
+                mx = fmax(mx, fabs(a));
+                const double d = fabs(x1[o] + a - b[(size_t)m * C + o]);
+                if (d != d) { nan_count++; worst = m; }
+                else if (d > mxd) { mxd = d; worst = m; }
+            }
+        }
+        printf("grid %d: max |y Wo^T| %.4f  max |mlp output| %.4f   max |kernel - fp64| %.3e (token %d)\n", grid, mxop, mx, mxd, worst);
+        if (nan_count) printf("grid %d: %ld NaN outputs\n", grid, nan_count);
+        if (!(mxd < 5e-6) || nan_count) rc = 1;
+        if (first.empty()) first = b;
+        else {
+            size_t nd = 0, fi = 0;
+            for (size_t i = 0; i < b.size(); i++) if (memcmp(&b[i], &first[i], 4) != 0) { if (!nd) fi = i; nd++; }
+            printf("grid %d vs grid 1: %zu elements differ", grid, nd);
+            if (nd) { printf(" (first: token %zu feature %zu: %.9g vs %.9g)", fi / C, fi % C, b[fi], first[fi]); rc = 1; }
+            printf("\n");
+        }
+        hipFree(x); hipFree(y);
+    }
+    if (argc > 1 && atoi(argv[1]) == 0) return rc;
+    // ---- time: 4096 rows, realistic operands ----
+    const int M = 4096 * 256, nb = M / 128;
+    int dev = 0; hipDeviceProp_t prop; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev);
+    const int ncu = prop.multiProcessorCount;
+    std::vector<float> hx((size_t)M * C);
+    for (auto &v : hx) v = gauss(seed);
+    float *x; hipMalloc(&x, hx.size() * 4);
+    hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    uint16_t *y; hipMalloc(&y, (size_t)M * C * 2 * 2);
+    {   // random fp16 planes of plausible magnitude (hi ~ N(0, 0.5), lo = residual scale)
+        std::vector<uint16_t> yp((size_t)M * C * 2);
+        uint64_t s3 = 5;
+        for (size_t f = 0; f < yp.size() / 1024; f++) {            // fragment f: [tile][k-step][plane][512]
+            const bool lo = (f & 1) != 0;
+            for (int i = 0; i < 512; i++) { const _Float16 v = (_Float16)((lo ? 2.4e-4f : 0.5f) * gauss(s3)); yp[f * 512 + i] = __builtin_bit_cast(uint16_t, v); }
+        }
+        hipMemcpy(y, yp.data(), yp.size() * 2, hipMemcpyHostToDevice);
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; rep++) {
+        float ms;
+        hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+        hipEventRecord(e0);
+        for (int i = 0; i < 40; i++) mlp256po_kernel<F16T, 2><<<ncu, 512, LDSQ>>>(x, y, pkq, 1.f / sco, 1.f / sc1, 1.f / sc2, dl, nb);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("mlp256po_kernel (out-projection + MLP, %d workgroups): %.3f ms per 4096-row launch  [%s]\n", ncu, ms / 40, hipGetErrorString(hipGetLastError()));
+        hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+        hipEventRecord(e0);
+        for (int i = 0; i < 40; i++) mlp256p_kernel<F16T, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("mlp256p_kernel  (MLP only)                              : %.3f ms per 4096-row launch  [%s]\n", ms / 40, hipGetErrorString(hipGetLastError()));
+    }
+    unsigned long long *st; hipMalloc(&st, (size_t)ncu * 2 * 4 * 8);
+    mlp256po_kernel<F16T, 2, 1><<<ncu, 512, LDSQ>>>(x, y, pkq, 1.f / sco, 1.f / sc1, 1.f / sc2, dl, nb, st);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)ncu * 8);
+    hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, rt = 0;
+    for (int w = 0; w < ncu; w++) { cyc += (double)(h[8 * w + 2] - h[8 * w]); rt += (double)(h[8 * w + 3] - h[8 * w + 1]); }
+    printf("mlp256po stamps: %.0f shader cycles per block = %.1f per 32-KiB stream step; shader clock %.3f GHz\n", cyc / ncu / (nb / (double)ncu),
+           cyc / ncu / (nb / (double)ncu) / kMQPeriod, cyc / rt / 10.0);
+    return rc;
+}
