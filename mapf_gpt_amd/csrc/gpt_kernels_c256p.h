@@ -96,7 +96,8 @@ __device__ __forceinline__ void vm_wait()
 }
 
 // STAMPS (tools/check_mlp256p.hip only): 1 = wave 0 and wave 4 of every workgroup leave s_memtime / s_memrealtime at entry and
-// exit; 2 = cycles spent in wait + barrier instead of the exit wall clock.
+// exit; 2 = cycles spent in wait + barrier instead of the exit wall clock; 3 = cycles per phase of a step: {wait + barrier,
+// DMA issue + slot bookkeeping, chunks 0-2, chunk 3 (up to the next step's top)}.
 template <class T, int NP, int STAMPS = 0>
 __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv1,
                                                          float inv2, const float2 *__restrict__ gelu_lut, int n_blocks,
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     constexpr int MS = 16;                                 // fragment pairs per step
     constexpr int STEP = MS * NP * 1024;                   // bytes per stream step
     constexpr int NSLOT = kMPSlots;
-    constexpr int PW = MS * NP / 8;                        // direct-to-LDS pieces per wave per step
+    constexpr int PWP = MS * NP / 4;                       // direct-to-LDS pieces per PRODUCER wave per step; the consumers issue none: measured
+                                                           // (STAMPS = 3), the consumer is the longer chain of a step (4 x 416 cycles of MFMA
+                                                           // chunks + 290 of piece issue vs 4 x 309 + 79 with 650 cycles of barrier wait)
     constexpr int LUT_BYTES = kGeluLutN * 8;
     constexpr int NM = (NP == 2 ? 6 : 2);                  // MFMAs per chunk (two fragment pairs)
     static_assert(NSLOT == 3, "the counted waits below assume that exactly the next step's pieces are in flight");
@@ -120,9 +123,15 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     const unsigned lds0 = (unsigned)(size_t)smem + lane16;
     const unsigned lut_addr = (unsigned)(size_t)smem + NSLOT * STEP;
     const unsigned hand0 = lut_addr + LUT_BYTES + (unsigned)pair * (2 * 2 * NP * 1024) + lane16;    // this pair's hand-off, this lane
-    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(wave * PW) * 1024 + lane16;
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(pair * PWP) * 1024 + lane16;
     const int n_mine = n_blocks > (int)blockIdx.x ? (n_blocks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    unsigned long long t_in[2] = {0, 0}, t_sync = 0;
+    unsigned long long t_in[2] = {0, 0}, t_sync = 0, t_ph[6] = {0, 0, 0, 0, 0, 0}, t_last = 0;
+    auto mark = [&](int ph) {                              // STAMPS == 3: cycles since the previous mark go to phase ph
+        if constexpr (STAMPS == 3) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            t_ph[ph] += t - t_last; t_last = t;
+        }
+    };
     if constexpr (STAMPS != 0) { t_in[0] = __builtin_readcyclecounter(); t_in[1] = wall_clock64(); }
     if (n_mine == 0) return;
 
@@ -134,10 +143,12 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     int slot_cur = 0, slot_prev = NSLOT - 1;
     unsigned cur_addr = 0, nxt_addr = 0;
     auto issue = [&](int slot) {
-        const unsigned char *src = wbase + (size_t)r_issue * STEP;
-        unsigned char *dst = smem + (size_t)slot * STEP + (size_t)(wave * PW) * 1024;
+        if (producer) {                                    // wave-uniform
+            const unsigned char *src = wbase + (size_t)r_issue * STEP;
+            unsigned char *dst = smem + (size_t)slot * STEP + (size_t)(pair * PWP) * 1024;
 #pragma unroll
-        for (int i = 0; i < PW; i++) dma_piece(src, dst, std::integral_constant<int, 0>{}, i);
+            for (int i = 0; i < PWP; i++) dma_piece(src + (i >> 2) * 4096, dst + (i >> 2) * 4096, std::integral_constant<int, 0>{}, i & 3);
+        }
         r_issue = r_issue + 1 == kMPPeriod ? 0 : r_issue + 1;
     };
     {   // Phi table -> LDS (24 pieces of 1 KiB, 3 per wave); older than every ring piece
@@ -156,10 +167,12 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     auto sync = [&](auto pending_c) {
         unsigned long long t0 = 0;
         if constexpr (STAMPS == 2) t0 = __builtin_readcyclecounter();
+        mark(5);
         vm_wait<decltype(pending_c)::value>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if constexpr (STAMPS == 2) t_sync += __builtin_readcyclecounter() - t0;
+        mark(0);
         issue(slot_prev);                                  // always: the stream is cyclic
         const int slot_next = slot_cur + 1 == NSLOT ? 0 : slot_cur + 1;
         cur_addr = lds0 + (unsigned)slot_cur * STEP;
@@ -260,18 +273,22 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
             constexpr int half = decltype(half_c)::value;
             using VN = std::integral_constant<int, (NP == 2 ? 4 : 12)>;
             sync(E0{});
+            mark(1);
             chunk_begin(MB{}, I0{}, true);
             if (with_gelu) gelu0(std::integral_constant<int, 2 * half>{}, hsrc);
             fc_mma(wb[0][0], xn[8 * half], wb[0][1], xn[8 * half + 1], hdst);
             pin(VN{});
+            mark(2);
             chunk_begin(MB{}, I1{}, true);
             if (with_gelu) gelu1(std::integral_constant<int, 2 * half>{}, par);
             fc_mma(wb[1][0], xn[8 * half + 2], wb[1][1], xn[8 * half + 3], hdst);
             pin(VN{});
+            mark(3);
             chunk_begin(MB{}, I2{}, true);
             if (with_gelu) gelu0(std::integral_constant<int, 2 * half + 1>{}, hsrc);
             fc_mma(wb[0][0], xn[8 * half + 4], wb[0][1], xn[8 * half + 5], hdst);
             pin(VN{});
+            mark(4);
             chunk_begin(MB{}, I3{}, next_step_has_fc);
             if (with_gelu) gelu1(std::integral_constant<int, 2 * half + 1>{}, par);
             fc_mma(wb[1][0], xn[8 * half + 6], wb[1][1], xn[8 * half + 7], hdst);
@@ -311,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
             // ---- step 1: GELU(tile 31), second k-step; rows landed; LayerNorm statistics (two-pass, model.py:19-20) ----
             sync(std::integral_constant<int, 32>{});
             gelu_only(I1{}, hB, 1);
-            asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) : [n] "n"(PW) : "memory");
+            asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) : [n] "n"(PWP) : "memory");
             asm volatile("" : "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]), "+v"(xr[15]));
             asm volatile("" : "+v"(xr[16]), "+v"(xr[17]), "+v"(xr[18]), "+v"(xr[19]), "+v"(xr[20]), "+v"(xr[21]), "+v"(xr[22]), "+v"(xr[23]));
             asm volatile("" : "+v"(xr[24]), "+v"(xr[25]), "+v"(xr[26]), "+v"(xr[27]), "+v"(xr[28]), "+v"(xr[29]), "+v"(xr[30]), "+v"(xr[31]));
@@ -406,17 +423,21 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
         auto step_pj = [&](auto kk_c, int par, bool next_step_has_pj, bool prefetch_next_tile, auto pending_c) {
             constexpr int kk = decltype(kk_c)::value;
             sync(pending_c);
+            mark(1);
             chunk_begin(MB{}, I0{}, true);
             if (kk == 0) load_hidden(I1{}, par);
             if (kk == 1 && prefetch_next_tile) load_hidden(I0{}, par ^ 1);
             pj_mma(wb[0][0], wb[0][1], hf[kk], acc[0], acc[1]);
             pin(E0{});
+            mark(2);
             chunk_begin(MB{}, I1{}, true);
             pj_mma(wb[1][0], wb[1][1], hf[kk], acc[2], acc[3]);
             pin(E0{});
+            mark(3);
             chunk_begin(MB{}, I2{}, true);
             pj_mma(wb[0][0], wb[0][1], hf[kk], acc[4], acc[5]);
             pin(E0{});
+            mark(4);
             chunk_begin(MB{}, I3{}, next_step_has_pj);
             pj_mma(wb[1][0], wb[1][1], hf[kk], acc[6], acc[7]);
             pin(E0{});
@@ -461,7 +482,8 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
             step_pj(I1{}, 1, false, false, E0{});          // step 3: every output tile is final after it
             ld(J0{}); ld(J1{});
             // ---- steps 4 .. 7: residual add + store, two output tiles per step, loads one step ahead ----
-            // vector-memory operations per step: PW ring pieces | 8 loads (two tiles) | 8 stores (two tiles)
+            // vector-memory operations of a consumer per step: 8 loads (two tiles) | 8 stores (two tiles)   (no ring pieces)
+            constexpr int PW = 0;
             sync(std::integral_constant<int, 8>{});                                       // step 4 (pending: L0 L1)
             ld(J2{}); ld(J3{});
             st(J0{}, std::integral_constant<int, PW + 8>{}); st(J1{}, std::integral_constant<int, PW + 8 + 4>{});
@@ -502,7 +524,8 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     if constexpr (STAMPS != 0) {
         if ((wave == 0 || wave == 4) && lane == 0) {
             unsigned long long *o = stamps + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 4;
-            o[0] = t_in[0]; o[1] = t_in[1]; o[2] = __builtin_readcyclecounter(); o[3] = STAMPS == 2 ? t_sync : wall_clock64();
+            if constexpr (STAMPS == 3) { o[0] = t_ph[0]; o[1] = t_ph[1]; o[2] = t_ph[2] + t_ph[3] + t_ph[4]; o[3] = t_ph[5]; }
+            else { o[0] = t_in[0]; o[1] = t_in[1]; o[2] = __builtin_readcyclecounter(); o[3] = STAMPS == 2 ? t_sync : wall_clock64(); }
         }
     }
 }

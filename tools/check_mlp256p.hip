@@ -169,6 +169,17 @@ int main(int argc, char **argv)
         for (int w = 0; w < ncu; w++) { tp += (double)(h2[8 * w + 2] - h2[8 * w]); sp += (double)h2[8 * w + 3]; tc += (double)(h2[8 * w + 6] - h2[8 * w + 4]); sc += (double)h2[8 * w + 7]; }
         printf("mlp256p (instrumented): producer wave 0 spends %.1f %% of its cycles in wait + barrier, consumer wave 4 %.1f %%\n", 100 * sp / tp, 100 * sc / tc);
     }
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256p_kernel<F16T, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    mlp256p_kernel<F16T, 2, 3><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb, st);
+    hipDeviceSynchronize();
+    {
+        std::vector<unsigned long long> h3((size_t)ncu * 8);
+        hipMemcpy(h3.data(), st, h3.size() * 8, hipMemcpyDeviceToHost);
+        double ph[8] = {0};
+        for (int w = 0; w < ncu; w++) for (int i = 0; i < 8; i++) ph[i] += (double)h3[8 * w + i] / ncu / (nb / (double)ncu) / kMPPeriod;
+        printf("mlp256p phases, cycles per 32-KiB step (all steps of a block averaged): producer: wait+barrier %.0f | DMA issue %.0f | chunks 0-2 %.0f | chunk 3 %.0f;  "
+               "consumer: wait+barrier %.0f | DMA issue %.0f | chunks 0-2 %.0f | chunk 3 %.0f\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+    }
     printf("mlp256p stamps: %.0f shader cycles per workgroup = %.0f per block = %.1f per 32-KiB stream step (24 MFMAs per wave); shader clock %.3f GHz\n", cyc / ncu,
            cyc / ncu / (nb / (double)ncu), cyc / ncu / (nb / (double)ncu) / kMPPeriod, cyc / rt / 10.0);
     return rc;
