@@ -15,6 +15,13 @@ static float gauss(uint64_t &st)
     auto u = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)((st >> 11) + 1) / 9007199254740993.0; };
     return (float)(sqrt(-2.0 * log(u())) * cos(6.283185307179586 * u()));
 }
+// experiment: zero the low `drop` mantissa bits of every lo-plane value of a packed weight stream (planes alternate per KiB)
+__global__ void mask_lo_planes(uint16_t *ws, size_t n16, int drop)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    if ((i >> 9) & 1) ws[i] &= (uint16_t)(0xffffu << drop);
+}
 int main(int argc, char **argv)
 {
     const int C = 256;
@@ -152,6 +159,16 @@ int main(int argc, char **argv)
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         printf("mlp256_kernel  (round 2)                    : %.3f ms per 4096-row launch  [%s]\n", ms / 60, hipGetErrorString(hipGetLastError()));
     }
+    for (int drop : {5, 8, 10}) {                          // energy experiment: fewer significant bits in the weights' lo planes
+        const size_t n16 = (size_t)kMPPeriod * 16 * 2 * 512;
+        mask_lo_planes<<<(unsigned)((n16 + 255) / 256), 256>>>(pkp, n16, drop);
+        float ms;
+        hipEventRecord(e0);
+        for (int i = 0; i < 60; i++) mlp256p_kernel<F16T, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("mlp256p_kernel, weights' lo planes with the low %2d mantissa bits zeroed: %.3f ms per launch\n", drop, ms / 60);
+    }
+    pack_mlp256p_kernel<F16T, 2><<<(kMPPeriod * 16 * 64 + 255) / 256, 256>>>(fc, pj, g, pkp, sc1, sc2);
     for (int i = 0; i < 40; i++) mlp256p_kernel<F16T, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb);
     mlp256p_kernel<F16T, 2, 1><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb, st);
     hipDeviceSynchronize();
