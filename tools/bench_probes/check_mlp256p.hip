@@ -7,7 +7,7 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
-#include "../mapf_gpt_amd/csrc/gpt_kernels_c256p.h"
+#include "../../mapf_gpt_amd/csrc/gpt_kernels_c256p.h"
 namespace mgpt { void set_error(const char *, ...) {} }
 using namespace mgpt::fastk;
 static float gauss(uint64_t &st)

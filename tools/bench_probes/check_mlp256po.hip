@@ -8,7 +8,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
-#include "../mapf_gpt_amd/csrc/gpt_kernels_c256po.h"
+#include "../experiments/gpt_kernels_c256po.h"
 namespace mgpt { void set_error(const char *, ...) {} }
 using namespace mgpt::fastk;
 static float gauss(uint64_t &st)

@@ -1,11 +1,11 @@
-// tools/check_mlp256.hip -- mlp256_kernel against an fp64 host computation of x + c_proj(GELU_erf(c_fc(LayerNorm(x))))
+// tools/check_mlp256w.hip -- mlp256w_kernel (two waves per SIMD, 16 tokens per wave) against an fp64 host computation of x + c_proj(GELU_erf(c_fc(LayerNorm(x))))
 // (model.py:84-89, 103) on random rows and weights.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <math.h>
 #include <vector>
-#include "../mapf_gpt_amd/csrc/gpt_kernels_c256.h"
+#include "../experiments/gpt_kernels_c256w.h"
 namespace mgpt { void set_error(const char *, ...) {} }
 using namespace mgpt::fastk;
 static float frand(unsigned &s) { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 8388608.f - 1.f; }
@@ -25,7 +25,7 @@ int main()
     hipMemcpy(pj, hpj.data(), hpj.size() * 4, hipMemcpyHostToDevice);
     const float sc = 32768.f;
     uint16_t *pk2; hipMalloc(&pk2, (size_t)kM256Steps * 8 * 2 * 512 * 2);
-    pack_mlp256_kernel<F16T, 2><<<(kM256Steps * 8 * 64 + 255) / 256, 256>>>(fc, pj, pk2, sc, sc);
+    pack_mlp256w_kernel<F16T, 2><<<(kM256Steps * 8 * 64 + 255) / 256, 256>>>(fc, pj, pk2, sc, sc);
     std::vector<float2> lut(kGeluLutN);
     for (int i = 0; i < kGeluLutN; i++) {
         const double v0 = (i - (double)kGeluLutBias) / kGeluLutScale, v1 = (i + 1 - (double)kGeluLutBias) / kGeluLutScale;
@@ -34,8 +34,8 @@ int main()
     }
     float2 *dl; hipMalloc(&dl, lut.size() * 8); hipMemcpy(dl, lut.data(), lut.size() * 8, hipMemcpyHostToDevice);
     const int lds2 = 8 * 8 * 2 * 1024 + kGeluLutN * 8;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256_kernel<F16T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-    mlp256_kernel<F16T, 2><<<M / 128, 256, lds2>>>(x2, g, pk2, 1.f / sc, 1.f / sc, dl);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256w_kernel<F16T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    mlp256w_kernel<F16T, 2><<<M / 128, 512, lds2>>>(x2, g, pk2, 1.f / sc, 1.f / sc, dl);
     hipDeviceSynchronize();
     printf("launch status: %s\n", hipGetErrorString(hipGetLastError()));
     std::vector<float> b(hx.size());

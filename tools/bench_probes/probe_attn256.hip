@@ -5,7 +5,7 @@
 #include <math.h>
 #include <algorithm>
 #include <vector>
-#include "../mapf_gpt_amd/csrc/gpt_kernels_c256.h"
+#include "../../mapf_gpt_amd/csrc/gpt_kernels_c256.h"
 namespace mgpt { void set_error(const char *, ...) {} }
 using namespace mgpt::fastk;
 template <int ABL>

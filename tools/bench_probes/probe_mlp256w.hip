@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "experiments/gpt_kernels_c256w.h"
+#include "../experiments/gpt_kernels_c256w.h"
 namespace mgpt { void set_error(const char *, ...) {} }
 using namespace mgpt::fastk;
 

@@ -11,7 +11,7 @@
 //     16 .. 21        x rows in, + , store; LayerNorm; split                -
 //     22 .. 85        c_fc(tile t = (R - 22) / 2), GELU(t - 1)              c_proj(tile t - 2) from step 26
 #pragma once
-#include "gpt_kernels_c256p.h"
+#include "../../mapf_gpt_amd/csrc/gpt_kernels_c256p.h"
 
 namespace mgpt {
 namespace fastk {
