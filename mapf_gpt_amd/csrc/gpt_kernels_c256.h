@@ -1,6 +1,6 @@
 // gpt_kernels_c256.h -- 16-bit-MFMA kernels for n_embd = 256 (the MAPF-GPT-6M shape), gfx950.
 //
-// What round 1 got wrong for this shape, measured in round 2 (tools/probe_interleave.hip,
+// What round 1 got wrong for this shape, measured in round 2 (tools/bench_probes/probe_interleave.hip,
 // profiles/r02_probe_interleave.txt): when non-MFMA instructions are INTERLEAVED one v_mfma_f32_32x32x16 at a time, a
 // SIMD hides ~6 plain VALU instructions (or ~3 transcendentals, or 1-2 ds_read_b128 whose latency is covered) behind
 // every MFMA at no cost in MFMA rate; only when they are clumped before/after a run of MFMAs does their issue time add
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void pack_mlp256_kernel(const float *__restric
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
 }
 
-// ABL (tools/probe_mlp256.hip only; the library instantiates ABL = 0): 1 no weight DMA in the loop, 2 no GELU table gather,
+// ABL (tools/bench_probes/probe_mlp256.hip only; the library instantiates ABL = 0): 1 no weight DMA in the loop, 2 no GELU table gather,
 // 4 no barrier, 8 no MFMAs, 16 no fragment reads in the loop -- results are wrong unless ABL == 0.  32: wave 0 of every
 // block leaves (s_memtime, s_memrealtime) at kernel entry / first ring step / after the last step / exit in stamps[block][8].
 //
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restri
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
 }
 
-// ABL (tools/probe_attn256.hip only; the library instantiates ABL = 0): 1 no weight DMA in the loop, 2 no softmax arithmetic,
+// ABL (tools/bench_probes/probe_attn256.hip only; the library instantiates ABL = 0): 1 no weight DMA in the loop, 2 no softmax arithmetic,
 // 4 no attention phase, 8 no projection MFMAs, 16 no ring barriers -- results are wrong unless ABL == 0.  32: wave 0 of every
 // block leaves stamps[block][8] = {entry cycles, entry 100-MHz ticks, cycles after LayerNorm, exit cycles, exit ticks,
 // cycles in the q|k|v projection steps, cycles waiting at the head's k / v barrier, cycles in the attention phase}.

@@ -95,7 +95,7 @@ __device__ __forceinline__ void vm_wait()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// STAMPS (tools/check_mlp256p.hip only): 1 = wave 0 and wave 4 of every workgroup leave s_memtime / s_memrealtime at entry and
+// STAMPS (tools/bench_probes/check_mlp256p.hip only): 1 = wave 0 and wave 4 of every workgroup leave s_memtime / s_memrealtime at entry and
 // exit; 2 = cycles spent in wait + barrier instead of the exit wall clock; 3 = cycles per phase of a step: {wait + barrier,
 // DMA issue + slot bookkeeping, chunks 0-2, chunk 3 (up to the next step's top)}.
 template <class T, int NP, int STAMPS = 0>

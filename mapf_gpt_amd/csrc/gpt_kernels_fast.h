@@ -4,7 +4,7 @@
 // lo = fp16(v - hi) (22 significand bits together); a product is the 3-term expansion
 //     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi            (dropped a_lo*b_lo ~ 2^-22 |ab|)
 // issued as three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator.  fp16 subnormal inputs are
-// honoured by the matrix core on gfx950 (probed: tools/probe_mfma.hip, profiles/r01_probe_mfma.txt), and
+// honoured by the matrix core on gfx950 (probed: tools/bench_probes/probe_mfma.hip, profiles/r01_probe_mfma.txt), and
 // weights are pre-scaled by a power of two so their lo parts stay normal.  That buys ~fp32 accuracy
 // (logit error ~1e-6, tested against the reference goldens at 1e-5) at 1/3 of the 2.5 PFLOP/s fp16 rate
 // instead of the 157 TFLOP/s fp32-MFMA rate.  BF16 mode = one plane, one pass (the reference's autocast mode).
@@ -301,7 +301,7 @@ __device__ __forceinline__ float gelu_folded(float v)
 
 // gelu_folded on two values with packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32): the same operations in the same order,
 // so the same results.  Pays in the one-wave-per-SIMD GEMM epilogue, where an instruction costs ~5 cycles whatever it does
-// (tools/probe_pk.hip); the register-tight fused kernels keep the scalar form (its constants are inline literals).
+// (tools/bench_probes/probe_pk.hip); the register-tight fused kernels keep the scalar form (its constants are inline literals).
 __device__ __forceinline__ f32x2 gelu_folded2(f32x2 v)
 {
     const f32x2 u = {__builtin_amdgcn_fmed3f(v[0], -5.6568542f, 5.6568542f), __builtin_amdgcn_fmed3f(v[1], -5.6568542f, 5.6568542f)};
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
 
 // NWV = 4: one wave per SIMD, 128 x 128 per wave (512 registers).  NWV = 8: two waves per SIMD, 64 x 128 per wave (256
 // registers): 1.5x the LDS reads per MFMA, but the second wave on the SIMD covers the issue time of the ds_reads, the
-// refill loads and the epilogue's VALU work, all of which otherwise ADD to the MFMA time (tools/probe_mfma_lds*.hip:
+// refill loads and the epilogue's VALU work, all of which otherwise ADD to the MFMA time (tools/bench_probes/probe_mfma_lds*.hip:
 // 460 -> 373 ns per block k-step in bf16, against 311 ns for the MFMAs alone).
 template <class T, int NP, int EPI, int NWV>
 __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)

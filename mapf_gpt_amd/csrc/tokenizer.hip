@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void tok_next_kernel(AgentRec *__restrict__ re
 //        and a 12-entry distance-bucket table.
 //   HBM reads per row: the 121-cell window of the agent's own distance field (one byte per cell from
 //        `dist8` when every field fits a byte, else two from `dist`); writes: one coalesced 256-B store.
-// Measured (tools/bench_tokenizer.py, tools/probe_salu.hip): the kernel is instruction-issue bound before
+// Measured (tools/bench_tokenizer.py, tools/bench_probes/probe_salu.hip): the kernel is instruction-issue bound before
 // it is HBM bound -- a wave64 VALU instruction costs its SIMD ~1.6 ns, a scalar one ~1.8 ns, and an LDS
 // store whose lanes collide on one address serialises -- so the row body is written around issue count:
 //   * window token = LUT[med3(v - (mid-21), 0, 42)] (43 = unreachable);
