@@ -159,6 +159,20 @@ int main(int argc, char **argv)
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         printf("mlp256_kernel  (round 2)                    : %.3f ms per 4096-row launch  [%s]\n", ms / 60, hipGetErrorString(hipGetLastError()));
     }
+    {   // upper bound of what decoupling the waves could buy: the same kernel without its s_barrier (results wrong, x restored after)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256p_kernel<F16T, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+        float ms;
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; i++) mlp256p_kernel<F16T, 2, 4><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb, st);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h4((size_t)ncu * 8);
+        hipMemcpy(h4.data(), st, h4.size() * 8, hipMemcpyDeviceToHost);
+        double cyc4 = 0, rt4 = 0;
+        for (int w = 0; w < ncu; w++) { cyc4 += (double)(h4[8 * w + 2] - h4[8 * w]); rt4 += (double)(h4[8 * w + 3] - h4[8 * w + 1]); }
+        printf("mlp256p_kernel WITHOUT s_barrier (wrong results, timing only): %.3f ms per launch, %.0f cycles per block, clock %.3f GHz\n", ms / 20,
+               cyc4 / ncu / (nb / (double)ncu), cyc4 / rt4 / 10.0);
+        hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    }
     for (int drop : {5, 8, 10}) {                          // energy experiment: fewer significant bits in the weights' lo planes
         const size_t n16 = (size_t)kMPPeriod * 16 * 2 * 512;
         mask_lo_planes<<<(unsigned)((n16 + 255) / 256), 256>>>(pkp, n16, drop);
