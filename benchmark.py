@@ -30,9 +30,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        # MGPT_BENCH_BACKEND=gloo + MGPT_BENCH_SHARE_GPU=1: dry run of the sharded path on a one-GPU box (as in bench.py)
+        backend = os.environ.get("MGPT_BENCH_BACKEND", "nccl")
+        local = 0 if os.environ.get("MGPT_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     MAPFGPTInference.build()                                                   # benchmark.py:26
     overrides = dict(w.split("=", 1) for w in a.weights)
     folders = a.folders or sorted(d for d in os.listdir(a.eval_root) if os.path.isdir(os.path.join(a.eval_root, d)))
@@ -46,7 +51,7 @@ def main():
             if name in overrides:
                 algo["path_to_weights"] = overrides[name]
             if world > 1:
-                algo["device"] = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+                algo["device"] = f"cuda:{0 if os.environ.get('MGPT_BENCH_SHARE_GPU') else int(os.environ.get('LOCAL_RANK', '0'))}"
         if rank == 0:
             print(f"=== {folder}")
         ev.evaluation(cfg, eval_dir=os.path.join(a.eval_root, folder), registry=reg, precision=a.precision, rank=rank, world=world)

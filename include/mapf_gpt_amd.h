@@ -89,6 +89,11 @@ int mgpt_tokenizer_create_agents(mgpt_tokenizer *tok, const int16_t *d_pos, cons
  * 0 skips that comparison (on_target = "nothing": goals never change). */
 int mgpt_tokenizer_update_agents(mgpt_tokenizer *tok, const int16_t *d_pos, const int16_t *d_goal,
                                  const int32_t *d_actions, int goals_may_change, void *stream);
+/* The same for a subset of the instances: d_active uint8 [n_inst] (NULL = all); instances with 0 keep their state (position,
+ * action history, goal, distance field) untouched -- what the adapter needs when one act_batch call (inference.py:151-172)
+ * presents only some of the environment slots that share a tokenizer context. */
+int mgpt_tokenizer_update_agents_masked(mgpt_tokenizer *tok, const int16_t *d_pos, const int16_t *d_goal,
+                                        const int32_t *d_actions, const uint8_t *d_active, int goals_may_change, void *stream);
 
 /* = generate_observations(), cpp:516-528.  d_tokens: uint8 [n_inst * n_agents, 256], row-major,
  * row = inst * n_agents + agent.  Token ids are < 67 and fit a byte (the reference widens them to
@@ -125,6 +130,10 @@ int mgpt_env_step(mgpt_env *env, const int32_t *d_actions, void *stream);
 int mgpt_env_state(mgpt_env *env, const int16_t **d_pos, const int16_t **d_goal, const uint8_t **d_done);
 /* the same state copied (stream-ordered, device to device) into caller-owned buffers; any may be NULL */
 int mgpt_env_copy_state(mgpt_env *env, int16_t *d_pos_out, int16_t *d_goal_out, uint8_t *d_done_out, void *stream);
+/* The reference-shaped list API (create_env.py:14-15: step(list) -> lists) in one call: h_actions int32 [n_inst * n_agents] on
+ * the HOST (NULL: no step, just read the state back, e.g. after reset), state back into the HOST buffer
+ * h_state_out = [pos int16 n*2 | goal int16 n*2 | done uint8 n_inst], n = n_inst * n_agents.  Synchronises `stream`. */
+int mgpt_env_step_host(mgpt_env *env, const int32_t *h_actions, uint8_t *h_state_out, void *stream);
 /* per-instance episode metrics, float32 [n_inst, 6] = {CSR, ISR, SoC, makespan, ep_length, avg_agents_density}
  * (the keys the reference's result tables use: eval_configs/05-puzzles/05-puzzles.yaml:49-58; avg_agents_density =
  * POGEMA's AgentsDensityWrapper of experiment_setup/create_env.py:38: mean over the reset observation and every step of

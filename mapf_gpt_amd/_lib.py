@@ -44,6 +44,7 @@ SYMBOLS = {
     "mgpt_tokenizer_set_grids": (_i, [_vp, _vp, _vp]),
     "mgpt_tokenizer_create_agents": (_i, [_vp, _vp, _vp, _vp]),
     "mgpt_tokenizer_update_agents": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "mgpt_tokenizer_update_agents_masked": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mgpt_tokenizer_generate_observations": (_i, [_vp, _vp, _vp]),
     "mgpt_tokenizer_state": (_i, [_vp, _pp, _pp]),
     "mgpt_tokenizer_copy_state": (_i, [_vp, _vp, _vp, _vp]),
@@ -54,6 +55,7 @@ SYMBOLS = {
     "mgpt_env_step": (_i, [_vp, _vp, _vp]),
     "mgpt_env_state": (_i, [_vp, _pp, _pp, _pp]),
     "mgpt_env_copy_state": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mgpt_env_step_host": (_i, [_vp, _vp, _vp, _vp]),
     "mgpt_env_metrics": (_i, [_vp, _vp, _vp]),
     "mgpt_env_set_lifelong": (_i, [_vp, _vp, _i, _vp]),
     "mgpt_env_lifelong_counts": (_i, [_vp, _vp, _vp]),

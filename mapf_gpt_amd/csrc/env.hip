@@ -229,6 +229,8 @@ struct mgpt_env {
     uint8_t *grids = nullptr;
     int16_t *pos = nullptr, *goal = nullptr;
     int32_t *arrive = nullptr, *tcount = nullptr;
+    int32_t *act_stage = nullptr;               // device staging of host actions (mgpt_env_step_host)
+    uint8_t *state_blob = nullptr;              // [pos int16 total*2 | goal int16 total*2 | done u8 n_inst]: pos / goal / done point into it
     uint8_t *done = nullptr;
     uint8_t *wfree = nullptr;           // [n_grids][H][W] traversable cells of the observation window around each cell
     double *dens = nullptr;             // [n_inst] running sum of the per-sample mean agent densities
@@ -248,11 +250,15 @@ extern "C" int mgpt_env_create(mgpt_env **out, int n_inst, int n_agents, int H, 
     e->n_inst = n_inst; e->n_agents = n_agents; e->H = H; e->W = W; e->n_grids = n_grids; e->max_steps = max_episode_steps;
     const size_t total = (size_t)n_inst * n_agents;
     hipError_t err = hipMalloc(&e->grids, (size_t)n_grids * H * W);
-    if (err == hipSuccess) err = hipMalloc(&e->pos, total * 2 * sizeof(int16_t));
-    if (err == hipSuccess) err = hipMalloc(&e->goal, total * 2 * sizeof(int16_t));
+    // pos | goal | done live in ONE allocation, in the order mgpt_env_step_host hands them to the host (one copy)
+    if (err == hipSuccess) err = hipMalloc(&e->state_blob, total * 8 + (size_t)n_inst);
+    if (err == hipSuccess) {
+        e->pos = reinterpret_cast<int16_t *>(e->state_blob);
+        e->goal = e->pos + total * 2;
+        e->done = reinterpret_cast<uint8_t *>(e->goal + total * 2);
+    }
     if (err == hipSuccess) err = hipMalloc(&e->arrive, total * sizeof(int32_t));
     if (err == hipSuccess) err = hipMalloc(&e->tcount, (size_t)n_inst * sizeof(int32_t));
-    if (err == hipSuccess) err = hipMalloc(&e->done, (size_t)n_inst);
     if (err == hipSuccess) err = hipMalloc(&e->wfree, (size_t)n_grids * H * W);
     if (err == hipSuccess) err = hipMalloc(&e->dens, (size_t)n_inst * sizeof(double));
     if (err != hipSuccess) {
@@ -267,9 +273,9 @@ extern "C" int mgpt_env_create(mgpt_env **out, int n_inst, int n_agents, int H, 
 extern "C" int mgpt_env_destroy(mgpt_env *e)
 {
     if (!e) return MGPT_OK;
-    (void)hipFree(e->grids); (void)hipFree(e->pos); (void)hipFree(e->goal);
-    (void)hipFree(e->arrive); (void)hipFree(e->tcount); (void)hipFree(e->done);
-    (void)hipFree(e->wfree); (void)hipFree(e->dens);
+    (void)hipFree(e->grids); (void)hipFree(e->state_blob);
+    (void)hipFree(e->arrive); (void)hipFree(e->tcount);
+    (void)hipFree(e->wfree); (void)hipFree(e->dens); (void)hipFree(e->act_stage);
     (void)hipFree(e->goal_queue); (void)hipFree(e->qnext); (void)hipFree(e->reached);
     delete e;
     return MGPT_OK;
@@ -356,6 +362,25 @@ extern "C" int mgpt_env_step(mgpt_env *e, const int32_t *d_actions, void *stream
                        e->n_grids, e->n_agents, e->H, e->W, e->max_steps, e->pos, e->goal, d_actions, e->arrive,
                        e->tcount, e->done, e->goal_queue, e->queue_len, e->qnext, e->reached, e->wfree, e->dens);
     MGPT_LAUNCH_CHECK();
+    return MGPT_OK;
+}
+
+// Host-list step of the reference-shaped API (create_env.py:14-15: lists in, lists out) in ONE call: actions from a host buffer,
+// the step, and positions / goals / done flags back into a host buffer [pos int16 n*2 | goal int16 n*2 | done u8 n_inst],
+// n = n_inst * n_agents.  h_actions may be NULL (no step: just pull the state, e.g. after reset).  Synchronises the stream.
+extern "C" int mgpt_env_step_host(mgpt_env *e, const int32_t *h_actions, uint8_t *h_state_out, void *stream)
+{
+    MGPT_REQUIRE(e && h_state_out, MGPT_ERR_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)e->n_inst * e->n_agents;
+    if (h_actions) {
+        if (!e->act_stage) MGPT_HIP(hipMalloc(&e->act_stage, n * sizeof(int32_t)));
+        MGPT_HIP(hipMemcpyAsync(e->act_stage, h_actions, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        int rc = mgpt_env_step(e, e->act_stage, stream);
+        if (rc != MGPT_OK) return rc;
+    }
+    MGPT_HIP(hipMemcpyAsync(h_state_out, e->state_blob, 8 * n + (size_t)e->n_inst, hipMemcpyDeviceToHost, s));   // pos | goal | done
+    MGPT_HIP(hipStreamSynchronize(s));
     return MGPT_OK;
 }
 

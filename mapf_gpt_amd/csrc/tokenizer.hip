@@ -151,10 +151,14 @@ __global__ __launch_bounds__(256) void tok_update_kernel(AgentRec *__restrict__ 
                                                          const int16_t *__restrict__ goal,
                                                          const int32_t *__restrict__ actions, uint8_t *__restrict__ dirty,
                                                          int total, int check_goals, const uint16_t *__restrict__ dist,
-                                                         int H, int W, int gstep)
+                                                         int H, int W, int gstep, const uint8_t *__restrict__ active, int n_agents)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
+    if (active != nullptr && active[i / n_agents] == 0) {   // instance not presented in this call: its state does not advance
+        if (check_goals) dirty[i] = 0;
+        return;
+    }
     AgentRec r = recs[i];
     r.pr = pos[2 * i]; r.pc = pos[2 * i + 1];
     const int act = actions[i];
@@ -774,6 +778,13 @@ extern "C" int mgpt_tokenizer_create_agents(mgpt_tokenizer *t, const int16_t *d_
 extern "C" int mgpt_tokenizer_update_agents(mgpt_tokenizer *t, const int16_t *d_pos, const int16_t *d_goal,
                                             const int32_t *d_actions, int goals_may_change, void *stream)
 {
+    return mgpt_tokenizer_update_agents_masked(t, d_pos, d_goal, d_actions, nullptr, goals_may_change, stream);
+}
+
+extern "C" int mgpt_tokenizer_update_agents_masked(mgpt_tokenizer *t, const int16_t *d_pos, const int16_t *d_goal,
+                                                   const int32_t *d_actions, const uint8_t *d_active, int goals_may_change,
+                                                   void *stream)
+{
     MGPT_REQUIRE(t && d_pos && d_actions && (d_goal || !goals_may_change), MGPT_ERR_ARG, "NULL argument");
     MGPT_REQUIRE(t->have_agents, MGPT_ERR_STATE, "create_agents must precede update_agents");
     hipStream_t s = (hipStream_t)stream;
@@ -781,7 +792,7 @@ extern "C" int mgpt_tokenizer_update_agents(mgpt_tokenizer *t, const int16_t *d_
     {
         ProfScope ps(P_TOK_UPDATE, s);
         hipLaunchKernelGGL(tok_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, d_pos, d_goal, d_actions,
-                           t->dirty, total, goals_may_change ? 1 : 0, t->dist, t->H, t->W, t->step);
+                           t->dirty, total, goals_may_change ? 1 : 0, t->dist, t->H, t->W, t->step, d_active, t->n_agents);
         MGPT_LAUNCH_CHECK();
     }
     if (goals_may_change) {

@@ -122,28 +122,40 @@ class GridEnv:
         self._env = BatchedEnv(self.grid, 1, num_agents, max_episode_steps, device=device)
         self._obst = self.grid.astype(np.float32)
 
-    def _obs(self):
-        pos, goal, _ = self._env.sync_state()
-        pos, goal = pos.cpu().numpy()[0], goal.cpu().numpy()[0]
-        return [{"global_xy": (int(pos[a, 0]), int(pos[a, 1])), "global_target_xy": (int(goal[a, 0]), int(goal[a, 1])),
-                 "global_obstacles": self._obst} for a in range(self.num_agents)]
+    def _pull(self, actions=None):
+        """One library call: (optional) step with host actions, then positions / goals / done back on the host."""
+        e, n = self._env, self.num_agents
+        if not hasattr(self, "_host"):
+            self._host = np.empty(8 * n + 8, dtype=np.uint8)
+        act = None
+        if actions is not None:
+            act = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1)
+            assert act.size == n
+        with _lib.on_device(e.device):
+            _lib.check(_lib.lib().mgpt_env_step_host(e._h, ctypes.c_void_p(act.ctypes.data) if act is not None else None,
+                                                     ctypes.c_void_p(self._host.ctypes.data), _lib.stream_ptr()))
+        host = self._host
+        return host[:4 * n].view(np.int16).reshape(n, 2), host[4 * n:8 * n].view(np.int16).reshape(n, 2), int(host[8 * n])
+
+    def _obs(self, pos, goal):
+        p, g = pos.tolist(), goal.tolist()
+        return [{"global_xy": (p[a][0], p[a][1]), "global_target_xy": (g[a][0], g[a][1]), "global_obstacles": self._obst}
+                for a in range(self.num_agents)]
 
     def reset(self, seed=None, **kwargs):
         if seed is not None:
             self.seed = seed
         pos, goal = maps.place_agents(self.grid, self.num_agents, self.seed, self.start_ok, self.goal_ok)
         self._env.reset(torch.from_numpy(pos[None]), torch.from_numpy(goal[None]))
-        return self._obs(), {}
+        pos, goal, _ = self._pull()
+        return self._obs(pos, goal), {}
 
     def step(self, actions):
-        act = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(1, -1)).to(self._env.device)
-        self._env.step(act)
-        obs = self._obs()
-        done = int(self._env.done.cpu()[0])
+        pos, goal, done = self._pull(actions)
+        obs = self._obs(pos, goal)
         terminated = [done == 1] * self.num_agents
         truncated = [done == 2] * self.num_agents
-        pos, goal = self._env.pos.cpu().numpy()[0], self._env.goal.cpu().numpy()[0]
-        rewards = [float((pos[a] == goal[a]).all()) for a in range(self.num_agents)]
+        rewards = (pos == goal).all(axis=1).astype(np.float64).tolist()
         infos = [{} for _ in range(self.num_agents)]
         if done:
             m = self._env.metrics().cpu().numpy()[0]

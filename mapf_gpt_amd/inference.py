@@ -60,10 +60,22 @@ def strip_prefix_from_state_dict(state_dict, prefix="_orig_mod."):
     return weights.strip_prefix(state_dict, prefix)
 
 
+class _SlotGroup:
+    """One tokenizer context for environment slots of equal shape: instance i = slot slots[i], with its own map."""
+
+    def __init__(self, slots, grids, n, params, device):
+        self.slots = list(slots)
+        self.index = {p: i for i, p in enumerate(self.slots)}
+        self.k, self.n = len(self.slots), int(n)
+        self.tok = BatchedTokenizer(grids, self.k, self.n, params, device=device)
+        self.rows = torch.empty((self.k * self.n, 256), dtype=torch.uint8, device=device)
+        self.created = False
+
+
 class MAPFGPTInference:
     def __init__(self, cfg: MAPFGPTInferenceConfig, net=None):
         self.cfg = cfg
-        self._obs_generators = {}     # env slot -> BatchedTokenizer (one instance)
+        self._obs_generators = {}     # env slot -> the tokenizer context (shared _SlotGroup) that holds its instance
         self._last_actions = {}       # env slot -> list[int]
         if self.cfg.device is None:
             self.cfg.device = "cuda"
@@ -110,25 +122,82 @@ class MAPFGPTInference:
 
     # ---- per-step path ---------------------------------------------------------------------
     def _prepare_inputs(self, pos, observations):
-        """= inference.py:127-146 -> uint8 device tensor [n_agents, 256]."""
+        """= inference.py:127-146 -> uint8 device tensor [n_agents, 256] (one environment; act_batch handles many at once)."""
         if isinstance(observations[0], dict):
-            n = len(observations)
-            agent_positions = np.asarray([obs["global_xy"] for obs in observations], dtype=np.int16).reshape(1, n, 2)
-            goals = np.asarray([obs["global_target_xy"] for obs in observations], dtype=np.int16).reshape(1, n, 2)
-            d_pos = torch.from_numpy(agent_positions).to(self.cfg.device)
-            d_goal = torch.from_numpy(goals).to(self.cfg.device)
-            if pos not in self._obs_generators:
-                grid = np.asarray(observations[0]["global_obstacles"]).copy().astype(int)     # inference.py:135
-                gen = BatchedTokenizer(grid, 1, n, self.input_parameters, device=self.cfg.device)
-                gen.create_agents(d_pos, d_goal)                                             # inference.py:138
-                self._obs_generators[pos] = gen
-                self._last_actions[pos] = [-1] * n                                           # inference.py:140
-            gen = self._obs_generators[pos]
-            act = torch.as_tensor(np.asarray(self._last_actions[pos], dtype=np.int32).reshape(1, n)).to(self.cfg.device)
-            gen.update_agents(d_pos, d_goal, act, goals_may_change=True)                     # inference.py:142-144
-            return gen.generate_observations()                                               # inference.py:145
+            return self._tokenize([pos], [observations])
         rows = torch.as_tensor(np.asarray(observations, dtype=np.int64))                     # inference.py:146 (pre-tokenised)
         return rows.to(torch.uint8).to(self.cfg.device)
+
+    def _tokenize(self, positions, observations_list, out=None, offsets=None):
+        """Token rows of dict-observation environments -> `out` (uint8 [total, 256], environment e at rows offsets[e] ..).
+
+        Environment slots of equal shape (map frame H x W, agent count) that first appear in the same call share ONE tokenizer
+        context (`_SlotGroup`: one instance per slot, every instance its own map), so a call costs one host-to-device copy, one
+        update launch and one tokens launch per group instead of two launches and a dozen small copies per environment
+        (inference.py:133-145 keeps one ObservationGenerator per slot: same state, kept per instance here).  A later call may
+        present any subset of a group's slots: absent instances are masked out of the update and keep their state."""
+        dev = self.cfg.device
+        counts = [len(o) for o in observations_list]
+        if offsets is None:
+            offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).tolist()
+        if out is None:
+            out = torch.empty((sum(counts), 256), dtype=torch.uint8, device=dev)
+        # new slots: one group per (H, W, n) among the slots this call introduces
+        fresh = {}
+        for pos, obs in zip(positions, observations_list):
+            if pos not in self._obs_generators:
+                grid = np.asarray(obs[0]["global_obstacles"])                                # inference.py:135
+                fresh.setdefault((grid.shape[0], grid.shape[1], len(obs)), []).append((pos, (grid != 0).astype(np.uint8)))
+        for (H, W, n), members in fresh.items():
+            grp = _SlotGroup([p for p, _ in members], np.stack([g for _, g in members]), n, self.input_parameters, dev)
+            for p in grp.slots:
+                self._obs_generators[p] = grp
+                self._last_actions[p] = [-1] * n                                             # inference.py:140
+        # group the call's environments by context
+        touched = {}
+        for e, pos in enumerate(positions):
+            touched.setdefault(id(self._obs_generators[pos]), (self._obs_generators[pos], []))[1].append(e)
+        # one staging buffer for the whole call: per group [actions int32 k*n | positions int16 k*n*2 | goals int16 k*n*2 | active u8 k (+pad)]
+        plan, nbytes = [], 0
+        for grp, envs in touched.values():
+            kn = grp.k * grp.n
+            plan.append((grp, envs, nbytes))
+            nbytes += 12 * kn + ((grp.k + 15) & ~15)
+        buf = np.zeros(nbytes, dtype=np.uint8)
+        for grp, envs, base in plan:
+            kn, n = grp.k * grp.n, grp.n
+            acts = buf[base:base + 4 * kn].view(np.int32)
+            xy = buf[base + 4 * kn:base + 8 * kn].view(np.int16)
+            gxy = buf[base + 8 * kn:base + 12 * kn].view(np.int16)
+            active = buf[base + 12 * kn:base + 12 * kn + grp.k]
+            for e in envs:
+                i, obs = grp.index[positions[e]], observations_list[e]
+                xy[2 * i * n:2 * (i + 1) * n] = np.asarray([o["global_xy"] for o in obs], dtype=np.int16).reshape(-1)       # inference.py:130-131
+                gxy[2 * i * n:2 * (i + 1) * n] = np.asarray([o["global_target_xy"] for o in obs], dtype=np.int16).reshape(-1)
+                acts[i * n:(i + 1) * n] = self._last_actions[positions[e]]
+                active[i] = 1
+        d = torch.from_numpy(buf).to(dev)
+        for grp, envs, base in plan:
+            kn, n, k = grp.k * grp.n, grp.n, grp.k
+            d_act = d[base:base + 4 * kn].view(torch.int32).view(k, n)
+            d_xy = d[base + 4 * kn:base + 8 * kn].view(torch.int16).view(k, n, 2)
+            d_gxy = d[base + 8 * kn:base + 12 * kn].view(torch.int16).view(k, n, 2)
+            everyone = len(envs) == k
+            if not grp.created:                                                              # inference.py:138 (all of a new group's
+                grp.tok.create_agents(d_xy, d_gxy)                                           #  slots are in the call that creates it)
+                grp.created = True
+            grp.tok.update_agents(d_xy, d_gxy, d_act, goals_may_change=True,                 # inference.py:142-144
+                                  active=None if everyone else d[base + 12 * kn:base + 12 * kn + k])
+            inst = [grp.index[positions[e]] for e in envs]
+            row0 = offsets[envs[0]]
+            if everyone and inst == list(range(k)) and all(offsets[e] == row0 + j * n for j, e in enumerate(envs)):
+                grp.tok.generate_observations(out[row0:row0 + kn])                           # inference.py:145, straight into place
+            else:
+                rows = grp.tok.generate_observations(grp.rows)
+                src = torch.as_tensor(np.concatenate([np.arange(i * n, (i + 1) * n) for i in inst]), device=dev)
+                dst = torch.as_tensor(np.concatenate([np.arange(offsets[e], offsets[e] + n) for e in envs]), device=dev)
+                out[dst] = rows[src]
+        return out
 
     def _forward_batch(self, inputs):
         """= inference.py:87-101: chunk at batch_size, sample with the adapter's generator."""
@@ -144,51 +213,20 @@ class MAPFGPTInference:
         return self.act_batch([observations])[0]                                             # inference.py:148-149
 
     def act_batch(self, observations_list, positions=None):
-        """= inference.py:151-172: rows of many envs -> one forward -> split back per env.
-        Host side of the reference-shaped call: the positions, goals and fed-back actions of ALL environments of the call
-        travel in ONE host-to-device copy, and every environment's tokenizer writes its rows straight into its slice of one
-        [total_rows, 256] tensor (no per-environment copies, no concatenation)."""
+        """= inference.py:151-172: rows of many envs -> one forward -> split back per env."""
         if positions is None:
             positions = list(range(len(observations_list)))
         counts = [len(o) for o in observations_list]
-        total = sum(counts)
-        tokens = torch.empty((total, 256), dtype=torch.uint8, device=self.cfg.device)
+        offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64).tolist() if counts else []
+        tokens = torch.empty((sum(counts), 256), dtype=torch.uint8, device=self.cfg.device)
         is_env = [len(o) > 0 and isinstance(o[0], dict) for o in observations_list]
-        n_dict = sum(c for c, e in zip(counts, is_env) if e)
-        if n_dict:
-            # staging buffer: [actions int32 | positions int16 x2 | goals int16 x2] of every dict-observation env, in call order
-            buf = np.empty(12 * n_dict, dtype=np.uint8)
-            acts, xy, gxy = buf[:4 * n_dict].view(np.int32), buf[4 * n_dict:8 * n_dict].view(np.int16), buf[8 * n_dict:].view(np.int16)
-            o = 0
-            for pos, observations, n, env in zip(positions, observations_list, counts, is_env):
-                if not env:
-                    continue
-                xy[2 * o:2 * (o + n)] = np.asarray([obs["global_xy"] for obs in observations], dtype=np.int16).reshape(-1)
-                gxy[2 * o:2 * (o + n)] = np.asarray([obs["global_target_xy"] for obs in observations], dtype=np.int16).reshape(-1)
-                acts[o:o + n] = self._last_actions[pos] if pos in self._obs_generators else -1      # inference.py:140
-                o += n
-            dev = torch.from_numpy(buf).to(self.cfg.device)
-            d_act = dev[:4 * n_dict].view(torch.int32)
-            d_xy = dev[4 * n_dict:8 * n_dict].view(torch.int16).view(n_dict, 2)
-            d_gxy = dev[8 * n_dict:].view(torch.int16).view(n_dict, 2)
-        row, o = 0, 0
-        for pos, observations, n, env in zip(positions, observations_list, counts, is_env):
-            out = tokens[row:row + n]
-            if env:
-                p, g, a = d_xy[o:o + n].view(1, n, 2), d_gxy[o:o + n].view(1, n, 2), d_act[o:o + n].view(1, n)
-                if pos not in self._obs_generators:                                               # inference.py:133-140
-                    grid = np.asarray(observations[0]["global_obstacles"]).copy().astype(int)
-                    gen = BatchedTokenizer(grid, 1, n, self.input_parameters, device=self.cfg.device)
-                    gen.create_agents(p, g)
-                    self._obs_generators[pos] = gen
-                    self._last_actions[pos] = [-1] * n
-                gen = self._obs_generators[pos]
-                gen.update_agents(p, g, a, goals_may_change=True)                                 # inference.py:142-144
-                gen.generate_observations(out)                                                    # inference.py:145
-                o += n
-            elif n:
-                out.copy_(self._prepare_inputs(pos, observations))                                # inference.py:146 (pre-tokenised)
-            row += n
+        env_ids = [e for e, f in enumerate(is_env) if f]
+        if env_ids:
+            self._tokenize([positions[e] for e in env_ids], [observations_list[e] for e in env_ids], out=tokens,
+                           offsets=[offsets[e] for e in env_ids])
+        for e, (pos, observations, n) in enumerate(zip(positions, observations_list, counts)):
+            if n and not is_env[e]:
+                tokens[offsets[e]:offsets[e] + n].copy_(self._prepare_inputs(pos, observations))   # inference.py:146 (pre-tokenised)
         all_actions = self._forward_batch(tokens)
         results, offset = [], 0
         for pos, count in zip(positions, counts):

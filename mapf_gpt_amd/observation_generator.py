@@ -81,14 +81,18 @@ class BatchedTokenizer:
         with _lib.on_device(self.device):
             _lib.check(_lib.lib().mgpt_tokenizer_create_agents(self._h, _lib.ptr(pos), _lib.ptr(goal), _lib.stream_ptr()))
 
-    def update_agents(self, pos, goal, actions, goals_may_change=True):
+    def update_agents(self, pos, goal, actions, goals_may_change=True, active=None):
+        """active: optional uint8 [n_inst] device tensor; instances with 0 keep their state (not presented in this call)."""
         shp = (self.n_inst, self.n_agents, 2)
         pos = self._chk(pos, torch.int16, shp)
         goal = self._chk(goal, torch.int16, shp)
         actions = self._chk(actions, torch.int32, (self.n_inst, self.n_agents))
+        if active is not None:
+            active = self._chk(active, torch.uint8, (self.n_inst,))
         with _lib.on_device(self.device):
-            _lib.check(_lib.lib().mgpt_tokenizer_update_agents(self._h, _lib.ptr(pos), _lib.ptr(goal), _lib.ptr(actions),
-                                                               1 if goals_may_change else 0, _lib.stream_ptr()))
+            _lib.check(_lib.lib().mgpt_tokenizer_update_agents_masked(self._h, _lib.ptr(pos), _lib.ptr(goal), _lib.ptr(actions),
+                                                                      _lib.ptr(active) if active is not None else None,
+                                                                      1 if goals_may_change else 0, _lib.stream_ptr()))
 
     def generate_observations(self, out=None):
         """-> uint8 [n_inst * n_agents, 256] on the device."""

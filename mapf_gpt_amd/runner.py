@@ -36,13 +36,16 @@ def gather_metrics(local, n_total, rank=0, world=1, group=None):
     if world == 1:
         return local
     import torch.distributed as dist
+    dev = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":      # CPU collectives (tests, dry runs): stage through the host
+        local = local.cpu()
     counts = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
     pad = max(counts)
     buf = torch.zeros((pad, local.shape[1]), dtype=local.dtype, device=local.device)
     buf[: local.shape[0]] = local
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf, group=group)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0).to(dev)
 
 
 def make_instances(grid, n_inst, n_agents, first_seed=0, start_ok=None, goal_ok=None):

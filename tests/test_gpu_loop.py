@@ -59,6 +59,50 @@ def test_adapter_act_batch_bookkeeping():
     assert algo._obs_generators == {} and algo._last_actions == {}
 
 
+def test_adapter_shared_context_subset_calls_vs_oracle():
+    """Slots of equal shape share one tokenizer context (one instance per slot, own map each); a call may present any subset
+    of them and in any order: absent slots keep their state (action history, goal field, window origin).  Five environments
+    (three on one map shape with 10 agents, one on the same shape with another map, one with 7 agents) driven through
+    _tokenize with changing subsets; every row is compared with that environment's own oracle generator (the reference keeps one
+    ObservationGenerator per slot, inference.py:133-145), fed the same positions and the same previous actions."""
+    from mapf_gpt_amd.env import GridEnv
+    from mapf_gpt_amd.inference import MAPFGPTInference, MAPFGPTInferenceConfig
+    algo = MAPFGPTInference(MAPFGPTInferenceConfig(path_to_weights="synthetic:tiny", batch_size=64))
+    specs = [("validation-random-seed-000", 10, 0), ("validation-random-seed-000", 10, 1), ("validation-random-seed-001", 10, 2),
+             ("validation-random-seed-000", 7, 3), ("validation-random-seed-000", 10, 4)]
+    envs = [GridEnv(map_name=m, num_agents=n, seed=sd, max_episode_steps=64) for m, n, sd in specs]
+    slots = [100, 7, 42, 5, 3]
+    obs = [e.reset()[0] for e in envs]
+    gens = [orc.OracleGenerator(e.grid) for e in envs]
+    last = [np.full(n, -1, np.int32) for _, n, _ in specs]
+    started = [False] * 5
+    rng = np.random.Generator(np.random.PCG64(9))
+    algo.reset_states()
+    subsets = [[0, 1, 2, 3], [1], [3, 0], [0, 1, 2, 3, 4], [4, 2], [2, 1, 0], [0, 1, 2, 4, 3], [3]]
+    for t, sub in enumerate(subsets):
+        rows = algo._tokenize([slots[e] for e in sub], [obs[e] for e in sub]).cpu().numpy()
+        off = 0
+        for e in sub:
+            n = specs[e][1]
+            p = np.array([o["global_xy"] for o in obs[e]], np.int32)
+            g = np.array([o["global_target_xy"] for o in obs[e]], np.int32)
+            if not started[e]:
+                gens[e].create_agents(p, g)
+                started[e] = True
+            gens[e].update_agents(p, g, last[e])
+            assert np.array_equal(rows[off:off + n], gens[e].generate_observations()), f"call {t} env {e}"
+            off += n
+            act = rng.integers(0, 5, n).astype(np.int32)         # what act_batch would have stored (inference.py:168)
+            algo._last_actions[slots[e]] = act.tolist()
+            last[e] = act
+            obs[e] = envs[e].step(act.tolist())[0]
+    # contexts: slots 0 and 1 (same frame, 10 agents, first call) share one; slot 2 (another map frame), slot 3 (7 agents) and
+    # slot 4 (first seen in a later call) have their own
+    g = [algo._obs_generators[slots[e]] for e in range(5)]
+    assert g[0] is g[1] and g[0].k == 2 and (envs[2].grid.shape != envs[0].grid.shape) == (g[2] is not g[0])
+    assert g[3].n == 7 and g[3] is not g[0] and g[4].k == 1 and g[4] is not g[0]
+
+
 def test_adapter_accepts_pretokenised_rows_and_chunks():
     from mapf_gpt_amd.inference import MAPFGPTInference, MAPFGPTInferenceConfig
     from tests.helpers import load_tok
