@@ -13,27 +13,10 @@
 namespace mgpt {
 namespace fastk {
 
-// split of 4 values into hi/lo fp16 words with the packed conversions (10 instead of 13 VALU per 4 values; same
-// results as split4: hi = RNE fp16(v), lo = RNE fp16(v - hi) with v - hi exact in fp32)
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-template <class T, int NP>
-__device__ __forceinline__ void split4p(const float v[4], u32x2 &hi, u32x2 &lo)
-{
-    if constexpr (NP == 2 && std::is_same<T, F16T>::value) {
-        float x[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) { x[i] = v[i]; asm("" : "+v"(x[i])); }     // one rounded fp32 value first (see split4)
-        const f16x2 a = __builtin_convertvector((f32x2){x[0], x[1]}, f16x2), b = __builtin_convertvector((f32x2){x[2], x[3]}, f16x2);
-        const float r0 = x[0] - (float)a[0], r1 = x[1] - (float)a[1], r2 = x[2] - (float)b[0], r3 = x[3] - (float)b[1];
-        const f16x2 c = __builtin_convertvector((f32x2){r0, r1}, f16x2), d = __builtin_convertvector((f32x2){r2, r3}, f16x2);
-        hi[0] = __builtin_bit_cast(unsigned, a); hi[1] = __builtin_bit_cast(unsigned, b);
-        lo[0] = __builtin_bit_cast(unsigned, c); lo[1] = __builtin_bit_cast(unsigned, d);
-    } else {
-        split4<T, NP>(v, hi, lo);
-    }
-}
-
-// the same for one pair of values -> one hi word and one lo word
+// the same for one pair of values -> one hi word and one lo word.  Split-fp16 path: 3 VALU for the pair -- one packed conversion
+// for hi, then lo = RNE fp16(v - hi) by v_fma_mixlo / mixhi_f16 (fma(hi as fp16, -1.0, v) rounded once to fp16: v - hi is exact in
+// fp32, so this is the same value the conversion chain cvt_f32_f16 / sub / cvt_pk gave, in half the instructions)
 template <class T, int NP>
 __device__ __forceinline__ void split2p(float v0, float v1, unsigned &hi, unsigned &lo)
 {
@@ -41,10 +24,11 @@ __device__ __forceinline__ void split2p(float v0, float v1, unsigned &hi, unsign
     asm("" : "+v"(v1));
     if constexpr (NP == 2 && std::is_same<T, F16T>::value) {
         const f16x2 a = __builtin_convertvector((f32x2){v0, v1}, f16x2);
-        const float r0 = v0 - (float)a[0], r1 = v1 - (float)a[1];
-        const f16x2 c = __builtin_convertvector((f32x2){r0, r1}, f16x2);
         hi = __builtin_bit_cast(unsigned, a);
-        lo = __builtin_bit_cast(unsigned, c);
+        unsigned l;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(v0));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(v1));
+        lo = l;
     } else if constexpr (NP == 1 && std::is_same<T, BF16T>::value) {
         hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2));
         lo = 0u;
@@ -53,6 +37,20 @@ __device__ __forceinline__ void split2p(float v0, float v1, unsigned &hi, unsign
         const uint16_t b0 = (NP == 2) ? T::cvt(v0 - T::back(a0)) : (uint16_t)0, b1 = (NP == 2) ? T::cvt(v1 - T::back(a1)) : (uint16_t)0;
         hi = (unsigned)a0 | ((unsigned)a1 << 16);
         lo = (unsigned)b0 | ((unsigned)b1 << 16);
+    }
+}
+
+// split of 4 values into hi / lo fp16 words (same results as split4: hi = RNE fp16(v), lo = RNE fp16(v - hi))
+template <class T, int NP>
+__device__ __forceinline__ void split4p(const float v[4], u32x2 &hi, u32x2 &lo)
+{
+    if constexpr (NP == 2 && std::is_same<T, F16T>::value) {
+        unsigned h0, l0, h1, l1;
+        split2p<T, NP>(v[0], v[1], h0, l0);
+        split2p<T, NP>(v[2], v[3], h1, l1);
+        hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+    } else {
+        split4<T, NP>(v, hi, lo);
     }
 }
 

@@ -68,6 +68,24 @@ __device__ __forceinline__ void split4(const float v[4], u32x2 &hi, u32x2 &lo)
         lo[0] = 0u; lo[1] = 0u;
         return;
     }
+    if constexpr (NP == 2 && std::is_same<T, F16T>::value) {
+        // split-fp16: 6 VALU for the four values -- two packed conversions for hi, then lo = RNE fp16(v - hi) by
+        // v_fma_mixlo / mixhi_f16 (fma(hi as fp16, -1.0, v) rounded once to fp16; v - hi is exact in fp32, so this is the value
+        // the chain below gives, in half the instructions).  The fence keeps each value ONE rounded fp32 first (see below).
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { x[i] = v[i]; asm("" : "+v"(x[i])); }
+        hi[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x[0], x[1]}, h2));
+        hi[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x[2], x[3]}, h2));
+        unsigned l0, l1;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi[0]), "v"(x[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(hi[0]), "v"(x[1]));
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi[1]), "v"(x[2]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(hi[1]), "v"(x[3]));
+        lo[0] = l0; lo[1] = l1;
+        return;
+    }
     uint16_t a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
