@@ -237,7 +237,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                 if ((rc = pack(m->proj2_pk2, lo.proj2_w, C, 4 * C, 1.0f / m->proj2[l].inv_scale, l)) != MGPT_OK) return rc;
             }
         }
-        const int lds = (NP == 2 ? 4 : 6) * 16 * NP * 1024;
+        const int lds = fastk::gemm_pk_lds(NP);
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -314,14 +314,14 @@ int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
 template <class T, int NP, int EPI>
 int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
 {
-    constexpr int NST = (NP == 2) ? 4 : 6;
-    MGPT_REQUIRE(a.M % 256 == 0 && a.N % 256 == 0 && a.K % 32 == 0 && a.K >= 16 * NST, MGPT_ERR_UNSUPPORTED,
+    constexpr int NST = fastk::gemm_pk_nst(NP), KPS = fastk::gemm_pk_kps(NP);
+    MGPT_REQUIRE(a.M % 256 == 0 && a.N % 256 == 0 && a.K % 32 == 0 && a.K >= 16 * KPS * NST, MGPT_ERR_UNSUPPORTED,
                  "gemm_pk shape M=%d N=%d K=%d", a.M, a.N, a.K);
     a.n_tiles_n = a.N / 256;
     if (EPI == fastk::EPI_RESID) a.stats_out = nullptr;               // rows span two waves: stats come from row_stats_kernel
     const bool lut = EPI == fastk::EPI_GELU && a.gelu_lut != nullptr;
     hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
-                       (size_t)NST * 16 * NP * 1024 + (lut ? fastk::kGeluLutN * 8 : 0), s, a);
+                       (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0), s, a, (unsigned long long *)nullptr);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }

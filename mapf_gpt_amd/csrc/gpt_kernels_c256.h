@@ -445,6 +445,10 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(float *__restrict__ x, c
 // output row goes to row b of the compact matrix y (packed-fragment layout over rows instead of tokens).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kA256StepsPerHead = 6;
+// The two waves of a SIMD (w and w + 4) leave the head's k / v barrier together and would run the attention phase in phase --
+// both in the S / PV MFMAs, then both in the softmax arithmetic, each at half speed.  Waves 4-7 start it STG x 64 cycles late
+// (s_sleep), half a key tile, so that one wave's softmax runs under the other's MFMAs (tools/bench_probes/probe_attn256.hip).
+constexpr int kA256Stagger = 0;
 
 template <class T, int NP>
 __global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restrict__ w, uint16_t *__restrict__ out, float scale)
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restri
 // 4 no attention phase, 8 no projection MFMAs, 16 no ring barriers -- results are wrong unless ABL == 0.  32: wave 0 of every
 // block leaves stamps[block][8] = {entry cycles, entry 100-MHz ticks, cycles after LayerNorm, exit cycles, exit ticks,
 // cycles in the q|k|v projection steps, cycles waiting at the head's k / v barrier, cycles in the attention phase}.
-template <class T, int NP, bool LAST, int ABL = 0>
+template <class T, int NP, bool LAST, int ABL = 0, int STG = kA256Stagger>
 __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict__ x, const float *__restrict__ gain,
                                                          const uint16_t *__restrict__ wstream, float inv_scale, float scale_log2e,
                                                          uint16_t *__restrict__ y, unsigned long long *stamps = nullptr)
@@ -739,6 +743,7 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
         for (int g = 0; g < 16; g++) o[g] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
         if (full && !(ABL & 4)) {
+            if constexpr (!LAST && STG > 0) { if (wave >= NW / 2) __builtin_amdgcn_s_sleep(STG); }
             u32x4 kf[2][2], vf[2][2];
             auto load_k = [&](int kt) {                    // K fragments of key tile kt: [k-step][plane]
                 const unsigned a = kr_addr + (unsigned)kt * (32 * KROW);

@@ -705,18 +705,30 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
     }
 }
 
-// NWV = 4: one wave per SIMD, 128 x 128 per wave (512 registers).  NWV = 8: two waves per SIMD, 64 x 128 per wave (256
-// registers): 1.5x the LDS reads per MFMA, but the second wave on the SIMD covers the issue time of the ds_reads, the
-// refill loads and the epilogue's VALU work, all of which otherwise ADD to the MFMA time (tools/bench_probes/probe_mfma_lds*.hip:
-// 460 -> 373 ns per block k-step in bf16, against 311 ns for the MFMAs alone).
-template <class T, int NP, int EPI, int NWV>
-__global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
+// 8 waves of 64 x 128 (2 x 4 MFMA tiles, 256 registers, two waves per SIMD: the second wave on the SIMD covers part of the
+// issue time of the ds_reads, the refill loads and the epilogue's VALU work -- tools/bench_probes/probe_mfma_lds*.hip).
+// One ring stage = KPS k-steps of the 256 x 256 block tile (16 * KPS * NP fragments of 1 KiB, fetched by direct
+// global->LDS loads NST - 1 stages ahead), one s_barrier per stage.  KPS = 2 in the one-plane (bf16) mode (16 MFMAs per
+// wave between barriers) was measured and changes nothing (860 vs 888 cycles per k-step, tools/bench_probes/probe_gemm_pk.hip);
+// the library runs KPS = 1.
+// DBG (probe only): 1 = wave 0 leaves stamps[block][6] = {entry cycles, entry 100-MHz ticks, cycles at the first stage, at the
+// end of the main loop, at exit, exit ticks}.
+constexpr int gemm_pk_kps(int NP) { return 1; }
+constexpr int gemm_pk_nst(int NP) { return NP == 2 ? 4 : 6; }
+constexpr int gemm_pk_lds(int NP) { return gemm_pk_nst(NP) * 16 * gemm_pk_kps(NP) * NP * 1024; }   // + the Phi table when used
+
+template <class T, int NP, int EPI, int NWV, int DBG = 0>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p, unsigned long long *stamps = nullptr)
 {
-    constexpr int TM = (NWV == 4) ? 4 : 2, TN = 4;         // MFMA tiles per wave; waves are (NWV / 2) x 2
+    static_assert(NWV == 8, "8 waves of 64 x 128");
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (DBG != 0) { ts[0] = __builtin_readcyclecounter(); ts[1] = wall_clock64(); }
+    constexpr int TM = 2, TN = 4;                          // MFMA tiles per wave; waves are 4 x 2
     constexpr bool SWAP = (EPI != EPI_VT);
-    constexpr int NST = (NP == 2) ? 4 : 6;                 // ring depth, in k-steps
-    constexpr int STAGE = 16 * NP * 1024;                  // 8 A fragments + 8 B fragments, NP planes each
-    constexpr int PER_WAVE = 16 * NP / NWV;                // direct-to-LDS loads a wave issues per stage
+    constexpr int KPS = gemm_pk_kps(NP);                   // k-steps per ring stage
+    constexpr int NST = gemm_pk_nst(NP);                   // ring depth, in stages
+    constexpr int STAGE = 16 * KPS * NP * 1024;            // 8 A fragments + 8 B fragments, KPS k-steps, NP planes each
+    constexpr int PER_WAVE = 16 * KPS * NP / NWV;          // direct-to-LDS loads a wave issues per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NST][STAGE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -734,18 +746,19 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
     const int gm = min(GM, mtn - band * GM);
     const int rem = id - band * GM * ntn;
     const int nt = rem / gm, mt = band * GM + (rem - nt * gm);
-    const int KS = p.K >> 4;
+    const int KS = p.K >> 4, NSTG = KS / KPS;
     const unsigned char *abase = reinterpret_cast<const unsigned char *>(p.a_hi) + (size_t)mt * 8 * KS * NP * 1024 + lane * 16;
     const unsigned char *bbase = reinterpret_cast<const unsigned char *>(p.w_hi) + (size_t)nt * 8 * KS * NP * 1024 + lane * 16;
 
-    auto issue = [&](int s_) {
-        unsigned char *dst = smem + (size_t)(s_ % NST) * STAGE;
+    // stage S -> LDS [fragment f][k-step kk of the stage][plane]: the KPS * NP pieces of a fragment are contiguous on both sides
+    auto issue = [&](int S) {
+        unsigned char *dst = smem + (size_t)(S % NST) * STAGE;
 #pragma unroll
         for (int i = 0; i < PER_WAVE; i++) {
-            const int c = wave + NWV * i;                  // piece = (fragment f, plane pl), c = f * NP + pl
-            const int f = c / NP, pl = c - f * NP;
-            const unsigned char *src = (f < 8) ? abase + ((size_t)(f * KS + s_) * NP + pl) * 1024
-                                               : bbase + ((size_t)((f - 8) * KS + s_) * NP + pl) * 1024;
+            const int c = wave + NWV * i;                  // piece c = (f * KPS + kk) * NP + pl
+            const int f = c / (KPS * NP), q = c - f * (KPS * NP);
+            const unsigned char *src = (f < 8) ? abase + ((size_t)(f * KS + S * KPS) * NP + q) * 1024
+                                               : bbase + ((size_t)((f - 8) * KS + S * KPS) * NP + q) * 1024;
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
         }
     };
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
         lut_addr = (unsigned)(size_t)dst;
     }
 #pragma unroll
-    for (int s_ = 0; s_ < NST - 1; s_++) issue(s_);        // K >= 16 * NST is checked by the launcher
+    for (int S = 0; S < NST - 1; S++) issue(S);            // K >= 16 * KPS * NST is checked by the launcher
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -771,14 +784,14 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
 
     u32x4 fa[2][TM][NP], fb[2][TN][NP];                    // [buffer][tile][plane]
-    auto fetch = [&](int s_, int buf) {
-        const unsigned char *st = smem + (size_t)(s_ % NST) * STAGE + lane * 16;
+    auto fetch = [&](int S, int kk, int buf) {             // fragments of k-step kk of stage S
+        const unsigned char *st = smem + (size_t)(S % NST) * STAGE + (size_t)kk * NP * 1024 + lane * 16;
 #pragma unroll
         for (int pl = 0; pl < NP; pl++) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) fa[buf][i][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((wm * TM + i) * NP + pl) * 1024);
+            for (int i = 0; i < TM; i++) fa[buf][i][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((wm * TM + i) * KPS * NP + pl) * 1024);
 #pragma unroll
-            for (int j = 0; j < TN; j++) fb[buf][j][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((8 + wn * TN + j) * NP + pl) * 1024);
+            for (int j = 0; j < TN; j++) fb[buf][j][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((8 + wn * TN + j) * KPS * NP + pl) * 1024);
         }
     };
     auto round = [&](int buf, int pa, int pb) {            // one MFMA on each of the TM x TN accumulators
@@ -789,17 +802,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
                 acc[i][j] = SWAP ? T::mfma(fb[buf][j][pb], fa[buf][i][pa], acc[i][j]) : T::mfma(fa[buf][i][pa], fb[buf][j][pb], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto step = [&](int s_, int buf) {
-        if (s_ + 1 < KS) {
-            // stage s+1 landed for everyone; everyone is done reading the slot that gets refilled below
-            if (s_ + NST - 2 < KS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * PER_WAVE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (s_ + NST - 1 < KS) issue(s_ + NST - 1);
-            fetch(s_ + 1, buf ^ 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    auto mfmas = [&](int buf) {
         if (NP == 2) {
             // weight operand = B side when SWAP (fb), its lo plane first: lo.hi, hi.lo, hi.hi
             round(buf, SWAP ? 0 : 1, SWAP ? 1 : 0);
@@ -807,16 +810,49 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p)
         }
         round(buf, 0, 0);
     };
+    // global k-step t = S * KPS + kk uses fragment buffer t & 1; its fragments were requested one k-step earlier
+    auto stage = [&](int S, int buf0) {
+        if (S + 1 < NSTG) {
+            // stage S+1 landed for everyone; everyone is done reading the slot that gets refilled below
+            if (S + NST - 2 < NSTG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (S + NST - 1 < NSTG) issue(S + NST - 1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KPS; kk++) {
+            const int buf = (buf0 + kk) & 1;
+            if (kk + 1 < KPS) fetch(S, kk + 1, buf ^ 1);
+            else if (S + 1 < NSTG) fetch(S + 1, 0, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(buf);
+        }
+    };
 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER_WAVE) : "memory");
     __builtin_amdgcn_s_barrier();
-    fetch(0, 0);
+    if constexpr (DBG != 0) ts[2] = __builtin_readcyclecounter();
+    fetch(0, 0, 0);
+    if (KPS == 2) {
 #pragma unroll 1
-    for (int s_ = 0; s_ < KS; s_ += 2) {
-        step(s_, 0);
-        step(s_ + 1, 1);
+        for (int S = 0; S < NSTG; S++) stage(S, 0);
+    } else {
+#pragma unroll 1
+        for (int S = 0; S < NSTG; S += 2) {
+            stage(S, 0);
+            stage(S + 1, 1);
+        }
     }
+    if constexpr (DBG != 0) { asm volatile("s_nop 0" ::: "memory"); ts[3] = __builtin_readcyclecounter(); }
     gemm16_epilogue<T, NP, EPI, TM, TN, 2>(p, acc, (int64_t)mt * 256, nt * 256, wm, wn, r, h, lut_addr);
+    if constexpr (DBG != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[4] = __builtin_readcyclecounter(); ts[5] = wall_clock64();
+        if (tid == 0)
+#pragma unroll
+            for (int i = 0; i < 6; i++) stamps[(size_t)blockIdx.x * 6 + i] = ts[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

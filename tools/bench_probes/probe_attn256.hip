@@ -5,6 +5,7 @@
 #include <math.h>
 #include <algorithm>
 #include <vector>
+#include <cstring>
 #include "../../mapf_gpt_amd/csrc/gpt_kernels_c256.h"
 namespace mgpt { void set_error(const char *, ...) {} }
 using namespace mgpt::fastk;
@@ -52,6 +53,32 @@ void run_real(const float *x, const float *gain, uint16_t *ws, uint16_t *y, int 
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("real operands: attn256_kernel %.3f ms per launch (100 launches)\n", ms / 100);
+    }
+    // stagger of the second wave of every SIMD at the start of the attention phase (x 64 cycles); y must not change
+    {
+        const size_t ny = (size_t)rows * 256 * 256 * 2;
+        std::vector<uint16_t> y0(ny), y1(ny);
+        attn256_kernel<F16T, 2, false, 0, 0><<<rows, 512, lds>>>(x, gain, ws, isc, sl2, y);
+        hipMemcpy(y0.data(), y, ny * 2, hipMemcpyDeviceToHost);
+        auto one = [&](auto stg_c) {
+            constexpr int STG = decltype(stg_c)::value;
+            auto kern = &attn256_kernel<F16T, 2, false, 0, STG>;
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipMemset(y, 0, ny * 2);
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; rep++) {
+                hipEventRecord(e0);
+                for (int i = 0; i < 60; i++) kern<<<rows, 512, lds>>>(x, gain, ws, isc, sl2, y, nullptr);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                best = std::min(best, ms / 60);
+            }
+            hipMemcpy(y1.data(), y, ny * 2, hipMemcpyDeviceToHost);
+            printf("stagger %2d x 64 cycles: %.3f ms per launch (best of 3 x 60), y %s\n", STG, best, memcmp(y0.data(), y1.data(), ny * 2) ? "DIFFERS" : "identical");
+        };
+        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 5>{}); one(std::integral_constant<int, 6>{});
+        one(std::integral_constant<int, 7>{}); one(std::integral_constant<int, 8>{}); one(std::integral_constant<int, 10>{}); one(std::integral_constant<int, 13>{});
+        one(std::integral_constant<int, 0>{});
     }
     unsigned long long *stp; hipMalloc(&stp, (size_t)rows * 64);
     attn256_kernel<F16T, 2, false, 32><<<rows, 512, lds>>>(x, gain, ws, isc, sl2, y, stp);
