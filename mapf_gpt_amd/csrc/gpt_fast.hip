@@ -55,6 +55,8 @@ struct ModeState {          // one precision mode
     std::vector<uint16_t *> proj_pk;
     // last-layer shortcut: new residual rows of token 255 only, [round_up(max_rows, 256)][C] fp32
     float *x_last = nullptr;
+    float *x_head = nullptr;                   // x_tiled: the last-token rows in plain row-major order for the head kernel
+    bool x_tiled = false;                      // residual stream chunk-major (fastk::xt_off): the C = 256 kernels
     uint16_t *y_last = nullptr;                // packed-GEMM path: attention output of token 255 of every row, PK planes [rows_pad][C]
     // PK GEMM path (C % 256 == 0: 6M, 85M): weights as MFMA-fragment streams, activations produced in the same layout
     bool pk_gemm = false;
@@ -120,7 +122,9 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             if ((rc = pack_matrix<T, NP>(g->params + mt.off, mt.n, sc, mt.dst, nullptr)) != MGPT_OK) return rc;
         }
     }
-    m->mlp_fused = (C == 160 || C == 64 || C == 256);
+    // (C = 256: the fused kernels are the 6M shape's -- 8 heads of 32 -- and share the chunk-major residual stream; any other
+    //  C = 256 model takes the packed-fragment GEMM chain)
+    m->mlp_fused = (C == 160 || C == 64 || (C == 256 && g->hs == 32 && g->nh == 8));
     {   // Phi(v) = (1 + erf(v / sqrt 2)) / 2 on [-6, 6) in steps of 1/256, as (value, forward difference) pairs
         std::vector<float2> lut(fastk::kGeluLutN);
         auto phi = [](double v) { return 0.5 * (1.0 + erf(v * 0.70710678118654752440)); };
@@ -249,6 +253,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         const size_t nl = (size_t)((g->max_rows + 255) / 256) * 256 * C;
         MGPT_HIP(hipMalloc(&m->x_last, nl * sizeof(float)));
         MGPT_HIP(hipMemset(m->x_last, 0, nl * sizeof(float)));           // padding rows stay finite
+        m->x_tiled = m->attn256 && m->mlp_fused && m->pk_gemm && C == 256;
+        if (m->x_tiled) MGPT_HIP(hipMalloc(&m->x_head, nl * sizeof(float)));
         if (m->pk_gemm) {
             MGPT_HIP(hipMalloc(&m->y_last, nl * NP * sizeof(uint16_t)));
             MGPT_HIP(hipMemset(m->y_last, 0, nl * NP * sizeof(uint16_t)));
@@ -283,6 +289,7 @@ void free_mode(ModeState *m)
     (void)hipFree(m->apk);
     (void)hipFree(m->stats);
     (void)hipFree(m->x_last);
+    (void)hipFree(m->x_head);
     (void)hipFree(m->y_last);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
@@ -365,7 +372,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     const bool attn_block = m->qkv_fused && g->hs == 32 && m->mlp_fused;
     // the first attention block forms x = wte[token] + wpe[position] itself (no embedding kernel, no first read of x)
     const bool embed_fused = attn_block && g->L > 1;
-    if (!embed_fused) {
+    if (m->x_tiled) {
+        ProfScope ps(P_EMBED, s);
+        hipLaunchKernelGGL(fastk::embed_tiled_kernel, dim3((unsigned)(M / 32)), dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, C);
+        MGPT_LAUNCH_CHECK();
+    } else if (!embed_fused) {
         ProfScope ps(P_EMBED, s);
         const dim3 grid((unsigned)cdiv64(M, 4));
         if (C <= 256) hipLaunchKernelGGL((fastk::embed_stats_kernel<1>), grid, dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, m->stats, M, C);
@@ -441,13 +452,13 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if (ls) {
                 ProfScope ps(P_EMBED, s);
                 hipLaunchKernelGGL(fastk::gather_last_kernel, dim3((unsigned)cdiv64((int64_t)rows_pad * (C / 4), 256)), dim3(256), 0, s, g->x, m->x_last, rows,
-                                   rows_pad, C);
+                                   rows_pad, C, m->x_tiled ? 1 : 0);
                 MGPT_LAUNCH_CHECK();
             }
             // ---- attention output projection + residual (+ stats of the new rows) ----
             a.a_hi = ls ? m->y_last : m->y[0]; a.a_lo = m->y[1]; a.K = C; a.N = C;
             a.w_hi = m->proj[l].hi; a.w_lo = m->proj[l].lo; a.out_scale = m->proj[l].inv_scale;
-            a.x_out = ls ? m->x_last : g->x; a.stats_out = m->stats;
+            a.x_out = ls ? m->x_last : g->x; a.stats_out = m->stats; a.x_tiled = m->x_tiled ? 1 : 0;
             if (ls) a.M = rows_pad;
             ProfScope ps(P_GEMM_PROJ, s);
             if (m->pk_gemm) {
@@ -520,6 +531,14 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
         if (!fused_stats(C) && l + 1 < g->L && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
+    }
+    if (m->x_tiled) {
+        {
+            ProfScope ps(P_HEAD, s);
+            hipLaunchKernelGGL(fastk::untile_rows_kernel, dim3((unsigned)cdiv64((int64_t)rows * (C / 4), 256)), dim3(256), 0, s, m->x_last, m->x_head, rows, C);
+            MGPT_LAUNCH_CHECK();
+        }
+        return gpt_launch_head_at(g, m->x_head, (int64_t)C, 0, rows, d_logits, s);
     }
     if (attn_block || m->pk_gemm) return gpt_launch_head_at(g, m->x_last, (int64_t)C, 0, rows, d_logits, s);
     return gpt_launch_head(g, rows, d_logits, s);

@@ -533,14 +533,15 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
     // ---- LayerNorm of this lane's token; operand planes in registers ----
     u32x4 xn[KS][2];
     {
-        const float *xrow = x + (b * kT + tok0 + r) * C;
+        // x is chunk-major (xt_off in gpt_kernels_fast.h): every load of the wave is 1 KiB contiguous
+        const float *xt = x + (b * kT + tok0) * C + r * 8 + 4 * h;
         f32x16 xv[CT];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < CT; j++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xt + (4 * j + gq) * 256);
                 xv[j][4 * gq] = v[0]; xv[j][4 * gq + 1] = v[1]; xv[j][4 * gq + 2] = v[2]; xv[j][4 * gq + 3] = v[3];
                 s += (v[0] + v[1]) + (v[2] + v[3]);
             }

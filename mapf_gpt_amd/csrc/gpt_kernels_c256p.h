@@ -317,14 +317,18 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
         for (int k = 0; k < n_mine; k++) {
             // (k == 0: hB is zero, its GELU writes zero hidden planes -- what the consumer's first steps expect)
             const int64_t blk = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
-            const float *xrow = x + (blk * 128 + pair * 32 + r) * C + 4 * h;   // this lane's token, its half of every octet
-            f32x4 xr[32];                                  // raw row pieces: xr[4 j + gq] = features 32 j + 8 gq + 4 h .. + 3
+            // x is chunk-major (xt_off): [32-token tile][C / 8 chunks][32 tokens][8 floats]; lane (r, h) owns the 16 bytes at
+            // r * 32 + h * 16 of every 1-KiB chunk, so that a wave's load or store is 1 KiB contiguous
+            const float *xrow = x + (blk * 128 + pair * 32) * C + r * 8 + 4 * h;
+            f32x4 xr[32];                                  // raw row pieces: xr[4 j + gq] = features 32 j + 8 gq + 4 h .. + 3 (chunk 4 j + gq)
             // ---- step 0: GELU(tile 31), first k-step; row loads ----
             sync(E0{});
             gelu_only(I0{}, hB, 1);
 #pragma unroll
-            for (int i = 0; i < 32; i++)
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xr[i]) : "v"(xrow), "n"((32 * (i >> 2) + 8 * (i & 3)) * 4) : "memory");
+            for (int i = 0; i < 32; i++) {
+                const float *xq = xrow + (i >> 2) * 1024;  // (13-bit immediate offsets: four chunks per address)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xr[i]) : "v"(xq), "n"((i & 3) * 1024) : "memory");
+            }
             // ---- step 1: GELU(tile 31), second k-step; rows landed; LayerNorm statistics (two-pass, model.py:19-20) ----
             sync(std::integral_constant<int, 32>{});
             gelu_only(I1{}, hB, 1);
@@ -446,19 +450,19 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
         // steps 0 .. 7 of a period for the consumer: the block blk_prev is finished (c_proj of its tiles 30, 31, then the
         // residual add + store, acc = 0)
         auto finish_block = [&](int64_t blk_prev) {
-            float *xrow = x + (blk_prev * 128 + pair * 32 + r) * C + 4 * h;
+            float *xrow = x + (blk_prev * 128 + pair * 32) * C + r * 8 + 4 * h;    // chunk-major, as in the producer
             auto ld = [&](auto j_c) {                      // residual pieces of output tile j -> xs[j % 4]
                 constexpr int j = decltype(j_c)::value;
                 f32x4 (&xj)[4] = xs[j % 4];
-                float *xp = xrow;
+                float *xp = xrow + j * 1024;
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++)
-                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xj[gq]) : "v"(xp), "n"((32 * j + 8 * gq) * 4) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xj[gq]) : "v"(xp), "n"(gq * 1024) : "memory");
             };
             auto st = [&](auto j_c, auto younger_c) {      // x = x + acc[j] * inv2 for output tile j; YOUNGER = operations issued after its loads
                 constexpr int j = decltype(j_c)::value;
                 f32x4 (&xj)[4] = xs[j % 4];
-                float *xp = xrow;
+                float *xp = xrow + j * 1024;
                 asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(xj[0]), "+v"(xj[1]), "+v"(xj[2]), "+v"(xj[3]) : [n] "n"(decltype(younger_c)::value) : "memory");
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
                     for (int e = 0; e < 4; e++) o[e] = fmaf(acc[j][4 * gq + e], inv2, xj[gq][e]);
                     // (s_nop: a store of more than 8 bytes reads its data registers after issue; hipcc pads a VALU write of them for
                     //  its own stores, but it cannot see through inline asm -- without this the next piece's FMAs clobbered the data)
-                    asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" ::"v"(xp), "v"(o), "n"((32 * j + 8 * gq) * 4) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" ::"v"(xp), "v"(o), "n"(gq * 1024) : "memory");
                 }
 #pragma unroll
                 for (int g = 0; g < 16; g++) acc[j][g] = 0.f;

@@ -207,16 +207,43 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
 
 // last-layer shortcut of the packed-GEMM path: compact residual rows x_last[b] = x[b, 255, :] for b < rows, zeros for the
 // padding rows up to rows_pad (they go through the compact GEMMs and the MLP and must stay finite whatever ran before)
+// (tiled: both x and x_last are chunk-major, xt_off below)
+__device__ __forceinline__ int64_t xt_off(int64_t m, int n, int C);
 __global__ __launch_bounds__(256) void gather_last_kernel(const float *__restrict__ x, float *__restrict__ x_last, int rows,
-                                                          int rows_pad, int C)
+                                                          int rows_pad, int C, int tiled)
 {
     const int c4n = C >> 2;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)rows_pad * c4n) return;
     const int b = (int)(i / c4n), c4 = (int)(i - (int64_t)b * c4n);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (b < rows) v = reinterpret_cast<const f32x4 *>(x + ((int64_t)b * kT + kT - 1) * C)[c4];
-    reinterpret_cast<f32x4 *>(x_last + (int64_t)b * C)[c4] = v;
+    const int64_t m = (int64_t)b * kT + kT - 1;
+    if (b < rows) v = *reinterpret_cast<const f32x4 *>(x + (tiled ? xt_off(m, 4 * c4, C) : m * C + 4 * c4));
+    *reinterpret_cast<f32x4 *>(x_last + (tiled ? xt_off(b, 4 * c4, C) : (int64_t)b * C + 4 * c4)) = v;
+}
+
+// chunk-major rows -> plain rows (the compact last-token matrix in front of the head kernel)
+__global__ __launch_bounds__(256) void untile_rows_kernel(const float *__restrict__ xt, float *__restrict__ out, int rows, int C)
+{
+    const int c4n = C >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows * c4n) return;
+    const int b = (int)(i / c4n), c4 = (int)(i - (int64_t)b * c4n);
+    *reinterpret_cast<f32x4 *>(out + (int64_t)b * C + 4 * c4) = *reinterpret_cast<const f32x4 *>(xt + xt_off(b, 4 * c4, C));
+}
+
+// x = wte[token] + wpe[position] (model.py:171-175) written chunk-major: one workgroup per 32-token tile, a wave writes
+// whole 1-KiB chunks (lane (r, h): token r, columns 8 c + 4 h .. + 3); the embedding rows come from L2
+__global__ __launch_bounds__(256) void embed_tiled_kernel(const uint8_t *__restrict__ tokens, const float *__restrict__ wte,
+                                                          const float *__restrict__ wpe, float *__restrict__ x, int C)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int64_t tok = (int64_t)blockIdx.x * 32 + r;
+    const int t = (int)(tok & (kT - 1)), id = tokens[tok];
+    const float *pa = wte + (size_t)id * C + 4 * h, *pb = wpe + (size_t)t * C + 4 * h;
+    float *px = x + (int64_t)blockIdx.x * 32 * C + r * 8 + 4 * h;
+    for (int c = wave; c < (C >> 3); c += 4)
+        *reinterpret_cast<f32x4 *>(px + c * 256) = *reinterpret_cast<const f32x4 *>(pa + 8 * c) + *reinterpret_cast<const f32x4 *>(pb + 8 * c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -254,7 +281,14 @@ struct GemmArgs {
     int o_pk;                                                        // EPI_GELU: write the hidden planes in PK layout (o_hi = base)
     int chunk_major;                                                 // EPI_QK / EPI_VT: chunk-major q|k and v^T planes (below)
     const float2 *gelu_lut;                                          // EPI_GELU in gemm_pk_kernel: the Phi table (kGeluLutN pairs) or NULL
+    int stagger;                                                     // gemm_pk_kernel: start-up spread of the CUs, x 64 cycles (see there)
+    int x_tiled;                                                     // EPI_RESID: x_out is chunk-major (xt_off) instead of row-major
 };
+
+// Chunk-major residual stream: x[M][C] stored as [M / 32][C / 8][32 tokens][8 floats].  A wave whose lane (r, h) owns token r
+// and the 4 floats at columns 8c + 4h reads or writes 64 x 16 B = 1 KiB CONTIGUOUS per instruction (8 full cache lines)
+// instead of 32 row pieces of 32 B in 32 different lines -- the access shape of every kernel that keeps "lane = token".
+__device__ __forceinline__ int64_t xt_off(int64_t m, int n, int C) { return (((m >> 5) * (C >> 3) + (n >> 3)) << 8) + ((m & 31) << 3) + (n & 7); }
 
 // erf(x) ~= x P(x^2) / Q(x^2) on [-4, 4] (|erf| = 1 - 1.5e-8 beyond): max abs error 4.5e-7 in fp32 arithmetic
 // (checked against scipy over [-6, 6]); ~15 instructions instead of ocml erff's ~40 -- the GELU sits in GEMM epilogues.
@@ -392,6 +426,71 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int64_t m = m0 + (wm * TM + i) * 32 + r;
+            if (EPI == EPI_RESID) {
+                // read-modify-write of the residual rows: the reads of two column tiles (8 x 16 B per lane) are all in flight
+                // before the first store -- one memory round trip per pair of tiles instead of one per 16-byte piece
+                // (the stores to x_out would otherwise keep the compiler from moving the next read up)
+                constexpr int JB = TN >= 2 ? 2 : 1;
+#pragma unroll
+                for (int jb = 0; jb < TN; jb += JB) {
+                    f32x4 cur[JB][4];
+#pragma unroll
+                    for (int jj = 0; jj < JB; jj++)
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++)
+                            cur[jj][gq] = *reinterpret_cast<const f32x4 *>(p.x_out + (p.x_tiled ? xt_off(m, n0 + (wn * TN + jb + jj) * 32 + 8 * gq + 4 * h, p.N)
+                                                                                                    : m * p.N + n0 + (wn * TN + jb + jj) * 32 + 8 * gq + 4 * h));
+#pragma unroll
+                    for (int jj = 0; jj < JB; jj++)
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++) {
+                            const int j = jb + jj;
+                            f32x4 c = cur[jj][gq];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { c[e] += acc[i][j][4 * gq + e] * os; acc[i][j][4 * gq + e] = c[e]; }   // keep the new row for the stats
+                            *reinterpret_cast<f32x4 *>(p.x_out + (p.x_tiled ? xt_off(m, n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h, p.N)
+                                                                             : m * p.N + n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h)) = c;
+                            rsum[i] += (c[0] + c[1]) + (c[2] + c[3]);
+                        }
+                }
+                continue;
+            }
+            if (EPI == EPI_GELU && lut_addr != 0u) {
+                // Phi table in LDS (gemm_pk_kernel): 8 VALU + one gather per value; the 16 gathers of a column tile are in
+                // flight together (one LDS round trip per tile instead of one per 4 values)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    float v[16], fr[16];
+                    f32x2 tb[16];
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        v[g] = acc[i][j][g] * os;
+                        const float tt = __builtin_amdgcn_fmed3f(fmaf(v[g], kGeluLutScale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.002f);
+                        fr[g] = __builtin_amdgcn_fractf(tt);
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(tb[g]) : "v"(lut_addr + (unsigned)tt * 8u) : "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        asm volatile("" : "+v"(tb[g]));
+                        v[g] *= fmaf(fr[g], tb[g][1], tb[g][0]);
+                    }
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const int n = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h;
+                        u32x2 hi, lo;
+                        split4<T, NP>(v + 4 * gq, hi, lo);
+                        if (p.o_pk) {                       // hidden planes feed gemm_pk_kernel next
+                            *reinterpret_cast<u32x2 *>(p.o_hi + pk_off(m, n, 0, p.N >> 4, NP)) = hi;
+                            if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_hi + pk_off(m, n, 1, p.N >> 4, NP)) = lo;
+                        } else {
+                            *reinterpret_cast<u32x2 *>(p.o_hi + m * p.N + n) = hi;
+                            if (NP == 2) *reinterpret_cast<u32x2 *>(p.o_lo + m * p.N + n) = lo;
+                        }
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -399,31 +498,8 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
                     const int n = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h;   // first of 4 consecutive columns
                     float v[4] = {acc[i][j][4 * gq] * os, acc[i][j][4 * gq + 1] * os, acc[i][j][4 * gq + 2] * os,
                                   acc[i][j][4 * gq + 3] * os};
-                    if (EPI == EPI_RESID) {
-                        f32x4 *dst = reinterpret_cast<f32x4 *>(p.x_out + m * p.N + n);
-                        f32x4 cur = *dst;
-                        cur[0] += v[0]; cur[1] += v[1]; cur[2] += v[2]; cur[3] += v[3];
-                        *dst = cur;
-                        acc[i][j][4 * gq] = cur[0]; acc[i][j][4 * gq + 1] = cur[1];          // keep the new row for the stats
-                        acc[i][j][4 * gq + 2] = cur[2]; acc[i][j][4 * gq + 3] = cur[3];
-                        rsum[i] += (cur[0] + cur[1]) + (cur[2] + cur[3]);
-                    } else if (EPI == EPI_GELU) {
-                        if (lut_addr != 0u) {                // Phi table in LDS (gemm_pk_kernel): 8 VALU + one gather per value
-                            float fr[4];
-                            f32x2 tb[4];
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const float tt = __builtin_amdgcn_fmed3f(fmaf(v[e], kGeluLutScale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.002f);
-                                fr[e] = __builtin_amdgcn_fractf(tt);
-                                asm volatile("ds_read_b64 %0, %1" : "=v"(tb[e]) : "v"(lut_addr + (unsigned)tt * 8u) : "memory");
-                            }
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                asm volatile("" : "+v"(tb[e]));
-                                v[e] *= fmaf(fr[e], tb[e][1], tb[e][0]);
-                            }
-                        } else if (TM * TN >= 16) {          // one-wave-per-SIMD kernel: packed math
+                    if (EPI == EPI_GELU) {
+                        if (TM * TN >= 16) {          // one-wave-per-SIMD kernel: packed math
                             const f32x2 g0 = gelu_folded2((f32x2){v[0], v[1]}), g1 = gelu_folded2((f32x2){v[2], v[3]});
                             v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
                         } else {
@@ -774,6 +850,13 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p, 
     }
 #pragma unroll
     for (int S = 0; S < NST - 1; S++) issue(S);            // K >= 16 * KPS * NST is checked by the launcher
+    if (p.stagger > 0 && blockIdx.x < 256 && wave == 0) {
+        // Equal tiles keep the CUs in phase: all 256 in the main loop (HBM idle), then all in the epilogue (a burst the
+        // HBM cannot serve).  The first block of every CU starts up to one tile period late, spread evenly over the CUs of
+        // an XCD (blocks are dealt round-robin to the XCDs); the blocks that follow on a CU inherit its phase.
+        const int n = (int)((blockIdx.x >> 3) & 31) * p.stagger >> 5;
+        for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
