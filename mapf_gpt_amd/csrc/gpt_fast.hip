@@ -253,7 +253,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         const size_t nl = (size_t)((g->max_rows + 255) / 256) * 256 * C;
         MGPT_HIP(hipMalloc(&m->x_last, nl * sizeof(float)));
         MGPT_HIP(hipMemset(m->x_last, 0, nl * sizeof(float)));           // padding rows stay finite
-        m->x_tiled = m->attn256 && m->mlp_fused && m->pk_gemm && C == 256;
+        // chunk-major residual stream: the fused kernels (6M shape; 2M / tiny shapes with heads of 32)
+        m->x_tiled = (m->attn256 && m->mlp_fused && m->pk_gemm && C == 256) || (m->qkv_fused && g->hs == 32 && m->mlp_fused);
         if (m->x_tiled) MGPT_HIP(hipMalloc(&m->x_head, nl * sizeof(float)));
         if (m->pk_gemm) {
             MGPT_HIP(hipMalloc(&m->y_last, nl * NP * sizeof(uint16_t)));
@@ -372,7 +373,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     const bool attn_block = m->qkv_fused && g->hs == 32 && m->mlp_fused;
     // the first attention block forms x = wte[token] + wpe[position] itself (no embedding kernel, no first read of x)
     const bool embed_fused = attn_block && g->L > 1;
-    if (m->x_tiled) {
+    if (m->x_tiled && !embed_fused) {
         ProfScope ps(P_EMBED, s);
         hipLaunchKernelGGL(fastk::embed_tiled_kernel, dim3((unsigned)(M / 32)), dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, C);
         MGPT_LAUNCH_CHECK();

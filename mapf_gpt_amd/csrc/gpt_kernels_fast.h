@@ -1168,7 +1168,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t m = (int64_t)blockIdx.x * (NW * 32) + wave * 32 + r;     // this lane's token
-    float *xrow = x + m * C;
+    // x is chunk-major (xt_off): a wave's load / store is 1 KiB contiguous; chunk c = 4 j + gq sits c * 256 floats up
+    float *xt = x + (m - r) * C + r * 8 + 4 * h;
 
     // ---- stream helper: packet t -> LDS buffer (t & 1); every wave moves FRAGS*NP/4 fragment-planes of 1 KiB ----
     auto issue = [&](int t) {
@@ -1204,7 +1205,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
     for (int j = 0; j < CT; j++)
 #pragma unroll
         for (int gq = 0; gq < 4; gq++) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xt + (4 * j + gq) * 256);
             acc[j][4 * gq] = v[0]; acc[j][4 * gq + 1] = v[1]; acc[j][4 * gq + 2] = v[2]; acc[j][4 * gq + 3] = v[3];
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }
@@ -1365,7 +1366,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
     for (int j = 0; j < CT; j++)
 #pragma unroll
         for (int gq = 0; gq < 4; gq++) {
-            f32x4 *dst = reinterpret_cast<f32x4 *>(xrow + 32 * j + 8 * gq + 4 * h);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(xt + (4 * j + gq) * 256);
             f32x4 cur = *dst;
 #pragma unroll
             for (int e = 0; e < 4; e++) { cur[e] += acc[j][4 * gq + e] * inv2; acc[j][4 * gq + e] = cur[e]; }
@@ -1486,7 +1487,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
     const int r = lane & 31, h = lane >> 5;
     const int64_t b = blockIdx.x;
     const int tok0 = wave * 32;
-    float *xrow = x + (b * kT + tok0 + r) * C;
+    float *xt = x + (b * kT + tok0) * C + r * 8 + 4 * h;                 // chunk-major x (xt_off): chunk c = 4 j + gq at xt + c * 256
     const float *erow = EMBED ? wte + (size_t)tokens[b * kT + tok0 + r] * C : nullptr;   // token embedding row of this lane's token
     const float *prow = EMBED ? wpe + (size_t)(tok0 + r) * C : nullptr;                   // position embedding row
     const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(wpk);
@@ -1524,7 +1525,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
             for (int gq = 0; gq < 4; gq++) {
                 const int off = 32 * j + 8 * gq + 4 * h;
                 const f32x4 v = EMBED ? *reinterpret_cast<const f32x4 *>(erow + off) + *reinterpret_cast<const f32x4 *>(prow + off)
-                                      : *reinterpret_cast<const f32x4 *>(xrow + off);
+                                      : *reinterpret_cast<const f32x4 *>(xt + (4 * j + gq) * 256);
                 xv[j][4 * gq] = v[0]; xv[j][4 * gq + 1] = v[1]; xv[j][4 * gq + 2] = v[2]; xv[j][4 * gq + 3] = v[3];
                 s += (v[0] + v[1]) + (v[2] + v[3]);
             }
@@ -1721,7 +1722,8 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
         // ---- residual add, store, LayerNorm statistics of the new row (as the GEMM / MLP epilogues) ----
         // LAST: only token 255 (lanes 31 and 63 of the last wave) is kept, in the compact buffer
         const bool keep = !LAST || r == 31;
-        float *orow = LAST ? x_last + b * C : xrow;
+        // (LAST: row b of the compact matrix, chunk-major as well: tile b / 32, token b % 32)
+        float *orow = LAST ? x_last + (b >> 5) * 32 * C + (b & 31) * 8 + 4 * h : xt;
         float s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < CT; j++)
@@ -1729,10 +1731,10 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
             for (int gq = 0; gq < 4; gq++) {
                 const int off = 32 * j + 8 * gq + 4 * h;
                 f32x4 cur = EMBED ? *reinterpret_cast<const f32x4 *>(erow + off) + *reinterpret_cast<const f32x4 *>(prow + off)
-                                  : *reinterpret_cast<const f32x4 *>(xrow + off);
+                                  : *reinterpret_cast<const f32x4 *>(xt + (4 * j + gq) * 256);
 #pragma unroll
                 for (int e = 0; e < 4; e++) { cur[e] += pacc[j][4 * gq + e] * inv_scale_p; pacc[j][4 * gq + e] = cur[e]; }
-                if (keep) *reinterpret_cast<f32x4 *>(orow + 32 * j + 8 * gq + 4 * h) = cur;
+                if (keep) *reinterpret_cast<f32x4 *>(orow + (4 * j + gq) * 256) = cur;
                 s2 += (cur[0] + cur[1]) + (cur[2] + cur[3]);
             }
         if (stats_out != nullptr && !LAST) {

@@ -22,6 +22,18 @@ __global__ void mask_lo_planes(uint16_t *ws, size_t n16, int drop)
     if (i >= n16) return;
     if ((i >> 9) & 1) ws[i] &= (uint16_t)(0xffffu << drop);
 }
+// the kernel's residual stream is chunk-major (xt_off): [32-token tile][C / 8][32 tokens][8 floats]
+static std::vector<float> retile(const std::vector<float> &a, int C, bool to_tiled)
+{
+    std::vector<float> o(a.size());
+    const size_t M = a.size() / C;
+    for (size_t m = 0; m < M; m++)
+        for (int n = 0; n < C; n++) {
+            const size_t t = (((m >> 5) * (C >> 3) + (n >> 3)) << 8) + ((m & 31) << 3) + (n & 7), p = m * C + n;
+            if (to_tiled) o[t] = a[p]; else o[p] = a[t];
+        }
+    return o;
+}
 int main(int argc, char **argv)
 {
     const int C = 256;
@@ -65,11 +77,12 @@ int main(int argc, char **argv)
         uint64_t s2 = 99;
         for (auto &v : hx) v = gauss(s2) + 0.3f;
         float *x; hipMalloc(&x, hx.size() * 4);
-        hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(x, retile(hx, C, true).data(), hx.size() * 4, hipMemcpyHostToDevice);
         mlp256p_kernel<F16T, 2><<<grid, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb);
         hipError_t e = hipDeviceSynchronize();
         printf("grid %d: launch status: %s / %s\n", grid, hipGetErrorString(hipGetLastError()), hipGetErrorString(e));
         hipMemcpy(b.data(), x, b.size() * 4, hipMemcpyDeviceToHost);
+        b = retile(b, C, false);
         double mxd = 0, mx = 0; int worst = -1; long nan_count = 0;
         std::vector<double> xn(C), hid(4 * C);
         for (int m = 0; m < M; m++) {
