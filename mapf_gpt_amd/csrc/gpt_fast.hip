@@ -253,8 +253,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         const size_t nl = (size_t)((g->max_rows + 255) / 256) * 256 * C;
         MGPT_HIP(hipMalloc(&m->x_last, nl * sizeof(float)));
         MGPT_HIP(hipMemset(m->x_last, 0, nl * sizeof(float)));           // padding rows stay finite
-        // chunk-major residual stream: the fused kernels (6M shape; 2M / tiny shapes with heads of 32)
-        m->x_tiled = (m->attn256 && m->mlp_fused && m->pk_gemm && C == 256) || (m->qkv_fused && g->hs == 32 && m->mlp_fused);
+        // chunk-major residual stream: the fused kernels (6M shape; 2M / tiny shapes with heads of 32) and the packed-fragment GEMM chain
+        m->x_tiled = m->pk_gemm || (m->qkv_fused && g->hs == 32 && m->mlp_fused);
         if (m->x_tiled) MGPT_HIP(hipMalloc(&m->x_head, nl * sizeof(float)));
         if (m->pk_gemm) {
             MGPT_HIP(hipMalloc(&m->y_last, nl * NP * sizeof(uint16_t)));
@@ -335,14 +335,14 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
 }
 
 template <class T, int NP>
-int launch_ln_pack(const float *x, const float *gain, uint16_t *out, int64_t M, int C, hipStream_t s)
+int launch_ln_pack(const float *x, const float *gain, uint16_t *out, int64_t M, int C, int tiled, hipStream_t s)
 {
     ProfScope ps(P_LAYERNORM, s);
     const dim3 grid((unsigned)(M / 32));
-    if (C == 256) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 4>), grid, dim3(256), 0, s, x, gain, out, C);
-    else if (C == 512) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 8>), grid, dim3(256), 0, s, x, gain, out, C);
-    else if (C == 768) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 12>), grid, dim3(256), 0, s, x, gain, out, C);
-    else if (C == 1024) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 16>), grid, dim3(256), 0, s, x, gain, out, C);
+    if (C == 256) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 4>), grid, dim3(256), 0, s, x, gain, out, C, tiled);
+    else if (C == 512) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 8>), grid, dim3(256), 0, s, x, gain, out, C, tiled);
+    else if (C == 768) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 12>), grid, dim3(256), 0, s, x, gain, out, C, tiled);
+    else if (C == 1024) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 16>), grid, dim3(256), 0, s, x, gain, out, C, tiled);
     else { set_error("ln_pack: C=%d unsupported", C); return MGPT_ERR_UNSUPPORTED; }
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
@@ -422,7 +422,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                                    m->attn256_pk[l], m->attn[l].inv_scale, scale_log2e, m->y[0]);
             MGPT_LAUNCH_CHECK();
         } else if (m->pk_gemm) {
-            if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln1, m->apk, M, C, s)) != MGPT_OK) return rc;
+            if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln1, m->apk, M, C, m->x_tiled ? 1 : 0, s)) != MGPT_OK) return rc;
             ProfScope ps(P_GEMM_QKV, s);
             const size_t tile_halves = (size_t)(C / 16) * NP * 512;          // one 32-row tile of a PK matrix with K = C
             a.a_hi = m->apk; a.w_hi = m->attn_pk2[l]; a.chunk_major = 1;
@@ -499,7 +499,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         }
         if (m->pk_gemm) {
             // ---- LN2 -> PK planes; FC + GELU -> hidden PK planes; proj2 + residual ----
-            if ((rc = launch_ln_pack<T, NP>(mlp_x, P + lo.ln2, m->apk, mlp_M, C, s)) != MGPT_OK) return rc;
+            if ((rc = launch_ln_pack<T, NP>(mlp_x, P + lo.ln2, m->apk, mlp_M, C, m->x_tiled ? 1 : 0, s)) != MGPT_OK) return rc;
             a.M = (int)mlp_M;
             a.a_hi = m->apk; a.K = C; a.N = 4 * C; a.w_hi = m->fc_pk2[l]; a.out_scale = m->fc[l].inv_scale;
             a.o_hi = m->hbuf[0]; a.o_pk = 1; a.gelu_lut = m->gelu_lut;

@@ -725,21 +725,23 @@ __global__ __launch_bounds__(256) void pack_pk_kernel(const float *__restrict__ 
 // fragments of k-steps w, w+4, ...
 template <class T, int NP, int KSW>                        // KSW = k-steps per wave = C / 64
 __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ x, const float *__restrict__ gain,
-                                                      uint16_t *__restrict__ out, int C)
+                                                      uint16_t *__restrict__ out, int C, int tiled)
 {
     __shared__ float red[2][8][32];
     const int KS = C >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t rt = blockIdx.x, m = rt * 32 + r;
-    const float *xr = x + m * C + h * 8;
+    // tiled: x is chunk-major (xt_off); lane (r, h) of k-step ks owns chunk 2 ks + h of token r
+    const float *xr = tiled ? x + rt * 32 * C + h * 256 + r * 8 : x + m * C + h * 8;
+    const int kstride = tiled ? 512 : 16;
     f32x4 va[KSW], vb[KSW];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < KSW; i++) {
         const int ks = wave + 4 * i;
-        va[i] = *reinterpret_cast<const f32x4 *>(xr + ks * 16);
-        vb[i] = *reinterpret_cast<const f32x4 *>(xr + ks * 16 + 4);
+        va[i] = *reinterpret_cast<const f32x4 *>(xr + ks * kstride);
+        vb[i] = *reinterpret_cast<const f32x4 *>(xr + ks * kstride + 4);
         s += ((va[i][0] + va[i][1]) + (va[i][2] + va[i][3])) + ((vb[i][0] + vb[i][1]) + (vb[i][2] + vb[i][3]));
     }
     red[0][wave * 2 + h][r] = s;
