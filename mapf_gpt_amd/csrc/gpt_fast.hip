@@ -44,6 +44,7 @@ struct ModeState {          // one precision mode
     // [period step][pair][plane][lane][8], and the scale c_fc * gain was packed with
     std::vector<uint16_t *> mlp256_pk;
     std::vector<float> mlp256_inv1;
+    std::vector<float> attn256_inv;            // 1 / scale of the attn256 weight stream (c_attn.weight * ln_1.weight)
     float2 *gelu_lut = nullptr;                // the Phi table of the fused MLP kernels (kGeluLutN pairs)
     // C = 256, head size 32 (6M): attn256_kernel's c_attn stream in consumption order, per layer
     std::vector<uint16_t *> attn256_pk;
@@ -136,7 +137,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         MGPT_HIP(hipMalloc(&m->gelu_lut, lut.size() * sizeof(float2)));
         MGPT_HIP(hipMemcpy(m->gelu_lut, lut.data(), lut.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
-    if (C == 256) {
+    if (C == 256 && m->mlp_fused) {
         const size_t n16 = (size_t)fastk::kMPPeriod * 16 * NP * 512;
         m->mlp256_pk.assign(g->L, nullptr);
         m->mlp256_inv1.assign(g->L, 1.f);
@@ -160,11 +161,18 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         if (m->attn256) {
             const size_t n16 = (size_t)8 * fastk::kA256StepsPerHead * 8 * NP * 512;
             m->attn256_pk.assign(g->L, nullptr);
+            m->attn256_inv.assign(g->L, 1.f);
             for (int l = 0; l < g->L; l++) {
                 MGPT_HIP(hipMalloc(&m->attn256_pk[l], n16 * sizeof(uint16_t)));
+                const LayerOff &lo = g->layers[l];
+                // the stream carries c_attn.weight * ln_1.weight (model.py:19-20, 50): its own power-of-two scale
+                std::vector<float> wg(3 * C * C);
+                for (size_t i = 0; i < wg.size(); i++) wg[i] = host[lo.attn_w + i] * host[lo.ln1 + i % C];
+                const float sc = pick_scale(wg.data(), wg.size(), f16);
+                m->attn256_inv[l] = 1.0f / sc;
                 ProfScope ps(P_PACK, nullptr);
                 hipLaunchKernelGGL((fastk::pack_attn256_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)8 * fastk::kA256StepsPerHead * 8 * 64, 256)), dim3(256), 0,
-                                   nullptr, g->params + g->layers[l].attn_w, m->attn256_pk[l], 1.0f / m->attn[l].inv_scale);
+                                   nullptr, g->params + lo.attn_w, g->params + lo.ln1, m->attn256_pk[l], sc);
                 MGPT_LAUNCH_CHECK();
             }
             MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256_kernel<T, NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
@@ -415,11 +423,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             // ---- LN1 + QKV + attention in one kernel (q, k, v stay on chip) -> y operand planes for the out-projection ----
             ProfScope ps(P_ATTN, s);
             if (last_short)
-                hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, true>), dim3((unsigned)rows), dim3(512), (size_t)kA256Lds<NP>, s, g->x, P + lo.ln1,
-                                   m->attn256_pk[l], m->attn[l].inv_scale, scale_log2e, m->y_last);
+                hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, true>), dim3((unsigned)rows), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
+                                   m->attn256_pk[l], m->attn256_inv[l], scale_log2e, m->y_last, (unsigned long long *)nullptr);
             else
-                hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, false>), dim3((unsigned)rows), dim3(512), (size_t)kA256Lds<NP>, s, g->x, P + lo.ln1,
-                                   m->attn256_pk[l], m->attn[l].inv_scale, scale_log2e, m->y[0]);
+                hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, false>), dim3((unsigned)rows), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
+                                   m->attn256_pk[l], m->attn256_inv[l], scale_log2e, m->y[0], (unsigned long long *)nullptr);
             MGPT_LAUNCH_CHECK();
         } else if (m->pk_gemm) {
             if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln1, m->apk, M, C, m->x_tiled ? 1 : 0, s)) != MGPT_OK) return rc;

@@ -451,7 +451,8 @@ constexpr int kA256StepsPerHead = 6;
 constexpr int kA256Stagger = 0;
 
 template <class T, int NP>
-__global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restrict__ w, uint16_t *__restrict__ out, float scale)
+__global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restrict__ w, const float *__restrict__ gain,
+                                                           uint16_t *__restrict__ out, float scale)
 {
     constexpr int C = 256, NH = 8;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (global step, pair, lane)
@@ -467,7 +468,8 @@ __global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restri
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int g = 8 * (ks & 1) + e;
-        v[e] = row[32 * (ks >> 1) + (g & 3) + 8 * (g >> 2) + 4 * h] * scale;
+        const int col = 32 * (ks >> 1) + (g & 3) + 8 * (g >> 2) + 4 * h;
+        v[e] = row[col] * gain[col] * scale;               // ln_1.weight folded in (model.py:19-20, 50): the kernel only normalises
     }
     u32x2 h0, l0, h1, l1;
     split4<T, NP>(v, h0, l0);
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restri
 // block leaves stamps[block][8] = {entry cycles, entry 100-MHz ticks, cycles after LayerNorm, exit cycles, exit ticks,
 // cycles in the q|k|v projection steps, cycles waiting at the head's k / v barrier, cycles in the attention phase}.
 template <class T, int NP, bool LAST, int ABL = 0, int STG = kA256Stagger>
-__global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict__ x, const float *__restrict__ gain,
+__global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict__ x,
                                                          const uint16_t *__restrict__ wstream, float inv_scale, float scale_log2e,
                                                          uint16_t *__restrict__ y, unsigned long long *stamps = nullptr)
 {
@@ -551,19 +553,18 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
 #pragma unroll
         for (int j = 0; j < CT; j++)
 #pragma unroll
-            for (int g = 0; g < 16; g++) { const float d = xv[j][g] - mean; qv += d * d; }
+            for (int g = 0; g < 16; g++) { const float d = xv[j][g] - mean; xv[j][g] = d; qv += d * d; }   // (the centred row is kept)
         qv += __shfl_xor(qv, 32);
         const float rstd = rsqrtf(qv / (float)C + 1e-5f);
+        // (x - mean) * rstd; ln_1.weight is part of the weight stream (pack_attn256_kernel)
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const int j = ks >> 1, g0 = 8 * (ks & 1);
-            const f32x4 ga = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 4 * h);
-            const f32x4 gb = *reinterpret_cast<const f32x4 *>(gain + 32 * j + 8 * (g0 >> 2) + 8 + 4 * h);
             float v0[4], v1[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                v0[e] = (xv[j][g0 + e] - mean) * rstd * ga[e];
-                v1[e] = (xv[j][g0 + 4 + e] - mean) * rstd * gb[e];
+                v0[e] = xv[j][g0 + e] * rstd;
+                v1[e] = xv[j][g0 + 4 + e] * rstd;
             }
             u32x2 h0, l0, h1, l1;
             split4<T, NP>(v0, h0, l0);

@@ -16,10 +16,10 @@ void run(const char *tag, const float *x, const float *gain, const uint16_t *ws,
     hipFuncSetAttribute(reinterpret_cast<const void *>(&attn256_kernel<F16T, 2, false, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     fprintf(stderr, "running %s\n", tag);
-    attn256_kernel<F16T, 2, false, ABL><<<rows, 512, lds>>>(x, gain, ws, 1e-3f, 0.255f, y);
+    attn256_kernel<F16T, 2, false, ABL><<<rows, 512, lds>>>(x, ws, 1e-3f, 0.255f, y);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < 5; i++) attn256_kernel<F16T, 2, false, ABL><<<rows, 512, lds>>>(x, gain, ws, 1e-3f, 0.255f, y);
+    for (int i = 0; i < 5; i++) attn256_kernel<F16T, 2, false, ABL><<<rows, 512, lds>>>(x, ws, 1e-3f, 0.255f, y);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     const double flops = 3.0 * (6.0 * 256 * 256 * 256 + 4.0 * 256 * 256 * 256) * rows;
@@ -40,7 +40,7 @@ void run_real(const float *x, const float *gain, uint16_t *ws, uint16_t *y, int 
     for (auto &v : w) { v = 0.02f * gauss(st); mx = std::max(mx, fabsf(v)); }
     const float sc = ldexpf(1.f, (int)floorf(log2f(4096.f / mx)));
     float *dw; hipMalloc(&dw, w.size() * 4); hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice);
-    pack_attn256_kernel<F16T, 2><<<(8 * kA256StepsPerHead * 8 * 64 + 255) / 256, 256>>>(dw, ws, sc);
+    pack_attn256_kernel<F16T, 2><<<(8 * kA256StepsPerHead * 8 * 64 + 255) / 256, 256>>>(dw, gain, ws, sc);
     hipDeviceSynchronize();
     const size_t lds = 5 * 8 * 2 * 1024 + 2 * (256 * 80 + 32 * 528);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&attn256_kernel<F16T, 2, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -49,7 +49,7 @@ void run_real(const float *x, const float *gain, uint16_t *ws, uint16_t *y, int 
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
-        for (int i = 0; i < 100; i++) attn256_kernel<F16T, 2, false, 0><<<rows, 512, lds>>>(x, gain, ws, isc, sl2, y);
+        for (int i = 0; i < 100; i++) attn256_kernel<F16T, 2, false, 0><<<rows, 512, lds>>>(x, ws, isc, sl2, y);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("real operands: attn256_kernel %.3f ms per launch (100 launches)\n", ms / 100);
@@ -58,7 +58,7 @@ void run_real(const float *x, const float *gain, uint16_t *ws, uint16_t *y, int 
     {
         const size_t ny = (size_t)rows * 256 * 256 * 2;
         std::vector<uint16_t> y0(ny), y1(ny);
-        attn256_kernel<F16T, 2, false, 0, 0><<<rows, 512, lds>>>(x, gain, ws, isc, sl2, y);
+        attn256_kernel<F16T, 2, false, 0, 0><<<rows, 512, lds>>>(x, ws, isc, sl2, y);
         hipMemcpy(y0.data(), y, ny * 2, hipMemcpyDeviceToHost);
         auto one = [&](auto stg_c) {
             constexpr int STG = decltype(stg_c)::value;
@@ -68,7 +68,7 @@ void run_real(const float *x, const float *gain, uint16_t *ws, uint16_t *y, int 
             float best = 1e9f;
             for (int rep = 0; rep < 3; rep++) {
                 hipEventRecord(e0);
-                for (int i = 0; i < 60; i++) kern<<<rows, 512, lds>>>(x, gain, ws, isc, sl2, y, nullptr);
+                for (int i = 0; i < 60; i++) kern<<<rows, 512, lds>>>(x, ws, isc, sl2, y, nullptr);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 best = std::min(best, ms / 60);
@@ -81,7 +81,7 @@ void run_real(const float *x, const float *gain, uint16_t *ws, uint16_t *y, int 
         one(std::integral_constant<int, 0>{});
     }
     unsigned long long *stp; hipMalloc(&stp, (size_t)rows * 64);
-    attn256_kernel<F16T, 2, false, 32><<<rows, 512, lds>>>(x, gain, ws, isc, sl2, y, stp);
+    attn256_kernel<F16T, 2, false, 32><<<rows, 512, lds>>>(x, ws, isc, sl2, y, stp);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)rows * 8);
     hipMemcpy(h.data(), stp, h.size() * 8, hipMemcpyDeviceToHost);
