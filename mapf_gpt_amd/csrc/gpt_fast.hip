@@ -330,7 +330,7 @@ int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
 template <class T, int NP, int EPI>
 int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
 {
-    constexpr int NST = fastk::gemm_pk_nst(NP), KPS = fastk::gemm_pk_kps(NP);
+    constexpr int NST = fastk::gemm_pk_nst(NP, 8, EPI), KPS = fastk::gemm_pk_kps(NP);
     MGPT_REQUIRE(a.M % 256 == 0 && a.N % 256 == 0 && a.K % 32 == 0 && a.K >= 16 * KPS * NST, MGPT_ERR_UNSUPPORTED,
                  "gemm_pk shape M=%d N=%d K=%d", a.M, a.N, a.K);
     a.n_tiles_n = a.N / 256;

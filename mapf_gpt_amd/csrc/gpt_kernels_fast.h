@@ -283,6 +283,7 @@ struct GemmArgs {
     const float2 *gelu_lut;                                          // EPI_GELU in gemm_pk_kernel: the Phi table (kGeluLutN pairs) or NULL
     int stagger;                                                     // gemm_pk_kernel: start-up spread of the CUs, x 64 cycles (see there)
     int x_tiled;                                                     // EPI_RESID: x_out is chunk-major (xt_off) instead of row-major
+    unsigned *cu_arrivals;                                           // gemm_pk_kernel<.., NWV = 4>: per-CU arrival counters (see there) or NULL
 };
 
 // Chunk-major residual stream: x[M][C] stored as [M / 32][C / 8][32 tokens][8 floats].  A wave whose lane (r, h) owns token r
@@ -791,22 +792,26 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
 // the library runs KPS = 1.
 // DBG (probe only): 1 = wave 0 leaves stamps[block][6] = {entry cycles, entry 100-MHz ticks, cycles at the first stage, at the
 // end of the main loop, at exit, exit ticks}.
+// NWV = 8: one 256 x 256 block per CU.  NWV = 4: 128 x 256 blocks, two per CU, each with its own ring and barrier, started
+// half a tile apart (cu_arrivals) so that the epilogue of one runs under the main loop of the other.
 constexpr int gemm_pk_kps(int NP) { return 1; }
-constexpr int gemm_pk_nst(int NP) { return NP == 2 ? 4 : 6; }
-constexpr int gemm_pk_lds(int NP) { return gemm_pk_nst(NP) * 16 * gemm_pk_kps(NP) * NP * 1024; }   // + the Phi table when used
+constexpr int gemm_pk_nst(int NP, int NWV = 8, int EPI = 0) { return NWV == 8 ? (NP == 2 ? 4 : 6) : (NP == 2 ? 3 : (EPI == EPI_GELU ? 4 : 6)); }
+constexpr int gemm_pk_lds(int NP, int NWV = 8, int EPI = 0) { return gemm_pk_nst(NP, NWV, EPI) * (NWV + 8) * gemm_pk_kps(NP) * NP * 1024; }   // + the Phi table when used
 
 template <class T, int NP, int EPI, int NWV, int DBG = 0>
-__global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p, unsigned long long *stamps = nullptr)
+__global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsigned long long *stamps = nullptr)
 {
-    static_assert(NWV == 8, "8 waves of 64 x 128");
+    static_assert(NWV == 8 || NWV == 4, "8 or 4 waves of 64 x 128");
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
     if constexpr (DBG != 0) { ts[0] = __builtin_readcyclecounter(); ts[1] = wall_clock64(); }
-    constexpr int TM = 2, TN = 4;                          // MFMA tiles per wave; waves are 4 x 2
+    constexpr int TM = 2, TN = 4;                          // MFMA tiles per wave; waves are (NWV / 2) x 2
+    constexpr int AF = NWV;                                // A fragments per k-step = block rows / 32
     constexpr bool SWAP = (EPI != EPI_VT);
     constexpr int KPS = gemm_pk_kps(NP);                   // k-steps per ring stage
-    constexpr int NST = gemm_pk_nst(NP);                   // ring depth, in stages
-    constexpr int STAGE = 16 * KPS * NP * 1024;            // 8 A fragments + 8 B fragments, KPS k-steps, NP planes each
-    constexpr int PER_WAVE = 16 * KPS * NP / NWV;          // direct-to-LDS loads a wave issues per stage
+    constexpr int NST = gemm_pk_nst(NP, NWV, EPI);         // ring depth, in stages
+    constexpr int STAGE = (AF + 8) * KPS * NP * 1024;      // AF A fragments + 8 B fragments, KPS k-steps, NP planes each
+    constexpr int PER_WAVE = (AF + 8) * KPS * NP / NWV;    // direct-to-LDS loads a wave issues per stage
+    static_assert((AF + 8) * KPS * NP % NWV == 0 && NST >= 3, "ring shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NST][STAGE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -819,13 +824,13 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p, 
     const int nb = gridDim.x, ntn = p.n_tiles_n, mtn = nb / ntn;
     int id = blockIdx.x;
     if ((nb & 7) == 0) id = (id & 7) * (nb >> 3) + (id >> 3);
-    constexpr int GM = 4;
+    constexpr int GM = 32 / AF;                            // 1024 token rows per band
     const int band = id / (GM * ntn);
     const int gm = min(GM, mtn - band * GM);
     const int rem = id - band * GM * ntn;
     const int nt = rem / gm, mt = band * GM + (rem - nt * gm);
     const int KS = p.K >> 4, NSTG = KS / KPS;
-    const unsigned char *abase = reinterpret_cast<const unsigned char *>(p.a_hi) + (size_t)mt * 8 * KS * NP * 1024 + lane * 16;
+    const unsigned char *abase = reinterpret_cast<const unsigned char *>(p.a_hi) + (size_t)mt * AF * KS * NP * 1024 + lane * 16;
     const unsigned char *bbase = reinterpret_cast<const unsigned char *>(p.w_hi) + (size_t)nt * 8 * KS * NP * 1024 + lane * 16;
 
     // stage S -> LDS [fragment f][k-step kk of the stage][plane]: the KPS * NP pieces of a fragment are contiguous on both sides
@@ -835,8 +840,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p, 
         for (int i = 0; i < PER_WAVE; i++) {
             const int c = wave + NWV * i;                  // piece c = (f * KPS + kk) * NP + pl
             const int f = c / (KPS * NP), q = c - f * (KPS * NP);
-            const unsigned char *src = (f < 8) ? abase + ((size_t)(f * KS + S * KPS) * NP + q) * 1024
-                                               : bbase + ((size_t)((f - 8) * KS + S * KPS) * NP + q) * 1024;
+            const unsigned char *src = (f < AF) ? abase + ((size_t)(f * KS + S * KPS) * NP + q) * 1024
+                                                : bbase + ((size_t)((f - AF) * KS + S * KPS) * NP + q) * 1024;
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(dst + (size_t)c * 1024), 16, 0, 0);
         }
     };
@@ -852,12 +857,18 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p, 
     }
 #pragma unroll
     for (int S = 0; S < NST - 1; S++) issue(S);            // K >= 16 * KPS * NST is checked by the launcher
-    if (p.stagger > 0 && blockIdx.x < 256 && wave == 0) {
-        // Equal tiles keep the CUs in phase: all 256 in the main loop (HBM idle), then all in the epilogue (a burst the
-        // HBM cannot serve).  The first block of every CU starts up to one tile period late, spread evenly over the CUs of
-        // an XCD (blocks are dealt round-robin to the XCDs); the blocks that follow on a CU inherit its phase.
-        const int n = (int)((blockIdx.x >> 3) & 31) * p.stagger >> 5;
-        for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1);
+    if (NWV == 4 && p.stagger > 0 && p.cu_arrivals != nullptr && blockIdx.x < 512 && wave == 0) {
+        // The two blocks of a CU start together and, with equal work, stay in phase: both in the main loop, then both in
+        // the epilogue.  Of the first two blocks that arrive on a CU (a counter per CU, identified by its hardware id), the
+        // second starts p.stagger x 64 cycles late -- half a tile; the blocks that follow on the CU inherit the phase.
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned old = 0;
+        if (lane == 0) old = atomicAdd(p.cu_arrivals + (((xcc & 15u) << 8) | ((hw >> 8) & 255u)), 1u);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old & 1u)
+            for (int i = 0; i < p.stagger; i++) __builtin_amdgcn_s_sleep(1);
     }
 
     f32x16 acc[TM][TN];
@@ -876,7 +887,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p, 
 #pragma unroll
             for (int i = 0; i < TM; i++) fa[buf][i][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((wm * TM + i) * KPS * NP + pl) * 1024);
 #pragma unroll
-            for (int j = 0; j < TN; j++) fb[buf][j][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((8 + wn * TN + j) * KPS * NP + pl) * 1024);
+            for (int j = 0; j < TN; j++) fb[buf][j][pl] = *reinterpret_cast<const u32x4 *>(st + (size_t)((AF + wn * TN + j) * KPS * NP + pl) * 1024);
         }
     };
     auto round = [&](int buf, int pa, int pb) {            // one MFMA on each of the TM x TN accumulators
@@ -930,7 +941,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pk_kernel(GemmArgs p, 
         }
     }
     if constexpr (DBG != 0) { asm volatile("s_nop 0" ::: "memory"); ts[3] = __builtin_readcyclecounter(); }
-    gemm16_epilogue<T, NP, EPI, TM, TN, 2>(p, acc, (int64_t)mt * 256, nt * 256, wm, wn, r, h, lut_addr);
+    gemm16_epilogue<T, NP, EPI, TM, TN, 2>(p, acc, (int64_t)mt * (AF * 32), nt * 256, wm, wn, r, h, lut_addr);
     if constexpr (DBG != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = __builtin_readcyclecounter(); ts[5] = wall_clock64();

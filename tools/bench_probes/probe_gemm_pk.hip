@@ -15,7 +15,9 @@ void run(const char *tag, uint16_t *a, uint16_t *w, uint16_t *o, float *x, const
     GemmArgs p{};
     p.a_hi = a; p.w_hi = w; p.out_scale = 1.0f; p.M = M; p.N = N; p.K = K; p.n_tiles_n = N / 256; p.x_out = x; p.o_hi = o; p.o_pk = 1; p.gelu_lut = lut;
     p.C = 768; p.n_head = 12; p.hs = 64; p.stagger = stagger < 0 ? 0 : stagger; p.x_tiled = stagger < 0;
-    const size_t lds = (size_t)gemm_pk_lds(NP) + (EPI == EPI_GELU ? kGeluLutN * 8 : 0);
+    const size_t lds = (size_t)gemm_pk_lds(NP, NWV, EPI) + (EPI == EPI_GELU ? kGeluLutN * 8 : 0);
+    static unsigned *arr = nullptr; if (!arr) { hipMalloc(&arr, 4096 * 4); hipMemset(arr, 0, 4096 * 4); }
+    p.cu_arrivals = arr;
     auto kern = &gemm_pk_kernel<T, NP, EPI, NWV>;
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -76,6 +78,10 @@ int main()
     }
     for (int K : {768, 1536, 3072}) run<BF16T, 1, EPI_GELU>("bf16 gelu->pk", a, w, o, x, lut, M, 3072, K);
     for (int K : {768, 1536, 3072}) run<BF16T, 1, EPI_RESID>("bf16 resid", a, w, o, x, lut, M, 768, K);
+    printf("two 128 x 256 blocks per CU, second arrival on a CU delayed by n x 64 cycles:\n");
+    for (int sg : {0, 200, 400, 600}) { printf("n = %d\n", sg); run<BF16T, 1, EPI_GELU, 4>("bf16 gelu->pk 2/CU", a, w, o, x, lut, M, 3072, 768, sg); }
+    for (int sg : {0, 300, 600}) { printf("n = %d\n", sg); run<BF16T, 1, EPI_RESID, 4>("bf16 resid 2/CU", a, w, o, x, lut, M, 768, 768, sg); }
+    for (int sg : {0, 800, 1600}) { printf("n = %d\n", sg); run<BF16T, 1, EPI_RESID, 4>("bf16 resid 2/CU", a, w, o, x, lut, M, 768, 3072, sg); }
     printf("chunk-major residual stream (x as [M/32][N/8][32][8]):\n");
     for (int K : {768, 3072}) run<BF16T, 1, EPI_RESID>("bf16 resid tiled", a, w, o, x, lut, M, 768, K, -1);
     run<F16T, 2, EPI_RESID, 8>("f16x3 resid tiled", a, w, o, x, lut, M, 256, 256, -1);
