@@ -311,7 +311,7 @@ def build_workload(name, precision, rank, world, local_rank, instances=0, use_gr
     n_total = inst_per_gpu * world
     lo, hi = shard_range(n_total, rank, world)
     rows = (hi - lo) * n_agents
-    chunk = min(rows, chunk_rows or (4096 if model != "85M" else 1024))
+    chunk = min(rows, chunk_rows or (16384 if model != "85M" else 1024))
     net = build_model(model, seed=0, max_rows=chunk, precision=precision, device=f"cuda:{local_rank}")
     if name == "cfg4":                     # one map per instance, seeded by the global instance id
         grid, pos, goal = cfg4_instances(lo, hi, n_agents)
@@ -322,7 +322,7 @@ def build_workload(name, precision, rank, world, local_rank, instances=0, use_gr
     run = BatchedRunner(grid, hi - lo, n_agents, net, max_episode_steps=max_steps, seed=0, do_sample=True,
                         precision=precision, device=f"cuda:{local_rank}", row_offset=lo * n_agents, use_graph=use_graph)
     run.reset(pos, goal)
-    return dict(name=name, run=run, net=net, pos=pos, goal=goal, grid=grid, s_ok=s_ok, g_ok=g_ok, rows=rows, n_total=n_total,
+    return dict(name=name, run=run, net=net, pos=pos, goal=goal, grid=grid, s_ok=s_ok, g_ok=g_ok, rows=rows, n_total=n_total, chunk=chunk,
                 n_agents=n_agents, inst_per_gpu=inst_per_gpu, model=model, max_steps=max_steps, map_name=map_name)
 
 
@@ -409,13 +409,16 @@ def secondary_shard(name, precision, steps, warmup, local_rank, coll_dev, instan
     return out
 
 
-def traffic_for(kernel_key):
+def traffic_for(kernel_key, rows_per_launch=None):
     """HBM bytes per launch from the committed PMC passes (profiles/r03_hbm_traffic.json, falling back to earlier rounds' files):
-    a replay of an earlier rocprofv3 run of this command, NOT a measurement of this run."""
+    a replay of an earlier rocprofv3 run of this command, NOT a measurement of this run.  An entry that records the launch size
+    it was measured at is only used for launches of that size."""
     for f in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tf = os.path.join(ROOT, "profiles", f)
         if os.path.exists(tf):
             t = json.load(open(tf)).get(kernel_key)
+            if t and rows_per_launch is not None and t.get("rows_per_launch", rows_per_launch) != rows_per_launch:
+                return None
             if t:
                 return {"hbm_bytes_per_launch": t["fetch_corrected_x2"] + t["write"], "fetch_raw": t["fetch_raw"], "write": t["write"],
                         "measured_in_run": False,
@@ -432,7 +435,7 @@ def main():
                     help="default: cfg3 at --gpus 1, cfg4 (its per-GPU shard) at --gpus N > 1")
     ap.add_argument("--precision", default=os.environ.get("MGPT_BENCH_PRECISION", "f16x3"), choices=["f32", "f16x3", "bf16"])
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default: the workload's)")
-    ap.add_argument("--chunk-rows", type=int, default=0, help="rows per forward launch (default 4096; 1024 for the 85M shape)")
+    ap.add_argument("--chunk-rows", type=int, default=0, help="rows per forward launch (default 16384; 1024 for the 85M shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tokenizer-leg", action="store_true", help="skip the >=1e5-row tokenizer roofline launch")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg2 run reported under 'secondary'")
@@ -505,8 +508,8 @@ def main():
                 ach = cls[dom] * a.steps / (ms * 1e-3) / 1e12
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[a.precision],
                                    "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.precision],
-                                   "traffic": traffic_for(f"{name}_{a.precision}_{dom}"),
-                                   "avg_launch_ms": ms / n, "launches": n,
+                                   "traffic": traffic_for(f"{name}_{a.precision}_{dom}", w["chunk"]),
+                                   "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": w["chunk"],
                                    "algorithmic_gflop_per_launch": cls[dom] * a.steps / n / 1e9,
                                    "mfma_issue_frac": (3.0 if a.precision == "f16x3" else 1.0) * ach / PEAK_TFLOPS[a.precision],
                                    "note": "algorithmic flops (reference-executed) / HIP-event time of the class over the timed region"

@@ -255,7 +255,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      lds + fastk::kGeluLutN * 8));
-        MGPT_HIP(hipMalloc(&m->apk, (size_t)g->max_rows * kT * C * NP * sizeof(uint16_t)));
+        if (!(C == 256 && m->mlp_fused && g->hs == 32 && g->nh == 8))      // LayerNorm planes of the GEMM chain (the 6M kernels normalise in registers)
+            MGPT_HIP(hipMalloc(&m->apk, (size_t)g->max_rows * kT * C * NP * sizeof(uint16_t)));
     }
     {
         const size_t nl = (size_t)((g->max_rows + 255) / 256) * 256 * C;
@@ -271,9 +272,13 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
     }
     const size_t M = (size_t)g->max_rows * kT;
     MGPT_HIP(hipMalloc(&m->stats, M * sizeof(float2)));
+    // q|k and v^T planes exist in HBM only where the projection is a GEMM of its own: the fused attention kernels keep them on chip
+    const bool qkv_on_chip = m->attn256 || (m->qkv_fused && g->hs == 32 && m->mlp_fused);
     for (int p = 0; p < NP; p++) {
-        MGPT_HIP(hipMalloc(&m->qk[p], 2 * M * C * sizeof(uint16_t)));
-        MGPT_HIP(hipMalloc(&m->vt[p], M * C * sizeof(uint16_t)));
+        if (!qkv_on_chip) {
+            MGPT_HIP(hipMalloc(&m->qk[p], 2 * M * C * sizeof(uint16_t)));
+            MGPT_HIP(hipMalloc(&m->vt[p], M * C * sizeof(uint16_t)));
+        }
         if (m->pk_gemm && p > 0) continue;                                   // PK buffers interleave the planes in [0]
         MGPT_HIP(hipMalloc(&m->y[p], M * C * (m->pk_gemm ? NP : 1) * sizeof(uint16_t)));
         if (!m->mlp_fused) MGPT_HIP(hipMalloc(&m->hbuf[p], 4 * M * C * (m->pk_gemm ? NP : 1) * sizeof(uint16_t)));

@@ -19,13 +19,13 @@ def table(path):
 KEYS = [  # (json key, kernel substring, grid, note)
     ("cfg3_f16x3_gpt_mlp_fused", "mlp256p_kernel<mgpt::fastk::F16T, 2, 0>", 131072,
      "mlp256p_kernel (persistent, 256 workgroups x 512 threads): x rows read by the producer for LayerNorm and again by the consumer for the "
-     "residual add (2 x 1.07 GB), the 2.2 MB cyclic weight stream per 128-token block served by L2, one write of x"),
-    ("cfg3_f16x3_gpt_attention", "attn256_kernel<mgpt::fastk::F16T, 2, false, 0", 2097152,
-     "attn256_kernel: one read of x (1.07 GB), y operand planes out (2 x 0.54 GB); q, k, v stay on chip"),
-    ("cfg3_f16x3_gpt_attention_last_layer", "attn256_kernel<mgpt::fastk::F16T, 2, true, 0", 2097152,
+     "residual add (2 x 3.22 GB), the 2.2 MB cyclic weight stream per 128-token block served by L2, one write of x"),
+    ("cfg3_f16x3_gpt_attention", "attn256_kernel<mgpt::fastk::F16T, 2, false, 0", 6291456,
+     "attn256_kernel: one read of x (3.22 GB), y operand planes out (2 x 1.61 GB); q, k, v stay on chip"),
+    ("cfg3_f16x3_gpt_attention_last_layer", "attn256_kernel<mgpt::fastk::F16T, 2, true, 0", 6291456,
      "last layer: all of x read for K/V, only token 255's output row written"),
-    ("cfg3_f16x3_gpt_gemm_attn_proj", "gemm_pk_kernel<mgpt::fastk::F16T, 2, 2, 8", 2097152,
-     "out-projection GEMM: y planes (1.07 GB) + x (1.07 GB) in, x out: HBM-bound"),
+    ("cfg3_f16x3_gpt_gemm_attn_proj", "gemm_pk_kernel<mgpt::fastk::F16T, 2, 2, 8", 6291456,
+     "out-projection GEMM: y planes (3.22 GB) + x (3.22 GB) in, x out: HBM-bound"),
     ("cfg3_tok_generate_observations", "tokens_kernel<4, 4>", 196608, "cfg3's own launch: 64 instances x 192 agents"),
     ("cfg4_tok_generate_observations_65536_rows", "tokens_kernel<2, 4>", 1048576, "cfg4 per-GPU shard: 512 instances x 128 agents, per-instance maps"),
     ("tok_generate_observations_524160_rows", "tokens_kernel<4, 16>", 2096640, "2730 instances x 192 agents on the warehouse map"),
@@ -35,7 +35,7 @@ f, w = table(sys.argv[1]), table(sys.argv[2])
 out = {"source": f"{sys.argv[1]} + {sys.argv[2]}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (counters + kernel trace only) of "
                  "`python bench.py --no-cpu-baseline --no-secondary --steps 4 --warmup 1` (cfg3, f16x3, plus the two tokenizer roofline legs); counters in KiB; "
                  "FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md (64 B counted per 128-B request)",
-       "units": "bytes per launch; a full GPT launch = 4096 rows = 1,048,576 tokens, C = 256 (x plane 1,073,741,824 B)"}
+       "units": "bytes per launch; a cfg3 GPT launch = all 12,288 rows of the step = 3,145,728 tokens, C = 256 (x plane 3,221,225,472 B)"}
 for key, sub, grid, note in KEYS:
     fk = [k for k in f if sub in k and k.endswith(f"grid={grid}")]
     wk = [k for k in w if sub in k and k.endswith(f"grid={grid}")]
@@ -44,5 +44,7 @@ for key, sub, grid, note in KEYS:
     fr = f[fk[0]][1]
     wr = w[wk[0]][1] if wk else 0.0
     out[key] = {"kernel": sub, "grid_threads": grid, "dispatches": f[fk[0]][0], "fetch_raw": fr, "fetch_corrected_x2": 2 * fr, "write": wr, "note": note}
+    if key.startswith("cfg3_f16x3_gpt"):
+        out[key]["rows_per_launch"] = 12288
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: (round(v["fetch_corrected_x2"] / 1e6, 1), round(v["write"] / 1e6, 1)) for k, v in out.items() if isinstance(v, dict)}, indent=1))
