@@ -581,6 +581,7 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
         if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3) + NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3)) : "memory");
         if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+        if constexpr (STG >= 100) { if (wave >= NW / 2) __builtin_amdgcn_s_sleep(STG - 100); }   // probe: phase offset in the projection steps
         if (!(ABL & 1) && gstep + NSLOT - 1 < NSTEP) issue(gstep + NSLOT - 1, slot_prev);   // (gstep + NSLOT - 1) % NSLOT
         gstep++;
     };
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
         for (int g = 0; g < 16; g++) o[g] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
         if (full && !(ABL & 4)) {
-            if constexpr (!LAST && STG > 0) { if (wave >= NW / 2) __builtin_amdgcn_s_sleep(STG); }
+            if constexpr (!LAST && STG > 0 && STG < 100) { if (wave >= NW / 2) __builtin_amdgcn_s_sleep(STG); }
             u32x4 kf[2][2], vf[2][2];
             auto load_k = [&](int kt) {                    // K fragments of key tile kt: [k-step][plane]
                 const unsigned a = kr_addr + (unsigned)kt * (32 * KROW);

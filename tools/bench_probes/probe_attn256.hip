@@ -76,8 +76,9 @@ void run_real(const float *x, const float *gain, uint16_t *ws, uint16_t *y, int 
             hipMemcpy(y1.data(), y, ny * 2, hipMemcpyDeviceToHost);
             printf("stagger %2d x 64 cycles: %.3f ms per launch (best of 3 x 60), y %s\n", STG, best, memcmp(y0.data(), y1.data(), ny * 2) ? "DIFFERS" : "identical");
         };
-        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 5>{}); one(std::integral_constant<int, 6>{});
-        one(std::integral_constant<int, 7>{}); one(std::integral_constant<int, 8>{}); one(std::integral_constant<int, 10>{}); one(std::integral_constant<int, 13>{});
+        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 5>{}); one(std::integral_constant<int, 8>{});
+        printf("(100 + n: waves 4-7 sleep n x 64 cycles after every ring barrier of the projection steps)\n");
+        one(std::integral_constant<int, 101>{}); one(std::integral_constant<int, 102>{}); one(std::integral_constant<int, 103>{}); one(std::integral_constant<int, 105>{});
         one(std::integral_constant<int, 0>{});
     }
     unsigned long long *stp; hipMalloc(&stp, (size_t)rows * 64);
