@@ -46,6 +46,7 @@ struct ModeState {          // one precision mode
     std::vector<float> mlp256_inv1;
     std::vector<float> attn256_inv;            // 1 / scale of the attn256 weight stream (c_attn.weight * ln_1.weight)
     float2 *gelu_lut = nullptr;                // the Phi table of the fused MLP kernels (kGeluLutN pairs)
+    std::vector<float2 *> mlp256_lut;          // per layer: the same table times 1 / scale of the layer's c_fc stream (mlp256p_kernel)
     // C = 256, head size 32 (6M): attn256_kernel's c_attn stream in consumption order, per layer
     std::vector<uint16_t *> attn256_pk;
     bool attn256 = false;
@@ -141,6 +142,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         const size_t n16 = (size_t)fastk::kMPPeriod * 16 * NP * 512;
         m->mlp256_pk.assign(g->L, nullptr);
         m->mlp256_inv1.assign(g->L, 1.f);
+        m->mlp256_lut.assign(g->L, nullptr);
         for (int l = 0; l < g->L; l++) {
             MGPT_HIP(hipMalloc(&m->mlp256_pk[l], n16 * sizeof(uint16_t)));
             const LayerOff &lo = g->layers[l];
@@ -149,6 +151,13 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             for (size_t i = 0; i < wg.size(); i++) wg[i] = host[lo.fc_w + i] * host[lo.ln2 + i % C];
             const float sc1 = pick_scale(wg.data(), wg.size(), f16);
             m->mlp256_inv1[l] = 1.0f / sc1;
+            {   // Phi table pre-multiplied by the (power-of-two) 1 / scale: GELU = pre-activation in stream units x entry, the same bits
+                std::vector<float2> lt(fastk::kGeluLutN);
+                MGPT_HIP(hipMemcpy(lt.data(), m->gelu_lut, lt.size() * sizeof(float2), hipMemcpyDeviceToHost));
+                for (auto &e : lt) { e.x *= m->mlp256_inv1[l]; e.y *= m->mlp256_inv1[l]; }
+                MGPT_HIP(hipMalloc(&m->mlp256_lut[l], lt.size() * sizeof(float2)));
+                MGPT_HIP(hipMemcpy(m->mlp256_lut[l], lt.data(), lt.size() * sizeof(float2), hipMemcpyHostToDevice));
+            }
             ProfScope ps(P_PACK, nullptr);
             hipLaunchKernelGGL((fastk::pack_mlp256p_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)fastk::kMPPeriod * 16 * 64, 256)), dim3(256), 0,
                                nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, g->params + lo.ln2, m->mlp256_pk[l], sc1,
@@ -295,6 +304,7 @@ void free_mode(ModeState *m)
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
     for (auto *p : m->mlp_pk) (void)hipFree(p);
     for (auto *p : m->mlp256_pk) (void)hipFree(p);
+    for (auto *p : m->mlp256_lut) (void)hipFree(p);
     for (auto *p : m->attn256_pk) (void)hipFree(p);
     (void)hipFree(m->gelu_lut);
     for (auto *p : m->qkv_pk) (void)hipFree(p);
@@ -490,7 +500,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                 // persistent: one workgroup per CU walks the 128-token blocks round-robin (results do not depend on the grid)
                 const int n_blocks = (int)(mlp_M / 128);
                 hipLaunchKernelGGL((fastk::mlp256p_kernel<T, NP>), dim3((unsigned)std::min(n_blocks, m->n_cu)), dim3(512), (size_t)fastk::kMPLds<NP>, s,
-                                   mlp_x, m->mlp256_pk[l], m->mlp256_inv1[l], m->proj2[l].inv_scale, m->gelu_lut, n_blocks, (unsigned long long *)nullptr);
+                                   mlp_x, m->mlp256_pk[l], m->mlp256_inv1[l], m->proj2[l].inv_scale, m->mlp256_lut[l], n_blocks, (unsigned long long *)nullptr);
                 if (!m->pk_gemm && l + 1 < g->L) {                       // this kernel leaves no LayerNorm statistics behind
                     MGPT_LAUNCH_CHECK();
                     if ((rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;

@@ -95,6 +95,7 @@ __device__ __forceinline__ void vm_wait()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// gelu_lut: the Phi table TIMES inv1 (GELU(v) = v_stream * (Phi(v) * inv1), the same bits as (v_stream * inv1) * Phi(v)).
 // STAMPS (tools/bench_probes/check_mlp256p.hip only): 1 = wave 0 and wave 4 of every workgroup leave s_memtime / s_memrealtime at entry and
 // exit; 2 = cycles spent in wait + barrier instead of the exit wall clock; 3 = cycles per phase of a step: {wait + barrier,
 // DMA issue + slot bookkeeping, chunks 0-2, chunk 3 (up to the next step's top)}.
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const float hv = hsrc[4 * q + e];
-                gvv[e] = hv * inv1;
+                gvv[e] = hv;                               // (stream units: the table entries carry the power-of-two 1 / scale)
                 const float t = __builtin_amdgcn_fmed3f(fmaf(hv, lut_scale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.002f);
                 gfr[e] = __builtin_amdgcn_fractf(t);
                 const unsigned idx = (unsigned)t;

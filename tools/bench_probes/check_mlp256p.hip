@@ -62,6 +62,9 @@ int main(int argc, char **argv)
         const float f0 = (float)(0.5 * (1.0 + erf(v0 * 0.70710678118654752440)));
         lut[i] = make_float2(f0, (float)(0.5 * (1.0 + erf(v1 * 0.70710678118654752440)) - (double)f0));
     }
+    std::vector<float2> lutp = lut;                        // mlp256p_kernel: the table times 1 / scale of the c_fc stream
+    for (auto &e : lutp) { e.x *= 1.f / sc1; e.y *= 1.f / sc1; }
+    float2 *dlp; hipMalloc(&dlp, lutp.size() * 8); hipMemcpy(dlp, lutp.data(), lutp.size() * 8, hipMemcpyHostToDevice);
     constexpr int LDSP = kMPLds<2>;
     float2 *dl; hipMalloc(&dl, lut.size() * 8); hipMemcpy(dl, lut.data(), lut.size() * 8, hipMemcpyHostToDevice);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256p_kernel<F16T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
@@ -78,7 +81,7 @@ int main(int argc, char **argv)
         for (auto &v : hx) v = gauss(s2) + 0.3f;
         float *x; hipMalloc(&x, hx.size() * 4);
         hipMemcpy(x, retile(hx, C, true).data(), hx.size() * 4, hipMemcpyHostToDevice);
-        mlp256p_kernel<F16T, 2><<<grid, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb);
+        mlp256p_kernel<F16T, 2><<<grid, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dlp, nb);
         hipError_t e = hipDeviceSynchronize();
         printf("grid %d: launch status: %s / %s\n", grid, hipGetErrorString(hipGetLastError()), hipGetErrorString(e));
         hipMemcpy(b.data(), x, b.size() * 4, hipMemcpyDeviceToHost);
@@ -164,7 +167,7 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 3; rep++) {
         float ms;
         hipEventRecord(e0);
-        for (int i = 0; i < 60; i++) mlp256p_kernel<F16T, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb);
+        for (int i = 0; i < 60; i++) mlp256p_kernel<F16T, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dlp, nb);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         printf("mlp256p_kernel (persistent, %d workgroups): %.3f ms per 4096-row launch  [%s]\n", ncu, ms / 60, hipGetErrorString(hipGetLastError()));
         hipEventRecord(e0);
@@ -176,7 +179,7 @@ int main(int argc, char **argv)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256p_kernel<F16T, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
         float ms;
         hipEventRecord(e0);
-        for (int i = 0; i < 20; i++) mlp256p_kernel<F16T, 2, 4><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb, st);
+        for (int i = 0; i < 20; i++) mlp256p_kernel<F16T, 2, 4><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dlp, nb, st);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         std::vector<unsigned long long> h4((size_t)ncu * 8);
         hipMemcpy(h4.data(), st, h4.size() * 8, hipMemcpyDeviceToHost);
@@ -191,20 +194,20 @@ int main(int argc, char **argv)
         mask_lo_planes<<<(unsigned)((n16 + 255) / 256), 256>>>(pkp, n16, drop);
         float ms;
         hipEventRecord(e0);
-        for (int i = 0; i < 60; i++) mlp256p_kernel<F16T, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb);
+        for (int i = 0; i < 60; i++) mlp256p_kernel<F16T, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dlp, nb);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         printf("mlp256p_kernel, weights' lo planes with the low %2d mantissa bits zeroed: %.3f ms per launch\n", drop, ms / 60);
     }
     pack_mlp256p_kernel<F16T, 2><<<(kMPPeriod * 16 * 64 + 255) / 256, 256>>>(fc, pj, g, pkp, sc1, sc2);
-    for (int i = 0; i < 40; i++) mlp256p_kernel<F16T, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb);
-    mlp256p_kernel<F16T, 2, 1><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb, st);
+    for (int i = 0; i < 40; i++) mlp256p_kernel<F16T, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dlp, nb);
+    mlp256p_kernel<F16T, 2, 1><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dlp, nb, st);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)ncu * 8);
     hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
     double cyc = 0, rt = 0;
     for (int w = 0; w < ncu; w++) { cyc += (double)(h[8 * w + 2] - h[8 * w]); rt += (double)(h[8 * w + 3] - h[8 * w + 1]); }
     hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256p_kernel<F16T, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
-    mlp256p_kernel<F16T, 2, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb, st);
+    mlp256p_kernel<F16T, 2, 2><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dlp, nb, st);
     hipDeviceSynchronize();
     {
         std::vector<unsigned long long> h2((size_t)ncu * 8);
@@ -214,7 +217,7 @@ int main(int argc, char **argv)
         printf("mlp256p (instrumented): producer wave 0 spends %.1f %% of its cycles in wait + barrier, consumer wave 4 %.1f %%\n", 100 * sp / tp, 100 * sc / tc);
     }
     hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp256p_kernel<F16T, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
-    mlp256p_kernel<F16T, 2, 3><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dl, nb, st);
+    mlp256p_kernel<F16T, 2, 3><<<ncu, 512, LDSP>>>(x, pkp, 1.f / sc1, 1.f / sc2, dlp, nb, st);
     hipDeviceSynchronize();
     {
         std::vector<unsigned long long> h3((size_t)ncu * 8);
