@@ -155,3 +155,20 @@ def test_chunking_and_batch_position_do_not_change_a_row(shape, precision):
     c = big.logits_tokens(tokens[perm].contiguous()).cpu().numpy()
     assert np.array_equal(c, b[perm.numpy()])
     assert np.isfinite(a).all()
+
+
+@pytest.mark.parametrize("n_head,n_embd,precision,tol", [(4, 256, "f16x3", TOL), (4, 256, "bf16", 6e-2), (8, 512, "f16x3", TOL), (2, 64, "f16x3", TOL)])
+def test_other_shapes_take_the_generic_chain(n_head, n_embd, precision, tol):
+    """Shapes that are none of the reference's three (model.py:107-115 allows any): C = 256 with heads of 64 and C = 512 run the
+    packed-fragment GEMM chain with the chunk-major residual stream, C = 64 the small fused kernels -- logits against the fp64
+    torch port of model.py on the same synthetic weights, last-layer shortcut and ragged chunking included (3 rows, max_rows 2)."""
+    from mapf_gpt_amd.model import GPT, GPTConfig
+    args = weights.model_args(dict(n_layer=2, n_head=n_head, n_embd=n_embd))
+    sd = weights.synthetic_state_dict(args, seed=11, scale=2.0)
+    net = GPT(GPTConfig(**args), max_rows=2, precision=precision)
+    net.load_state_dict(sd)
+    rows = load_tok("mazes000")["tokens"][7, :3]
+    logits = net.logits_tokens(torch.from_numpy(rows).cuda()).cpu().numpy()
+    ref = gpt_oracle.forward_logits(sd, args, rows, dtype=torch.float64).numpy()
+    err = np.abs(logits - ref).max()
+    assert np.isfinite(logits).all() and err <= tol, f"C={n_embd} heads={n_head} {precision}: max |dlogit| = {err:.3e}"
