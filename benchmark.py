@@ -19,7 +19,8 @@ def main():
     ap.add_argument("--eval-root", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "eval_configs"))
     ap.add_argument("--folders", nargs="*", default=None, help="default: every sub-folder of --eval-root")
     ap.add_argument("--weights", nargs="*", default=[], help="ALGORITHM=path overrides of path_to_weights")
-    ap.add_argument("--precision", default=None, choices=[None, "f32", "f16x3", "bf16"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "bf16"],
+                    help="policy arithmetic of every algorithm entry (the adapter's own default is f32)")
     a = ap.parse_args()
 
     import torch

@@ -12,11 +12,13 @@ namespace mgpt {
 
 void set_error(const char *fmt, ...);
 
-// Library-wide allocation generation: bumped whenever a context frees or re-allocates device memory that a captured step
-// graph may have baked in (weight planes and workspaces at finalize / lazy mode build, lifelong goal queues).  mgpt_step
-// compares it with the value it saw at its last step and, on a change, drops its graph and runs one eager step first.
-uint64_t alloc_generation();
-void bump_alloc_generation();
+// Allocation generation, PER CONTEXT: a policy / env context bumps its own counter whenever it frees or re-allocates device
+// memory that a captured step graph may have baked in (weight planes and workspaces at finalize / lazy mode build, lifelong
+// goal queues).  mgpt_step compares the generations of the contexts IT holds with the values it saw at its last step and, on
+// a change, drops its graph and runs one eager step first; other models, envs and runners of the process are not disturbed.
+// (The tokenizer context never re-allocates after create.)
+uint64_t gpt_generation(const mgpt_gpt *g);
+uint64_t env_generation(const mgpt_env *e);
 
 #define MGPT_HIP(call)                                                                     \
     do {                                                                                   \

@@ -240,7 +240,10 @@ struct mgpt_env {
     int32_t *qnext = nullptr, *reached = nullptr;
     int queue_len = 0;
     bool have_grids = false, have_reset = false;
+    uint64_t generation = 1;            // bumped when the goal queues are replaced (common.h: env_generation)
 };
+
+uint64_t mgpt::env_generation(const mgpt_env *e) { return e->generation; }
 
 extern "C" int mgpt_env_create(mgpt_env **out, int n_inst, int n_agents, int H, int W, int n_grids, int max_episode_steps)
 {
@@ -322,7 +325,7 @@ extern "C" int mgpt_env_set_lifelong(mgpt_env *e, const int16_t *d_goal_queue, i
 {
     MGPT_REQUIRE(e, MGPT_ERR_ARG, "NULL argument");
     hipStream_t s = (hipStream_t)stream;
-    bump_alloc_generation();                             // a captured step graph holds the queue pointers (or their absence)
+    e->generation++;                                     // a captured step graph holds the queue pointers (or their absence)
     (void)hipFree(e->goal_queue); (void)hipFree(e->qnext); (void)hipFree(e->reached);
     e->goal_queue = nullptr; e->qnext = nullptr; e->reached = nullptr; e->queue_len = 0;
     if (d_goal_queue == nullptr || queue_len <= 0) return MGPT_OK;          // back to on_target = "nothing"

@@ -8,6 +8,8 @@
 
 using namespace mgpt;
 
+uint64_t mgpt::gpt_generation(const mgpt_gpt *g) { return g->generation; }
+
 namespace {
 
 constexpr int kT = 256;

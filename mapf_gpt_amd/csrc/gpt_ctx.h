@@ -21,6 +21,7 @@ struct mgpt_gpt {
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *hbuf = nullptr, *logits_tmp = nullptr;
     // fast-path state (gpt_fast.hip)
     void *fast = nullptr;
+    uint64_t generation = 1;          // bumped when weight planes / workspaces are freed or rebuilt (common.h: gpt_generation)
 };
 
 

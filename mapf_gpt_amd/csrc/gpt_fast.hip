@@ -102,7 +102,7 @@ template <class T, int NP>
 int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
 {
     const size_t C = g->C;
-    bump_alloc_generation();                             // a step graph captured before this build must not be replayed as is
+    g->generation++;                                     // a step graph captured before this build must not be replayed as is
     std::vector<float> host(g->n_params);
     MGPT_HIP(hipMemcpy(host.data(), g->params, g->n_params * sizeof(float), hipMemcpyDeviceToHost));
     m->np = NP;
@@ -297,9 +297,9 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
     return MGPT_OK;
 }
 
-void free_mode(ModeState *m)
+void free_mode(mgpt_gpt *g, ModeState *m)
 {
-    if (m->built) bump_alloc_generation();               // captured step graphs hold these pointers
+    if (m->built) g->generation++;                       // captured step graphs hold these pointers
     auto fr = [](std::vector<PlaneSet> &v) { for (auto &p : v) { (void)hipFree(p.hi); (void)hipFree(p.lo); } v.clear(); };
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
     for (auto *p : m->mlp_pk) (void)hipFree(p);
@@ -583,7 +583,7 @@ int gpt_fast_finalize(mgpt_gpt *g)
 {
     FastState *f = static_cast<FastState *>(g->fast);
     if (f) {                                             // parameters changed: planes are rebuilt lazily
-        for (auto &m : f->mode) free_mode(&m);
+        for (auto &m : f->mode) free_mode(g, &m);
     } else {
         g->fast = new FastState();
     }
@@ -594,7 +594,7 @@ void gpt_fast_destroy(mgpt_gpt *g)
 {
     FastState *f = static_cast<FastState *>(g->fast);
     if (!f) return;
-    for (auto &m : f->mode) free_mode(&m);
+    for (auto &m : f->mode) free_mode(g, &m);
     delete f;
     g->fast = nullptr;
 }
@@ -615,7 +615,7 @@ int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_lo
             rc = build_mode<fastk::BF16T, 1>(g, m, false);
             if (rc == MGPT_OK) rc = (g->hs == 32) ? raise_attn_lds<fastk::BF16T, 1, 32>(attn_lds) : raise_attn_lds<fastk::BF16T, 1, 64>(attn_lds);
         }
-        if (rc != MGPT_OK) { free_mode(m); return rc; }         // no half-built planes survive a failed build (e.g. out of memory)
+        if (rc != MGPT_OK) { free_mode(g, m); return rc; }         // no half-built planes survive a failed build (e.g. out of memory)
     }
     if (precision == MGPT_PREC_F16X3) return forward_chunk<fastk::F16T, 2>(g, m, d_tokens, rows, d_logits, s);
     return forward_chunk<fastk::BF16T, 1>(g, m, d_tokens, rows, d_logits, s);

@@ -19,10 +19,6 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-static std::atomic<uint64_t> g_alloc_generation{1};
-uint64_t alloc_generation() { return g_alloc_generation.load(std::memory_order_acquire); }
-void bump_alloc_generation() { g_alloc_generation.fetch_add(1, std::memory_order_acq_rel); }
-
 static const char *kProfNames[P_COUNT] = {
     "bfs_distance_field", "tok_update_agents", "tok_next_action", "tok_generate_observations",
     "env_step", "env_metrics", "gpt_embed", "gpt_layernorm", "gpt_gemm_qkv", "gpt_attention",

@@ -36,7 +36,7 @@ struct mgpt_step {
     const int32_t *cap_actions = nullptr;
     int cap_gmc = -1;
     bool capture_failed = false;
-    uint64_t seen_gen = 0;                      // mgpt::alloc_generation() after our last step (0: never ran)
+    uint64_t seen_gpt_gen = 0, seen_env_gen = 0; // generations of OUR contexts after our last step (0: never ran)
 };
 
 namespace {
@@ -111,10 +111,10 @@ extern "C" int mgpt_step_run(mgpt_step *st, uint8_t *d_tokens, int32_t *d_action
     MGPT_REQUIRE(st && d_tokens && d_actions, MGPT_ERR_ARG, "NULL argument");
     hipStream_t s = (hipStream_t)stream;
     const int gmc = goals_may_change ? 1 : 0;
-    // a context re-allocated or freed device memory since our last step (weights reloaded -> planes freed and rebuilt lazily,
+    // one of OUR contexts re-allocated or freed device memory since our last step (weights reloaded -> planes freed and rebuilt lazily,
     // goal queues replaced): the graph holds dead pointers, and the rebuild (hipMalloc, synchronous copies, null-stream pack
     // kernels) must not happen inside a capture -> drop the graph and run one eager step first
-    if (alloc_generation() != st->seen_gen) {
+    if (gpt_generation(st->gpt) != st->seen_gpt_gen || env_generation(st->env) != st->seen_env_gen) {
         drop_graph(st);
         st->eager_runs = 0;
     }
@@ -122,7 +122,8 @@ extern "C" int mgpt_step_run(mgpt_step *st, uint8_t *d_tokens, int32_t *d_action
     if (!use_graph || st->capture_failed || st->eager_runs < 1 || prof_is_enabled()) {
         st->eager_runs++;
         const int rc = step_body(st, d_tokens, d_actions, gmc, s);
-        st->seen_gen = alloc_generation();     // (the lazy build inside this step bumped it)
+        st->seen_gpt_gen = gpt_generation(st->gpt);   // (the lazy build inside this step bumped it)
+        st->seen_env_gen = env_generation(st->env);
         return rc;
     }
     if (!st->exec || st->cap_tokens != d_tokens || st->cap_actions != d_actions || st->cap_gmc != gmc) {

@@ -51,8 +51,10 @@ class MAPFGPTInferenceConfig(BaseModel):
     parallel_backend: Optional[str] = None
     seed: Optional[int] = 0
     preprocessing: Optional[str] = None
-    # extension: arithmetic of the policy forward ("f32" exact, "f16x3" split-fp16, "bf16")
-    precision: str = "f16x3"     # default = the 1e-5 mode that runs at MFMA speed ("f32" stays selectable)
+    # extension: arithmetic of the policy forward.  Default "f32" = exact fp32 MFMA, the reference's own arithmetic, whatever the
+    # checkpoint's weight statistics; "f16x3" (split-fp16, 1e-5 of fp32 on N(0, 0.02)-scale weights, 2-3x faster) and "bf16"
+    # (the reference's autocast class) are opt-in: bench.py, benchmark.py and example.py pass theirs explicitly.
+    precision: Literal["f32", "f16x3", "bf16"] = "f32"
 
 
 def strip_prefix_from_state_dict(state_dict, prefix="_orig_mod."):
@@ -137,6 +139,9 @@ class MAPFGPTInference:
         (inference.py:133-145 keeps one ObservationGenerator per slot: same state, kept per instance here).  A later call may
         present any subset of a group's slots: absent instances are masked out of the update and keep their state."""
         dev = self.cfg.device
+        if len(set(positions)) != len(positions):
+            # the reference would update one generator twice; here the second entry would overwrite the first one's staging
+            raise ValueError("act_batch: every environment slot (positions entry) may appear once per call")
         counts = [len(o) for o in observations_list]
         if offsets is None:
             offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).tolist()
@@ -147,7 +152,8 @@ class MAPFGPTInference:
         for pos, obs in zip(positions, observations_list):
             if pos not in self._obs_generators:
                 grid = np.asarray(obs[0]["global_obstacles"])                                # inference.py:135
-                fresh.setdefault((grid.shape[0], grid.shape[1], len(obs)), []).append((pos, (grid != 0).astype(np.uint8)))
+                # .astype(int) first: the reference truncates (0.5 -> free cell) before the generator tests for non-zero
+                fresh.setdefault((grid.shape[0], grid.shape[1], len(obs)), []).append((pos, (grid.astype(int) != 0).astype(np.uint8)))
         for (H, W, n), members in fresh.items():
             grp = _SlotGroup([p for p, _ in members], np.stack([g for _, g in members]), n, self.input_parameters, dev)
             for p in grp.slots:

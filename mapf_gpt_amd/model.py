@@ -150,14 +150,29 @@ class GPT:
             probs = torch.softmax(logits[:, :5], dim=-1)                       # model.py:250-254
             nxt = torch.multinomial(probs, num_samples=1, generator=generator)  # model.py:257
             return nxt.squeeze()
-        if do_sample and (not hasattr(self, "_act_seed") or self._act_torch_seed != torch.initial_seed()):
-            # drawn lazily at the first SAMPLED call (a greedy first call must not pin seed 0) and re-drawn whenever
-            # torch.manual_seed was called since: the reference's multinomial follows the global RNG in both cases
-            self._act_torch_seed = torch.initial_seed()
-            self._act_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if do_sample:
+            # The library sampler's seed is drawn from torch's global (CPU) RNG at the first SAMPLED call (a greedy first call
+            # must not pin seed 0) and drawn again -- call counter back to 0 -- whenever that RNG was touched since our draw:
+            # torch.manual_seed(s), also with the SAME s as before (the usual reproducibility pattern: the second run then
+            # replays the first one's draws, as the reference's multinomial would), or any other consumer of the global stream.
+            state = torch.get_rng_state()
+            if getattr(self, "_act_seed", None) is None or not torch.equal(state, self._act_rng_after):
+                self._act_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                self._act_rng_after = torch.get_rng_state()
+                self._act_calls = 0
         step = self._act_calls
         self._act_calls += 1
-        return self.act_tokens(tokens, do_sample=do_sample, seed=getattr(self, "_act_seed", 0), step=step).to(torch.int64).squeeze()
+        return self.act_tokens(tokens, do_sample=do_sample, seed=getattr(self, "_act_seed", None) or 0, step=step).to(torch.int64).squeeze()
+
+    def reset_sampler(self, seed=None):
+        """Explicit control of the generator-less sampler: forget the drawn seed (the next sampled act() draws a new one from
+        torch's global RNG) or pin `seed`; the call counter restarts either way."""
+        self._act_calls = 0
+        if seed is None:
+            self._act_seed = None
+        else:
+            self._act_seed = int(seed)
+            self._act_rng_after = torch.get_rng_state()
 
 
 def build_model(name_or_args, seed=0, scale=1.0, max_rows=2048, precision="f32", device="cuda", state_dict=None):

@@ -55,8 +55,29 @@ def test_adapter_act_batch_bookkeeping():
         obs = [e.step(a)[0] for e, a in zip(envs, acts)]
     single = algo.act(obs[0])                                     # inference.py:148-149 -> slot 0, fresh generator
     assert len(single) == 12 and 0 in algo._obs_generators
+    with pytest.raises(ValueError):                               # a slot twice in one call would lose the first entry
+        algo.act_batch([obs[0], obs[1]], positions=[7, 7])
     algo.reset_states()
     assert algo._obs_generators == {} and algo._last_actions == {}
+
+
+def test_adapter_truncates_fractional_obstacles_like_the_reference():
+    """inference.py:135 builds the grid with .astype(int), so 0.5 is a FREE cell and 1.7 an obstacle; the rows of an
+    environment whose global_obstacles carries such values must equal the rows of the truncated integer map."""
+    from mapf_gpt_amd.env import GridEnv
+    from mapf_gpt_amd.inference import MAPFGPTInference, MAPFGPTInferenceConfig
+    from mapf_gpt_amd.model import build_model
+    net = build_model("tiny", seed=0, max_rows=32)
+    env = GridEnv(map_name="validation-random-seed-000", num_agents=8, seed=2, max_episode_steps=8)
+    obs = env.reset()[0]
+    g = np.asarray(obs[0]["global_obstacles"]).astype(np.float64)
+    frac = np.where(g != 0, 1.7, 0.5)                             # same truncated map, fractional entries
+    obs_frac = [dict(o, global_obstacles=frac) for o in obs]
+    rows = []
+    for o in (obs, obs_frac):
+        algo = MAPFGPTInference(MAPFGPTInferenceConfig(path_to_weights="synthetic:tiny", batch_size=16), net=_GreedyNet(net))
+        rows.append(algo._prepare_inputs(0, o).cpu().numpy())
+    assert np.array_equal(rows[0], rows[1])
 
 
 def test_adapter_shared_context_subset_calls_vs_oracle():

@@ -147,8 +147,13 @@ def test_256_real_rows_within_1e5_of_reference(shape, scale, precision):
     if precision == "f32" and (shape, scale) == ("85M", 4):
         assert e64 <= 2 * e_ref and e32 <= 2 * e_ref, msg
     else:
-        assert e32 <= TOL or e64 <= 1.05 * e_ref, msg
-        assert e64 <= max(TOL, 1.05 * e_ref), msg
+        # e32 stays bounded in every case (it may exceed 1e-5 only where the reference's own fp32 run is further
+        # than that from fp64, and then by at most twice that distance), and the fp64 yardstick gets real headroom: the recorded
+        # 85M x4 f16x3 numbers are e64 = 3.77e-5 against e_ref = 3.64e-5 (ratio 1.036, profiles/r03_parity_records.jsonl) --
+        # a 1.05 bound would flip on any change of accumulation order; 1.15 still means "as close to fp64 as the reference".
+        assert e32 <= max(TOL, 2.0 * e_ref), msg
+        assert e32 <= TOL or e64 <= 1.15 * e_ref, msg
+        assert e64 <= max(TOL, 1.15 * e_ref), msg
 
 
 @pytest.mark.parametrize("shape", ["2M", "6M"])
@@ -266,3 +271,14 @@ def test_generatorless_act_advances_between_calls():
     draws = np.stack([net.act(idx).cpu().numpy() for _ in range(4)])
     assert draws.min() >= 0 and draws.max() <= 4
     assert all((draws[i] != draws[j]).any() for i in range(4) for j in range(i))
+    # re-seeding with the SAME seed replays the same draws (the reference's multinomial follows the global RNG) ...
+    torch.manual_seed(11)
+    again = np.stack([net.act(idx).cpu().numpy() for _ in range(4)])
+    assert np.array_equal(draws, again)
+    # ... a different seed does not, and the explicit control pins / forgets the seed
+    torch.manual_seed(12)
+    assert (net.act(idx).cpu().numpy() != draws[0]).any()
+    net.reset_sampler(seed=5)
+    a = net.act(idx).cpu().numpy()
+    net.reset_sampler(seed=5)
+    assert np.array_equal(a, net.act(idx).cpu().numpy())

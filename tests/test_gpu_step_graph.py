@@ -100,4 +100,4 @@ def test_cfg1_graph_is_not_slower():
             res[tag].append((time.perf_counter() - t0) / 100 * 1e3)
     med = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
     print(f"cfg1 ms/step (median of 5): graph {med['graph']:.3f}  eager {med['eager']:.3f}  speedup {med['eager'] / med['graph']:.2f}x")
-    assert med["graph"] < 1.5 * med["eager"], res          # a gross regression only; the functional gate is graph == eager above
+    assert med["graph"] < 1.2 * med["eager"], res          # medians of 5 alternating repeats; the functional gate is graph == eager above

@@ -19,6 +19,10 @@ def test_config_mirrors_reference_fields_and_forbids_extras():
     MAPFGPTInferenceConfig(parallel_backend="balanced_dask", num_process=4)     # 01-random.yaml:147-148
     with pytest.raises(ValidationError):
         MAPFGPTInferenceConfig(not_a_field=1)                                   # extra=forbid, inference.py:13
+    # the adapter's own arithmetic default is the exact fp32 mode; the faster modes are opt-in and validated
+    assert c.precision == "f32" and MAPFGPTInferenceConfig(precision="f16x3").precision == "f16x3"
+    with pytest.raises(ValidationError):
+        MAPFGPTInferenceConfig(precision="fp8")
 
 
 def test_named_maps_and_padding():
