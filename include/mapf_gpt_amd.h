@@ -140,6 +140,17 @@ int mgpt_env_step_host(mgpt_env *env, const int32_t *h_actions, uint8_t *h_state
  * the agents' mean [agents in the 11 x 11 window / traversable cells of the window]). */
 int mgpt_env_metrics(mgpt_env *env, float *d_metrics, void *stream);
 
+/* Collision-rule switches (bit mask, default 0 = the spec of DESIGN.md section 4).  The two places where that spec rests on
+ * recalled -- not verifiable offline -- POGEMA behaviour are switchable, so that pinning against fixtures captured from POGEMA
+ * (tests/golden/make_golden_env.py) is a flag flip, not a rewrite:
+ *   MGPT_ENV_RULE_NO_FOLLOW (1)    a move into a cell another agent occupies at the start of the step becomes wait even if
+ *                                  that agent leaves it (default: following a leaving agent is allowed);
+ *   MGPT_ENV_RULE_LOWEST_WINS (2)  a contested empty cell goes to the lowest-id mover (default: every claimant waits).
+ * A captured step graph stays valid: the mask is a kernel argument of the next capture (the call bumps the env generation). */
+#define MGPT_ENV_RULE_NO_FOLLOW 1
+#define MGPT_ENV_RULE_LOWEST_WINS 2
+int mgpt_env_set_rules(mgpt_env *env, int rules);
+
 /* Lifelong mode (POGEMA on_target="restart", experiment_setup/create_env.py:28-32): d_goal_queue is int16
  * [n_inst][n_agents][queue_len][2] (padded coords); an agent that ends a step on its goal takes the next entry of its
  * queue (wrapping) and the arrival is counted; episodes then end by truncation only.  NULL / 0 switches back to

@@ -57,6 +57,7 @@ SYMBOLS = {
     "mgpt_env_copy_state": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mgpt_env_step_host": (_i, [_vp, _vp, _vp, _vp]),
     "mgpt_env_metrics": (_i, [_vp, _vp, _vp]),
+    "mgpt_env_set_rules": (_i, [_vp, _i]),
     "mgpt_env_set_lifelong": (_i, [_vp, _vp, _i, _vp]),
     "mgpt_env_lifelong_counts": (_i, [_vp, _vp, _vp]),
     "mgpt_dataset_create": (_i, [_pp, _vp, _i, _i, _vp]),

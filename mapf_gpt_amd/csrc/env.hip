@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1024) void env_step_kernel(const uint8_t *__restric
                                                         int32_t *__restrict__ tcount, uint8_t *__restrict__ done,
                                                         const int16_t *__restrict__ goal_queue, int queue_len,
                                                         int32_t *__restrict__ qnext, int32_t *__restrict__ reached,
-                                                        const uint8_t *__restrict__ wfree, double *__restrict__ dens)
+                                                        const uint8_t *__restrict__ wfree, double *__restrict__ dens, int rules)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *cur = reinterpret_cast<int *>(smem);
@@ -143,6 +143,14 @@ __global__ __launch_bounds__(1024) void env_step_kernel(const uint8_t *__restric
         tgt[a] = my_tgt;
     }
     __syncthreads();
+    if (rules & MGPT_ENV_RULE_NO_FOLLOW) {            // (workgroup-uniform) a cell occupied at the start of the step cannot be entered
+        bool occupied = false;
+        if (valid && my_tgt != my_cur)
+            for (int b = 0; b < n_agents; b++) occupied |= (b != a && cur[b] == my_tgt);
+        __syncthreads();
+        if (occupied) { my_tgt = my_cur; tgt[a] = my_cur; }
+        __syncthreads();
+    }
     bool swap = false;                                // rule 2, decided on the rule-1 targets
     if (valid && my_tgt != my_cur) {
         for (int b = 0; b < n_agents; b++)
@@ -154,9 +162,13 @@ __global__ __launch_bounds__(1024) void env_step_kernel(const uint8_t *__restric
     for (;;) {                                        // rule 3 (Jacobi: all reads see the previous round)
         int revert = 0;
         if (valid && my_tgt != my_cur) {
-            int c = 0;
-            for (int b = 0; b < n_agents; b++) c += (tgt[b] == my_tgt) ? 1 : 0;
-            revert = c > 1;
+            if (rules & MGPT_ENV_RULE_LOWEST_WINS) {  // a staying agent or a mover with a smaller id claims my target
+                for (int b = 0; b < n_agents; b++) revert |= (b != a && tgt[b] == my_tgt && (cur[b] == my_tgt || b < a)) ? 1 : 0;
+            } else {
+                int c = 0;
+                for (int b = 0; b < n_agents; b++) c += (tgt[b] == my_tgt) ? 1 : 0;
+                revert = c > 1;
+            }
         }
         const int any = __syncthreads_or(revert);
         if (revert) { my_tgt = my_cur; tgt[a] = my_cur; }
@@ -241,6 +253,7 @@ struct mgpt_env {
     int queue_len = 0;
     bool have_grids = false, have_reset = false;
     uint64_t generation = 1;            // bumped when the goal queues are replaced (common.h: env_generation)
+    int rules = 0;                      // MGPT_ENV_RULE_* mask (mgpt_env_set_rules)
 };
 
 uint64_t mgpt::env_generation(const mgpt_env *e) { return e->generation; }
@@ -321,6 +334,15 @@ extern "C" int mgpt_env_reset(mgpt_env *e, const int16_t *d_pos, const int16_t *
     return MGPT_OK;
 }
 
+extern "C" int mgpt_env_set_rules(mgpt_env *e, int rules)
+{
+    MGPT_REQUIRE(e, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE((rules & ~(MGPT_ENV_RULE_NO_FOLLOW | MGPT_ENV_RULE_LOWEST_WINS)) == 0, MGPT_ERR_ARG, "unknown rule bits in %d", rules);
+    if (rules != e->rules) e->generation++;              // the mask is a kernel argument inside a captured step graph
+    e->rules = rules;
+    return MGPT_OK;
+}
+
 extern "C" int mgpt_env_set_lifelong(mgpt_env *e, const int16_t *d_goal_queue, int queue_len, void *stream)
 {
     MGPT_REQUIRE(e, MGPT_ERR_ARG, "NULL argument");
@@ -365,7 +387,7 @@ extern "C" int mgpt_env_step(mgpt_env *e, const int32_t *d_actions, void *stream
     ProfScope ps(P_ENV_STEP, s);
     hipLaunchKernelGGL(env_step_kernel, dim3(e->n_inst), dim3(threads), env_lds_bytes(e->n_agents), s, e->grids,
                        e->n_grids, e->n_agents, e->H, e->W, e->max_steps, e->pos, e->goal, d_actions, e->arrive,
-                       e->tcount, e->done, e->goal_queue, e->queue_len, e->qnext, e->reached, e->wfree, e->dens);
+                       e->tcount, e->done, e->goal_queue, e->queue_len, e->qnext, e->reached, e->wfree, e->dens, e->rules);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }

@@ -15,6 +15,7 @@ import torch
 from . import _lib, maps
 
 METRIC_KEYS = ("CSR", "ISR", "SoC", "makespan", "ep_length", "avg_agents_density")   # eval_configs/*/*.yaml results_views
+RULE_NO_FOLLOW, RULE_LOWEST_WINS = 1, 2      # include/mapf_gpt_amd.h: MGPT_ENV_RULE_* (the two switchable, RECALLED collision rules)
 
 
 class BatchedEnv:
@@ -68,6 +69,10 @@ class BatchedEnv:
             assert q.dim() == 4 and tuple(q.shape[:2]) == (self.n_inst, self.n_agents) and q.shape[3] == 2
             _lib.check(_lib.lib().mgpt_env_set_lifelong(self._h, _lib.ptr(q), int(q.shape[2]), _lib.stream_ptr()))
             self.lifelong = True
+
+    def set_rules(self, rules=0):
+        """Collision-rule switches (bit mask of RULE_*; 0 = the spec of DESIGN.md section 4)."""
+        _lib.check(_lib.lib().mgpt_env_set_rules(self._h, int(rules)))
 
     def goals_reached(self):
         """int32 [n_inst, n_agents]: arrivals so far (lifelong mode)."""

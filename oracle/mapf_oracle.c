@@ -262,13 +262,18 @@ const uint8_t *orc_gen_hist(const orc_gen *g) { return g->hist; }
  * on_target = "nothing": agents stay on the grid and keep acting.
  * Returns the number of agents standing on their goal after the move.
  * ------------------------------------------------------------------------------------------ */
-int orc_env_step(const uint8_t *grid, int H, int W, int n, int32_t *pos /* n*2, in/out */,
-                 const int32_t *goal, const int32_t *actions)
+/* rules (bit mask; 0 = the spec above).  The two places where the spec rests on RECALLED pogema behaviour (box
+ * under E0) are switchable so that pinning against captured fixtures (tests/golden/make_golden_env.py) is a flag flip:
+ *   ORC_RULE_NO_FOLLOW (1)   a move into a cell that another agent occupies at the START of the step becomes wait, whether or
+ *                            not that agent leaves it (default: following a leaving agent is allowed);
+ *   ORC_RULE_LOWEST_WINS (2) a contested empty cell goes to the lowest-id mover instead of nobody: in rule 3 a mover reverts
+ *                            only if a staying agent or a mover with a smaller id claims its target (default: all revert). */
+int orc_env_step_rules(const uint8_t *grid, int H, int W, int n, int32_t *pos /* n*2, in/out */,
+                       const int32_t *goal, const int32_t *actions, int rules)
 {
     static const int dr[5] = {0, -1, 1, 0, 0}, dc[5] = {0, 0, 0, -1, 1};
     int *tgt = (int *)malloc(sizeof(int) * (size_t)n);
     int *cur = (int *)malloc(sizeof(int) * (size_t)n);
-    int *cnt = (int *)calloc((size_t)H * W, sizeof(int));
     int *who = (int *)malloc(sizeof(int) * (size_t)H * W);
     for (int i = 0; i < H * W; i++) who[i] = -1;
     for (int a = 0; a < n; a++) {
@@ -281,6 +286,7 @@ int orc_env_step(const uint8_t *grid, int H, int W, int n, int32_t *pos /* n*2, 
         int nr = pos[2 * a] + dr[act], nc = pos[2 * a + 1] + dc[act];
         int t = nr * W + nc;
         if (nr < 0 || nr >= H || nc < 0 || nc >= W || grid[t] != 0) t = cur[a];   /* rule 1 */
+        else if ((rules & 1) && who[t] >= 0 && who[t] != a) t = cur[a];            /* ORC_RULE_NO_FOLLOW */
         tgt[a] = t;
     }
     int *swap = (int *)calloc((size_t)n, sizeof(int));
@@ -291,24 +297,35 @@ int orc_env_step(const uint8_t *grid, int H, int W, int n, int32_t *pos /* n*2, 
     }
     for (int a = 0; a < n; a++) if (swap[a]) tgt[a] = cur[a];
     free(swap);
-    for (;;) {                                                 /* rule 3 */
-        for (int a = 0; a < n; a++) cnt[tgt[a]]++;
+    int *nt = (int *)malloc(sizeof(int) * (size_t)n);
+    for (;;) {                                                 /* rule 3 (Jacobi rounds: every test reads the previous round) */
         int changed = 0;
-        for (int a = 0; a < n; a++)
-            if (tgt[a] != cur[a] && cnt[tgt[a]] > 1) changed = 1;
-        int *nt = (int *)malloc(sizeof(int) * (size_t)n);
-        for (int a = 0; a < n; a++) nt[a] = (tgt[a] != cur[a] && cnt[tgt[a]] > 1) ? cur[a] : tgt[a];
-        for (int a = 0; a < n; a++) cnt[tgt[a]] = 0;
+        for (int a = 0; a < n; a++) {
+            nt[a] = tgt[a];
+            if (tgt[a] == cur[a]) continue;
+            int revert = 0;
+            for (int b = 0; b < n && !revert; b++) {
+                if (b == a || tgt[b] != tgt[a]) continue;
+                if (!(rules & 2)) revert = 1;                              /* any other claimant */
+                else revert = (tgt[b] == cur[b]) || (b < a);               /* a stayer, or a mover with a smaller id */
+            }
+            if (revert) { nt[a] = cur[a]; changed = 1; }
+        }
         memcpy(tgt, nt, sizeof(int) * (size_t)n);
-        free(nt);
         if (!changed) break;
     }
+    free(nt);
     int on_goal = 0;
     for (int a = 0; a < n; a++) {
         pos[2 * a] = tgt[a] / W;
         pos[2 * a + 1] = tgt[a] % W;
         if (pos[2 * a] == goal[2 * a] && pos[2 * a + 1] == goal[2 * a + 1]) on_goal++;
     }
-    free(tgt); free(cur); free(cnt); free(who);
+    free(tgt); free(cur); free(who);
     return on_goal;
+}
+
+int orc_env_step(const uint8_t *grid, int H, int W, int n, int32_t *pos, const int32_t *goal, const int32_t *actions)
+{
+    return orc_env_step_rules(grid, H, W, n, pos, goal, actions, 0);
 }

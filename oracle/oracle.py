@@ -54,6 +54,8 @@ def lib():
             getattr(L, f).restype = vp
         L.orc_env_step.argtypes = [u8p, i32, i32, i32, vp, vp, vp]
         L.orc_env_step.restype = i32
+        L.orc_env_step_rules.argtypes = [u8p, i32, i32, i32, vp, vp, vp, i32]
+        L.orc_env_step_rules.restype = i32
         _lib = L
     return _lib
 
@@ -115,13 +117,17 @@ class OracleGenerator:
         return np.frombuffer((ctypes.c_uint8 * (self.n * 5)).from_address(ptr), dtype=np.uint8).reshape(self.n, 5).copy()
 
 
-def env_step(grid, pos, goal, actions):
-    """Our env spec (parity unpinned).  Returns (new_pos int32[n,2], n_on_goal)."""
+RULE_NO_FOLLOW, RULE_LOWEST_WINS = 1, 2          # mapf_oracle.c: the two switchable (RECALLED) collision rules
+
+
+def env_step(grid, pos, goal, actions, rules=0):
+    """Our env spec (parity unpinned; `rules` = bit mask of the switchable collision rules, 0 = the spec).
+    Returns (new_pos int32[n,2], n_on_goal)."""
     g = np.ascontiguousarray(np.asarray(grid) != 0, dtype=np.uint8)
     H, W = g.shape
     p = _i32(pos).reshape(-1, 2).copy()
     gl, a = _i32(goal).reshape(-1, 2), _i32(actions)
-    k = lib().orc_env_step(g.ctypes.data, H, W, p.shape[0], p.ctypes.data, gl.ctypes.data, a.ctypes.data)
+    k = lib().orc_env_step_rules(g.ctypes.data, H, W, p.shape[0], p.ctypes.data, gl.ctypes.data, a.ctypes.data, int(rules))
     return p, int(k)
 
 

@@ -2,7 +2,7 @@
 """Round-2 policy goldens from the REAL reference model (build container only; needs /root/reference).
 
 For every released shape (2M, 6M, 85M) and weight scale (x1, x4: the x4 set mimics trained magnitudes, SURVEY.md
-appendix B) this writes tests/golden/gptbig_<shape>_s<scale>.npz with
+appendix B; x8 for 2M / 6M since round 4: record-only, beyond trained magnitudes) this writes tests/golden/gptbig_<shape>_s<scale>.npz with
     tokens       uint8 [256, 256]   256 REAL observation rows taken from the tokenizer goldens (all five eval maps)
     logits_f32   float32 [256, 67]  mapf_gpt/model.py GPT.forward in fp32               (model.py:167-189)
     logits_f64   float64 [256, 67]  the same module after .double()                      (the accuracy yardstick)
@@ -51,10 +51,13 @@ def main():
     torch.set_num_threads(8)
     rows = real_rows()
     idx = torch.from_numpy(rows.astype(np.int64))
-    shapes = sys.argv[1:] or ["2M", "6M", "85M"]
+    argv = sys.argv[1:]
+    scales_arg = [float(a[2:]) for a in argv if a.startswith("-s")]        # e.g. -s8: only that scale
+    shapes = [a for a in argv if not a.startswith("-s")] or ["2M", "6M", "85M"]
     for name in shapes:
         args = weights.model_args(name)
-        for scale in (1.0, 4.0):
+        # x8 (round 4, 2M / 6M only): maps where the ABSOLUTE 1e-5 bar breaks as logits grow, before real weights arrive
+        for scale in (scales_arg or ((1.0, 4.0, 8.0) if name != "85M" else (1.0, 4.0))):
             sd = weights.synthetic_state_dict(name, seed=0, scale=scale)
             net = GPT(GPTConfig(**args)).eval()
             net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)

@@ -97,3 +97,34 @@ def test_aec_facade_matches_parallel_api():
             steps_seen += 1
     assert steps_seen == 12 and not aec.agents
     assert "metrics" in aec.infos["agent_0"] and aec.infos["agent_0"]["metrics"]["ep_length"] == 12
+
+
+@pytest.mark.parametrize("rules", [1, 2, 3])
+def test_rule_switches_match_the_oracle(rules):
+    """The two switchable (RECALLED) collision rules -- no following of a leaving agent (1), lowest id wins a contested cell (2)
+    -- on the device against the oracle with the same mask, crowded instances, pushes in one direction every third step."""
+    from mapf_gpt_amd.env import BatchedEnv
+    from mapf_gpt_amd.runner import make_instances
+    grid, s_ok, g_ok = maps.load_named("validation-mazes-seed-000")
+    n_inst, n_agents = 3, 70
+    pos, goal = make_instances(grid, n_inst, n_agents, 5, s_ok, g_ok)
+    env = BatchedEnv(grid, n_inst, n_agents, max_episode_steps=64)
+    env.set_rules(rules)
+    env.reset(pos, goal)
+    p, g = pos.numpy().astype(np.int32).copy(), goal.numpy().astype(np.int32)
+    rng = np.random.Generator(np.random.PCG64(rules))
+    differs = False
+    for t in range(30):
+        act = rng.integers(0, 5, (n_inst, n_agents)).astype(np.int32)
+        if t % 3 == 0:
+            act[:] = rng.integers(1, 5)
+        env.step(torch.from_numpy(act).cuda())
+        got = env.sync_state()[0].cpu().numpy().astype(np.int32)
+        for i in range(n_inst):
+            exp, _ = orc.env_step(grid, p[i], g[i], act[i], rules=rules)
+            assert np.array_equal(got[i], exp), f"rules {rules} step {t} instance {i}"
+            differs |= not np.array_equal(exp, orc.env_step(grid, p[i], g[i], act[i])[0])
+            p[i] = exp
+    assert differs, "the mask must change at least one outcome on this scenario"
+    with pytest.raises(RuntimeError):
+        env.set_rules(8)

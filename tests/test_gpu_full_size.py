@@ -26,7 +26,7 @@ def _workload(name):
     return grid, pos, goal, n_inst, n_agents, model
 
 
-@pytest.mark.parametrize("name,precision,tol", [("cfg3", "f16x3", 1e-5), ("cfg4", "f16x3", 1e-5), ("cfg5", "bf16", 1e-1)])
+@pytest.mark.parametrize("name,precision,tol", [("cfg2", "f16x3", 1e-5), ("cfg3", "f16x3", 1e-5), ("cfg4", "f16x3", 1e-5), ("cfg5", "bf16", 1e-1)])
 def test_whole_step_at_full_size(name, precision, tol):
     from mapf_gpt_amd.model import build_model
     from mapf_gpt_amd.runner import BatchedRunner
@@ -36,7 +36,8 @@ def test_whole_step_at_full_size(name, precision, tol):
     if not per_inst:                                   # shared map: the second half replicates the first (arg-max policy below)
         pos[half:] = pos[:half]
         goal[half:] = goal[:half]
-    net = build_model(model, seed=0, max_rows=min(n_inst * n, 4096 if model != "85M" else 1024), precision=precision)
+    # cfg2: the whole 16 384-row step is ONE forward launch, as in bench.py (that launch was never compared with anything)
+    net = build_model(model, seed=0, max_rows=min(n_inst * n, 16384 if name == "cfg2" else (4096 if model != "85M" else 1024)), precision=precision)
     run = BatchedRunner(grids, n_inst, n, net, max_episode_steps=64, seed=0, do_sample=False, precision=precision)
     run.reset(pos, goal)
     sample = [0, n_inst // 3, n_inst - 1] if per_inst else [0, half // 2, half - 1]
@@ -76,12 +77,20 @@ def test_whole_step_at_full_size(name, precision, tol):
             assert np.array_equal(cur[i], exp), f"{name}: env step of instance {i}, step {t}"
             p[i], last[i] = exp, actions[i].copy()
         prev = cur
-    # ---- logits of sampled rows of the last step against the fp32 port ----
-    rows = np.concatenate([tokens[i][:: max(1, n // 4)][:4] for i in sample])
+    # ---- logits of the last step's rows: the forward of ALL rows (the launches the runner itself issues), sampled rows of it
+    #      against the fp32 port, the replicated half against the first half, and a small separate launch against the big one ----
+    all_logits = net.logits_tokens(run.tokens).cpu().numpy().reshape(n_inst, n, 67)
+    assert np.isfinite(all_logits).all()
+    if not per_inst:
+        assert np.array_equal(all_logits[half:2 * half], all_logits[:half]), "replicated instances: logits differ inside one forward"
+    pick = [(i, a) for i in sample for a in list(range(0, n, max(1, n // 4)))[:4]]
+    rows = np.stack([tokens[i][a] for i, a in pick])
     sd, args = weights.synthetic_state_dict(model, seed=0), weights.model_args(model)
     ref = gpt_oracle.forward_logits(sd, args, rows).numpy()
-    got = net.logits_tokens(torch.from_numpy(np.ascontiguousarray(rows)).cuda()).cpu().numpy()
+    got = np.stack([all_logits[i][a] for i, a in pick])
     err = float(np.abs(got - ref).max())
     assert err <= tol, f"{name} {precision}: max |dlogit| = {err:.3e}"
+    small = net.logits_tokens(torch.from_numpy(np.ascontiguousarray(rows)).cuda()).cpu().numpy()
+    assert np.abs(small - got).max() <= (tol if precision == "bf16" else 1e-6), "a row's logits depend on the launch it rides in"
     if precision != "bf16":                              # arg-max actions of those rows are the port's
         assert np.array_equal(got[:, :5].argmax(1), ref[:, :5].argmax(1))

@@ -156,6 +156,25 @@ def test_256_real_rows_within_1e5_of_reference(shape, scale, precision):
         assert e64 <= max(TOL, 1.15 * e_ref), msg
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("shape", ["2M", "6M"])
+def test_x8_weights_break_point_of_the_absolute_bar(shape, precision):
+    """VERDICT r03 item 6 (record-only): x8 synthetic weights (|logits| up to 7 / 10) lie beyond trained magnitudes; there the
+    reference's own fp32 forward is 1.5e-5 (2M) / 6.8e-5 (6M) away from its fp64 run, so the ABSOLUTE 1e-5 bar cannot hold for
+    anyone.  The numbers go to parity_records (test = "x8_break_point"); the only assertion is the class: as close to fp64 as
+    the reference's fp32 run, within a factor of two."""
+    from mapf_gpt_amd.model import build_model
+    g = _big(shape, 8)
+    net = build_model(shape, seed=0, scale=8.0, max_rows=128, precision=precision)
+    logits = net.logits_tokens(torch.from_numpy(g["tokens"]).cuda()).cpu().numpy().astype(np.float64)
+    e_ref = np.abs(g["logits_f32"].astype(np.float64) - g["logits_f64"]).max()
+    e32 = np.abs(logits - g["logits_f32"]).max()
+    e64 = np.abs(logits - g["logits_f64"]).max()
+    record_parity(test="x8_break_point", shape=shape, scale=8, precision=precision, e32=e32, e64=e64, e_ref=e_ref,
+                  max_abs_logit=np.abs(g["logits_f64"]).max(), rows=int(g["tokens"].shape[0]))
+    assert e64 <= 2.0 * e_ref and e32 <= 3.0 * e_ref, f"{shape} x8 {precision}: e32 {e32:.3e} e64 {e64:.3e} e_ref {e_ref:.3e}"
+
+
 @pytest.mark.parametrize("shape", ["2M", "6M"])
 def test_heavy_tailed_weights_x20(shape):
     """Headroom outside the goldens' N(0, 0.02) weights (tools/check_heavy_tails.py, now in the suite): 1 % of every 2-D weight
