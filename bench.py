@@ -186,6 +186,116 @@ def cpu_baseline(map_name, n_agents, model, budget_s=10.0):
             "reference_tokenizer_us_per_agent": ref_tok}
 
 
+class ClockPowerSampler:
+    """Shader clock and socket power of the GPU while the timed region runs (the energy-bound claim of
+    DESIGN section 10 rests on these two numbers, so they ride in the JSON line).  A daemon thread reads the amdgpu hwmon
+    files (freq1_input in Hz, power1_average / power1_input in microwatts) every `period` seconds -- microseconds per sample,
+    no subprocess; where hwmon is absent it falls back to one `rocm-smi --json` call per 0.5 s."""
+
+    def __init__(self, index=0, period=0.02):
+        import glob
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        cards = sorted({os.path.dirname(p) for p in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")})
+        self.freq = self.power = None
+        if cards:
+            d = cards[min(index, len(cards) - 1)]
+            self.freq = os.path.join(d, "freq1_input")
+            for f in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(d, f)):
+                    self.power = os.path.join(d, f)
+                    break
+        self.source = "hwmon" if self.freq else "rocm-smi"
+        self.index = index
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _smi(self):
+        import subprocess
+        try:
+            j = json.loads(subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout)
+            c = j.get(f"card{self.index}") or next(iter(j.values()))
+            f = p = float("nan")
+            for k, v in c.items():
+                if "sclk" in k and "(" in str(v):
+                    f = float(str(v).split("(")[1].split("Mhz")[0])
+                if "Power" in k and "W" in k:
+                    p = float(v)
+            return f, p
+        except Exception:
+            return float("nan"), float("nan")
+
+    def _run(self):
+        t0 = time.perf_counter()
+        while not self._stop.is_set():
+            if self.freq:
+                try:
+                    f = int(open(self.freq).read()) / 1e6
+                    p = int(open(self.power).read()) / 1e6 if self.power else float("nan")
+                except Exception:
+                    f = p = float("nan")
+                self.samples.append((time.perf_counter() - t0, f, p))
+                self._stop.wait(self.period)
+            else:
+                f, p = self._smi()
+                self.samples.append((time.perf_counter() - t0, f, p))
+                self._stop.wait(0.5)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._thread.join(timeout=10)
+
+    def summary(self, log_path=None):
+        f = np.array([x[1] for x in self.samples], dtype=np.float64)
+        p = np.array([x[2] for x in self.samples], dtype=np.float64)
+        f, p = f[np.isfinite(f)], p[np.isfinite(p)]
+        if log_path:
+            os.makedirs(os.path.dirname(log_path) or ".", exist_ok=True)
+            with open(log_path, "w") as fh:
+                fh.write(f"# t_s sclk_MHz socket_power_W -- sampled by bench.py ({self.source}) during the timed region\n")
+                for t, a, b in self.samples:
+                    fh.write(f"{t:.3f} {a:.0f} {b:.0f}\n")
+        if len(f) == 0:
+            return None
+        out = {"sclk_mhz_mean": float(f.mean()), "sclk_mhz_min": float(f.min()), "sclk_mhz_max": float(f.max()), "samples": int(len(f)),
+               "source": self.source, "period_s": self.period if self.source == "hwmon" else 0.5}
+        if len(p):
+            out.update({"socket_power_w_mean": float(p.mean()), "socket_power_w_max": float(p.max())})
+        return out
+
+
+LAST_SUFFIX = "_last"      # prof classes of the last layer's launches (token 255 only: model.py:186), timed apart from the full ones
+
+
+def fold_last(prof):
+    """-> (merged, full_only, last_only): the library times the last layer's shortcut launches under `<class>_last`; `merged`
+    folds them back into their class (what round 3 reported: the reference's flops over ALL launches of the class)."""
+    merged, full, last = {}, {}, {}
+    for k, (ms, n) in prof.items():
+        if k.endswith(LAST_SUFFIX):
+            last[k[:-len(LAST_SUFFIX)]] = (ms, n)
+        else:
+            full[k] = (ms, n)
+    for k in set(full) | set(last):
+        a, b = full.get(k, (0.0, 0)), last.get(k, (0.0, 0))
+        merged[k] = (a[0] + b[0], a[1] + b[1])
+    return merged, full, last
+
+
+def full_launch_frac(dom, full, f_class_dom, rows_per_launch, peak):
+    """The dominant class over its FULL-SIZE launches only: one layer's reference flops for the rows of a launch / the mean
+    duration of those launches (the shortcut launches of the last layer, which `frac` averages in while keeping the
+    reference's flops, are excluded)."""
+    if dom not in full or full[dom][1] == 0:
+        return None
+    ms, n = full[dom]
+    ach = f_class_dom * rows_per_launch / (ms / n * 1e-3) / 1e12
+    return {"frac_full_launch": ach / peak, "achieved_full_launch": ach, "avg_full_launch_ms": ms / n, "full_launches": n}
+
+
 def stream_floor_ms(total_bytes, dev, reps=20):
     """What a launch moving the SAME number of bytes costs with nothing to compute: a device copy of total_bytes / 2 (reads
     half, writes half), torch.cuda events on the current stream.  At cfg4's 45 MB per launch this is what separates "the
@@ -326,7 +436,7 @@ def build_workload(name, precision, rank, world, local_rank, instances=0, use_gr
                 n_agents=n_agents, inst_per_gpu=inst_per_gpu, model=model, max_steps=max_steps, map_name=map_name)
 
 
-def timed_steps(w, steps, warmup, world, use_prof, coll_dev):
+def timed_steps(w, steps, warmup, world, use_prof, coll_dev, sample_clock=None):
     """W untimed warmup steps, then exactly `steps` steps between barrier + synchronize on both sides; max over ranks."""
     from mapf_gpt_amd import _lib
     run, pos, goal, max_steps = w["run"], w["pos"], w["goal"], w["max_steps"]
@@ -350,10 +460,16 @@ def timed_steps(w, steps, warmup, world, use_prof, coll_dev):
         _lib.prof_reset()
         _lib.prof_enable(True)
     barrier()
+    sampler = ClockPowerSampler(index=sample_clock) if sample_clock is not None else None
+    if sampler:
+        sampler.__enter__()
     t0 = time.perf_counter()
     hot_steps(steps)
     barrier()
     dt = time.perf_counter() - t0
+    if sampler:
+        sampler.__exit__()
+        w["clock_power"] = sampler.summary(os.environ.get("MGPT_BENCH_CLOCK_LOG"))
     prof = {}
     if use_prof:
         _lib.prof_enable(False)
@@ -377,21 +493,26 @@ def class_flops(prof, f_class, L_, rows):
     return cls
 
 
-def roofline_of(prof, name, precision, model, rows, steps):
+def roofline_of(prof, name, precision, model, rows, steps, rows_per_launch=None):
     """Dominant kernel class of a timed run (by HIP-event time) -> its roofline dict (algorithmic flops / event time)."""
     from mapf_gpt_amd import weights
     margs = weights.model_args(model)
     _, f_class = flops_per_row(margs)
+    prof, full, last = fold_last(prof)
     cls = class_flops(prof, f_class, margs["n_layer"], rows)
     if not cls:
         return None
     dom = max(cls, key=lambda k: prof[k][0])
     ms, n = prof[dom]
     ach = cls[dom] * steps / (ms * 1e-3) / 1e12
-    return {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
-            "frac": ach / PEAK_TFLOPS[precision], "avg_launch_ms": ms / n, "launches": n,
-            "algorithmic_gflop_per_launch": cls[dom] * steps / n / 1e9, "traffic": traffic_for(f"{name}_{precision}_{dom}"),
-            "kernel_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]}}
+    out = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+           "frac": ach / PEAK_TFLOPS[precision], "avg_launch_ms": ms / n, "launches": n,
+           "algorithmic_gflop_per_launch": cls[dom] * steps / n / 1e9, "traffic": traffic_for(f"{name}_{precision}_{dom}", rows_per_launch),
+           "kernel_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]}}
+    if rows_per_launch:
+        out.update(full_launch_frac(dom, full, cls[dom] / (margs["n_layer"] * rows), rows_per_launch, PEAK_TFLOPS[precision]) or {})
+        out["rows_per_launch"] = rows_per_launch
+    return out
 
 
 def secondary_shard(name, precision, steps, warmup, local_rank, coll_dev, instances=0):
@@ -403,27 +524,28 @@ def secondary_shard(name, precision, steps, warmup, local_rank, coll_dev, instan
                        f"{w['inst_per_gpu']} instances, {w['rows']} rows/step",
            "value": w["n_total"] * w["n_agents"] * steps / dt, "unit": "agent-steps/s", "ms_per_step": 1e3 * dt / steps,
            "steps": steps, "warmup": warmup, "dtype": precision,
-           "roofline": roofline_of(prof, name, precision, w["model"], w["rows"], steps)}
+           "roofline": roofline_of(prof, name, precision, w["model"], w["rows"], steps, w["chunk"])}
     del w
     torch.cuda.empty_cache()
     return out
 
 
+TRAFFIC_FILE = "r04_hbm_traffic.json"
+
+
 def traffic_for(kernel_key, rows_per_launch=None):
-    """HBM bytes per launch from the committed PMC passes (profiles/r03_hbm_traffic.json, falling back to earlier rounds' files):
-    a replay of an earlier rocprofv3 run of this command, NOT a measurement of this run.  An entry that records the launch size
-    it was measured at is only used for launches of that size."""
-    for f in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-        tf = os.path.join(ROOT, "profiles", f)
-        if os.path.exists(tf):
-            t = json.load(open(tf)).get(kernel_key)
-            if t and rows_per_launch is not None and t.get("rows_per_launch", rows_per_launch) != rows_per_launch:
-                return None
-            if t:
-                return {"hbm_bytes_per_launch": t["fetch_corrected_x2"] + t["write"], "fetch_raw": t["fetch_raw"], "write": t["write"],
-                        "measured_in_run": False,
-                        "source": f"profiles/{f} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, FETCH_SIZE x2 gfx950 correction)"}
-    return None
+    """HBM bytes per launch from THIS round's committed PMC passes (profiles/r04_hbm_traffic.json; no fallback to earlier
+    rounds' files -- VERDICT r03: a stale entry is worse than null): a replay of a rocprofv3 run of this command, NOT a
+    measurement of this run.  An entry that records the launch size it was measured at is only used for launches of that size."""
+    tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    if not os.path.exists(tf):
+        return None
+    t = json.load(open(tf)).get(kernel_key)
+    if not t or (rows_per_launch is not None and t.get("rows_per_launch", rows_per_launch) != rows_per_launch):
+        return None
+    return {"hbm_bytes_per_launch": t["fetch_corrected_x2"] + t["write"], "fetch_raw": t["fetch_raw"], "write": t["write"],
+            "measured_in_run": False,
+            "source": f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, FETCH_SIZE x2 gfx950 correction)"}
 
 
 def main():
@@ -478,7 +600,8 @@ def main():
     name = a.workload or ("cfg3" if world == 1 else "cfg4")
     w = build_workload(name, a.precision, rank, world, local_rank, a.instances, chunk_rows=a.chunk_rows)
     use_prof = not a.no_prof
-    dt, prof = timed_steps(w, a.steps, a.warmup, world, use_prof, coll_dev)
+    dt, prof_raw = timed_steps(w, a.steps, a.warmup, world, use_prof, coll_dev, sample_clock=(local_rank if rank == 0 else None))
+    prof, prof_full, prof_last = fold_last(prof_raw)
     metrics = gather_metrics(w["run"].metrics().to(coll_dev), w["n_total"], rank, world)       # the job's one collective
     torch.cuda.synchronize()
 
@@ -512,7 +635,9 @@ def main():
                                    "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": w["chunk"],
                                    "algorithmic_gflop_per_launch": cls[dom] * a.steps / n / 1e9,
                                    "mfma_issue_frac": (3.0 if a.precision == "f16x3" else 1.0) * ach / PEAK_TFLOPS[a.precision],
-                                   "note": "algorithmic flops (reference-executed) / HIP-event time of the class over the timed region"
+                                   **(full_launch_frac(dom, prof_full, cls[dom] / (margs["n_layer"] * rows), w["chunk"], PEAK_TFLOPS[a.precision]) or {}),
+                                   "note": "frac = algorithmic flops (reference-executed, all layers) / HIP-event time of the class over ALL its launches of the timed region, "
+                                           "the last layer's token-255-only launches included; frac_full_launch = one layer's flops of a full launch / the mean duration of the full launches only"
                                            + ("; f16x3 issues 3 fp16 MFMAs per product against the fp16 dense peak: frac counts the reference's flops once, mfma_issue_frac counts the issued ones" if a.precision == "f16x3" else "")}
                 out["roofline_all_classes"] = {k: {"tflops": cls[k] * a.steps / (prof[k][0] * 1e-3) / 1e12,
                                                    "frac": cls[k] * a.steps / (prof[k][0] * 1e-3) / 1e12 / PEAK_TFLOPS[a.precision],
@@ -526,6 +651,9 @@ def main():
                                              "avg_launch_ms": ms / n, "launches": n, "rows_per_launch": rows,
                                              "note": "the workload's own launch (latency-bound when rows_per_launch < 1e5)"}
             out["kernel_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            out["kernel_ms_per_step_last_layer_launches"] = {k: v[0] / a.steps for k, v in prof_last.items()}
+        if w.get("clock_power"):
+            out["clock_power"] = dict(w["clock_power"], note="sampled on this GPU between the two barriers of the timed region (DESIGN section 10: the forward runs at the package power limit)")
         if world == 1 and not a.no_tokenizer_leg:
             # SURVEY 8d asks for the tokenizer's HBM roofline on >= 1e5-row launches: cfg4's own per-GPU launch (65 536 rows on
             # per-instance maps, 128 agents: the KP = 2 path) is the headline tokenizer figure; the 524 288-row leg is secondary
@@ -557,6 +685,11 @@ def main():
             # BASELINE configs[3] and [4]: the per-GPU shards of the two 8-GPU configurations, under this run's clock
             if name != "cfg4":
                 out["secondary"]["cfg4_shard"] = secondary_shard("cfg4", "f16x3", 4, 1, local_rank, coll_dev)
+                c4 = out["secondary"]["cfg4_shard"]
+                # --gpus N > 1 runs cfg4 (its per-GPU shard): a 1 -> 8 curve must start from THIS number, not from cfg3's
+                out["scale_reference"] = {"workload": c4["workload"], "value": c4["value"], "unit": "agent-steps/s", "ms_per_step": c4["ms_per_step"],
+                                          "n_gpus": 1, "dtype": "f16x3",
+                                          "note": "the N = 1 point of the multi-GPU (cfg4) curve; `bench.py --gpus 1 --workload cfg4` reproduces it as the headline"}
             if name != "cfg5":
                 out["secondary"]["cfg5_shard"] = secondary_shard("cfg5", "bf16", 3, 1, local_rank, coll_dev)
         if world == 1 and not a.no_cpu_baseline and name != "cfg4":

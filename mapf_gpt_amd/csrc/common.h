@@ -50,7 +50,9 @@ uint64_t env_generation(const mgpt_env *e);
 enum ProfId {
     P_BFS = 0, P_TOK_UPDATE, P_TOK_NEXT, P_TOKENS, P_ENV_STEP, P_ENV_METRICS,
     P_EMBED, P_LAYERNORM, P_GEMM_QKV, P_ATTN, P_GEMM_PROJ, P_GEMM_FC, P_GEMM_PROJ2, P_MLP_FUSED,
-    P_HEAD, P_SAMPLE, P_PACK, P_LNQKV_FUSED, P_COUNT
+    P_HEAD, P_SAMPLE, P_PACK, P_LNQKV_FUSED,
+    P_ATTN_LAST, P_GEMM_PROJ_LAST, P_MLP_FUSED_LAST,    // the last layer's launches (token 255 only, model.py:186): timed apart from the full ones
+    P_COUNT
 };
 
 // RAII: records start/stop events around a launch when profiling is enabled (no-op otherwise)

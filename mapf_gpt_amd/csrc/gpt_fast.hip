@@ -423,7 +423,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         const int rows_pad = ((rows + 255) / 256) * 256;
         if (attn_block) {
             // ---- LN1 + QKV + attention + out-projection + residual in one kernel: q, k, v, y stay on chip ----
-            ProfScope ps(P_ATTN, s);
+            ProfScope ps(last_short ? P_ATTN_LAST : P_ATTN, s);
             const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 4;   // K, V^T planes + 4 weight packet slots
 #define MGPT_ATTN_BLOCK(CT_, LAST_, EMB_)                                                                                        \
     hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, true, LAST_, EMB_>), dim3((unsigned)rows), dim3(512), lds, s, g->x, \
@@ -436,7 +436,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             MGPT_LAUNCH_CHECK();
         } else if (m->attn256) {
             // ---- LN1 + QKV + attention in one kernel (q, k, v stay on chip) -> y operand planes for the out-projection ----
-            ProfScope ps(P_ATTN, s);
+            ProfScope ps(last_short ? P_ATTN_LAST : P_ATTN, s);
             if (last_short)
                 hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, true>), dim3((unsigned)rows), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
                                    m->attn256_pk[l], m->attn256_inv[l], scale_log2e, m->y_last, (unsigned long long *)nullptr);
@@ -464,7 +464,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         if (!attn_block) {
             const bool ls = last_short && m->pk_gemm;       // only token 255 of every row from here on
             if (!m->attn256) {
-                ProfScope ps(P_ATTN, s);
+                ProfScope ps(ls ? P_ATTN_LAST : P_ATTN, s);
                 const uint16_t *qh = m->qk[0], *ql = m->qk[1], *kh = m->qk[0] + M * C, *kl = (NP == 2) ? m->qk[1] + M * C : nullptr;
                 uint16_t *yh = ls ? m->y_last : m->y[0];
                 if (g->hs == 32)
@@ -484,7 +484,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             a.w_hi = m->proj[l].hi; a.w_lo = m->proj[l].lo; a.out_scale = m->proj[l].inv_scale;
             a.x_out = ls ? m->x_last : g->x; a.stats_out = m->stats; a.x_tiled = m->x_tiled ? 1 : 0;
             if (ls) a.M = rows_pad;
-            ProfScope ps(P_GEMM_PROJ, s);
+            ProfScope ps(ls ? P_GEMM_PROJ_LAST : P_GEMM_PROJ, s);
             if (m->pk_gemm) {
                 a.w_hi = m->proj_pk2[l];
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
@@ -495,7 +495,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         const int64_t mlp_M = last_short ? (int64_t)rows_pad : M;
         if (m->mlp_fused) {
             // ---- whole MLP block in one kernel (hidden stays in registers) ----
-            ProfScope ps(P_MLP_FUSED, s);
+            ProfScope ps(last_short ? P_MLP_FUSED_LAST : P_MLP_FUSED, s);
             if (C == 256) {
                 // persistent: one workgroup per CU walks the 128-token blocks round-robin (results do not depend on the grid)
                 const int n_blocks = (int)(mlp_M / 128);

@@ -23,7 +23,8 @@ static const char *kProfNames[P_COUNT] = {
     "bfs_distance_field", "tok_update_agents", "tok_next_action", "tok_generate_observations",
     "env_step", "env_metrics", "gpt_embed", "gpt_layernorm", "gpt_gemm_qkv", "gpt_attention",
     "gpt_gemm_attn_proj", "gpt_gemm_mlp_fc", "gpt_gemm_mlp_proj", "gpt_mlp_fused", "gpt_head",
-    "gpt_sample", "gpt_pack_weights", "gpt_ln_qkv_fused"};
+    "gpt_sample", "gpt_pack_weights", "gpt_ln_qkv_fused",
+    "gpt_attention_last", "gpt_gemm_attn_proj_last", "gpt_mlp_fused_last"};
 
 struct ProfState {
     std::mutex mu;
