@@ -196,17 +196,23 @@ class ClockPowerSampler:
         import glob
         import threading
         self.period, self.samples, self._stop = period, [], threading.Event()
-        cards = sorted({os.path.dirname(p) for p in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")})
-        self.freq = self.power = None
-        if cards:
-            d = cards[min(index, len(cards) - 1)]
-            self.freq = os.path.join(d, "freq1_input")
-            for f in ("power1_average", "power1_input"):
-                if os.path.exists(os.path.join(d, f)):
-                    self.power = os.path.join(d, f)
-                    break
-        self.source = "hwmon" if self.freq else "rocm-smi"
+        # every amdgpu card of the box is sampled (a 1-GPU lease still lists the node's other cards in sysfs); the reported one is
+        # the card whose PCI address is the HIP device's, else the card that drew the most power during the region
+        self.cards = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")):
+            d = os.path.dirname(f)
+            pw = next((os.path.join(d, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(d, n))), None)
+            bdf = os.path.basename(os.path.realpath(os.path.join(d, "..", "..")))
+            self.cards.append((bdf, f, pw))
+        self.want_bdf = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            self.want_bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pass
+        self.source = "hwmon" if self.cards else "rocm-smi"
         self.index = index
+        self.chosen = None
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     def _smi(self):
@@ -227,17 +233,19 @@ class ClockPowerSampler:
     def _run(self):
         t0 = time.perf_counter()
         while not self._stop.is_set():
-            if self.freq:
-                try:
-                    f = int(open(self.freq).read()) / 1e6
-                    p = int(open(self.power).read()) / 1e6 if self.power else float("nan")
-                except Exception:
-                    f = p = float("nan")
-                self.samples.append((time.perf_counter() - t0, f, p))
+            if self.cards:
+                row = []
+                for _, ff, pf in self.cards:
+                    try:
+                        f = int(open(ff).read()) / 1e6
+                        p = int(open(pf).read()) / 1e6 if pf else float("nan")
+                    except Exception:
+                        f = p = float("nan")
+                    row.append((f, p))
+                self.samples.append((time.perf_counter() - t0, row))
                 self._stop.wait(self.period)
             else:
-                f, p = self._smi()
-                self.samples.append((time.perf_counter() - t0, f, p))
+                self.samples.append((time.perf_counter() - t0, [self._smi()]))
                 self._stop.wait(0.5)
 
     def __enter__(self):
@@ -249,21 +257,34 @@ class ClockPowerSampler:
         self._thread.join(timeout=10)
 
     def summary(self, log_path=None):
-        f = np.array([x[1] for x in self.samples], dtype=np.float64)
-        p = np.array([x[2] for x in self.samples], dtype=np.float64)
-        f, p = f[np.isfinite(f)], p[np.isfinite(p)]
+        if not self.samples:
+            return None
+        n_cards = len(self.samples[0][1])
+        f = np.array([[c[0] for c in row] for _, row in self.samples], dtype=np.float64)      # [samples, cards]
+        p = np.array([[c[1] for c in row] for _, row in self.samples], dtype=np.float64)
+        pick, how = 0, "only card"
+        if n_cards > 1:
+            match = [i for i, (bdf, _, _) in enumerate(self.cards) if bdf == self.want_bdf]
+            if match:
+                pick, how = match[0], f"PCI address {self.want_bdf} of the HIP device"
+            else:
+                pick, how = int(np.nanargmax(np.nan_to_num(np.nanmean(p, axis=0), nan=-1.0))), "card with the highest mean power in the region"
+        self.chosen = pick
         if log_path:
             os.makedirs(os.path.dirname(log_path) or ".", exist_ok=True)
             with open(log_path, "w") as fh:
-                fh.write(f"# t_s sclk_MHz socket_power_W -- sampled by bench.py ({self.source}) during the timed region\n")
-                for t, a, b in self.samples:
+                fh.write(f"# t_s sclk_MHz socket_power_W -- sampled by bench.py ({self.source}, {how}) during the timed region\n")
+                for (t, _), a, b in zip(self.samples, f[:, pick], p[:, pick]):
                     fh.write(f"{t:.3f} {a:.0f} {b:.0f}\n")
-        if len(f) == 0:
+        fs, ps = f[:, pick], p[:, pick]
+        fs, ps = fs[np.isfinite(fs)], ps[np.isfinite(ps)]
+        if len(fs) == 0:
             return None
-        out = {"sclk_mhz_mean": float(f.mean()), "sclk_mhz_min": float(f.min()), "sclk_mhz_max": float(f.max()), "samples": int(len(f)),
-               "source": self.source, "period_s": self.period if self.source == "hwmon" else 0.5}
-        if len(p):
-            out.update({"socket_power_w_mean": float(p.mean()), "socket_power_w_max": float(p.max())})
+        out = {"sclk_mhz_mean": float(fs.mean()), "sclk_mhz_min": float(fs.min()), "sclk_mhz_max": float(fs.max()), "samples": int(len(fs)),
+               "source": self.source, "card": (self.cards[pick][0] if self.cards else None), "card_chosen_by": how, "cards_sampled": n_cards,
+               "period_s": self.period if self.source == "hwmon" else 0.5}
+        if len(ps):
+            out.update({"socket_power_w_mean": float(ps.mean()), "socket_power_w_max": float(ps.max())})
         return out
 
 
@@ -481,14 +502,17 @@ def timed_steps(w, steps, warmup, world, use_prof, coll_dev, sample_clock=None):
     return dt, prof
 
 
-def class_flops(prof, f_class, L_, rows):
+def class_flops(prof, f_class, L_, rows, full=None):
     """Algorithmic (reference-executed) flops per step of every kernel class that actually ran; fused classes carry the
-    flops of everything they absorbed.  The last-layer shortcut is OUR saving: flops stay the reference's."""
-    cls = {k: f_class[k] * L_ * rows for k in f_class if k in prof}
-    if "gpt_attention" in prof:
-        if "gpt_gemm_qkv" not in prof and "gpt_ln_qkv_fused" not in prof:
+    flops of everything they absorbed.  The last-layer shortcut is OUR saving: flops stay the reference's.  `full` = the
+    classes that ran FULL-SIZE launches (fold_last): a class that only ran for the last layer's token-255 rows (the 6M shape's
+    out-projection since attn256o_kernel absorbed it everywhere else) has been absorbed, its flops belong to the attention class."""
+    ran = full if full is not None else prof
+    cls = {k: f_class[k] * L_ * rows for k in f_class if k in prof and k in ran}
+    if "gpt_attention" in cls:
+        if "gpt_gemm_qkv" not in ran and "gpt_ln_qkv_fused" not in ran:
             cls["gpt_attention"] += f_class["gpt_gemm_qkv"] * L_ * rows
-        if "gpt_gemm_attn_proj" not in prof:
+        if "gpt_gemm_attn_proj" not in ran:
             cls["gpt_attention"] += f_class["gpt_gemm_attn_proj"] * L_ * rows
     return cls
 
@@ -499,7 +523,7 @@ def roofline_of(prof, name, precision, model, rows, steps, rows_per_launch=None)
     margs = weights.model_args(model)
     _, f_class = flops_per_row(margs)
     prof, full, last = fold_last(prof)
-    cls = class_flops(prof, f_class, margs["n_layer"], rows)
+    cls = class_flops(prof, f_class, margs["n_layer"], rows, full)
     if not cls:
         return None
     dom = max(cls, key=lambda k: prof[k][0])
@@ -624,7 +648,7 @@ def main():
                        "unreachable offline, so the 1e-5 logit parity of the f16x3 mode is established on synthetic weights "
                        "(tests/test_gpu_gpt.py) and not on the released ones"}
         if prof:
-            cls = class_flops(prof, f_class, margs["n_layer"], rows)
+            cls = class_flops(prof, f_class, margs["n_layer"], rows, prof_full)
             if cls:
                 dom = max(cls, key=lambda k: prof[k][0])
                 ms, n = prof[dom]

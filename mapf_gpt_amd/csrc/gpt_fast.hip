@@ -13,6 +13,7 @@
 #include "gpt_kernels_fast.h"
 #include "gpt_kernels_c256.h"
 #include "gpt_kernels_c256p.h"
+#include "gpt_kernels_c256a.h"
 
 using namespace mgpt;
 
@@ -20,6 +21,12 @@ namespace {
 
 constexpr int kT = 256;
 constexpr int kV = MGPT_VOCAB;
+// A/B builds (tools/ab_lib.sh): -DMGPT_AB_ATTN_UNFUSED keeps round 3's attn256_kernel + packed-GEMM out-projection
+#ifdef MGPT_AB_ATTN_UNFUSED
+constexpr bool kAttn256Fused = false;
+#else
+constexpr bool kAttn256Fused = true;
+#endif
 
 struct PlaneSet {           // one weight matrix [N][K] as 16-bit planes
     uint16_t *hi = nullptr, *lo = nullptr;
@@ -50,6 +57,9 @@ struct ModeState {          // one precision mode
     // C = 256, head size 32 (6M): attn256_kernel's c_attn stream in consumption order, per layer
     std::vector<uint16_t *> attn256_pk;
     bool attn256 = false;
+    // attn256o_kernel (whole attention block, persistent): c_attn + c_proj stream per layer, and the per-workgroup spill slab
+    std::vector<uint16_t *> attn256o_pk;
+    unsigned char *attn256o_spill = nullptr;
     // register-resident LN+QKV (C = 64 / 160): per layer [tile][k-step][plane][lane][8] of c_attn.weight
     std::vector<uint16_t *> qkv_pk;
     bool qkv_fused = false;
@@ -184,6 +194,21 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                    nullptr, g->params + lo.attn_w, g->params + lo.ln1, m->attn256_pk[l], sc);
                 MGPT_LAUNCH_CHECK();
             }
+            {   // the whole attention block in one persistent kernel: 48 steps of c_attn * ln_1 followed by 16 steps of c_proj
+                const size_t n16o = (size_t)fastk::kA256oPeriod * 8 * NP * 512;
+                m->attn256o_pk.assign(g->L, nullptr);
+                for (int l = 0; l < g->L; l++) {
+                    MGPT_HIP(hipMalloc(&m->attn256o_pk[l], n16o * sizeof(uint16_t)));
+                    const LayerOff &lo = g->layers[l];
+                    ProfScope ps(P_PACK, nullptr);
+                    hipLaunchKernelGGL((fastk::pack_attn256o_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)fastk::kA256oPeriod * 8 * 64, 256)), dim3(256), 0,
+                                       nullptr, g->params + lo.attn_w, g->params + lo.ln1, g->params + lo.proj_w, m->attn256o_pk[l],
+                                       1.0f / m->attn256_inv[l], 1.0f / m->proj[l].inv_scale);
+                    MGPT_LAUNCH_CHECK();
+                }
+                MGPT_HIP(hipMalloc(&m->attn256o_spill, (size_t)m->n_cu * 8 * 14 * NP * 1024));
+                MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256o_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
+            }
             MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256_kernel<T, NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
             MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256_kernel<T, NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
         }
@@ -306,6 +331,8 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     for (auto *p : m->mlp256_pk) (void)hipFree(p);
     for (auto *p : m->mlp256_lut) (void)hipFree(p);
     for (auto *p : m->attn256_pk) (void)hipFree(p);
+    for (auto *p : m->attn256o_pk) (void)hipFree(p);
+    (void)hipFree(m->attn256o_spill);
     (void)hipFree(m->gelu_lut);
     for (auto *p : m->qkv_pk) (void)hipFree(p);
     for (auto *p : m->proj_pk) (void)hipFree(p);
@@ -421,6 +448,8 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         // last layer: only token 255 is needed downstream (model.py:186) -> compact buffer, MLP and head on `rows` tokens
         const bool last_short = (attn_block || m->pk_gemm) && l == g->L - 1;
         const int rows_pad = ((rows + 255) / 256) * 256;
+        // 6M shape, every layer but the last: attn256o_kernel does the out-projection and the residual add itself
+        const bool proj_fused = m->attn256 && !last_short && kAttn256Fused;
         if (attn_block) {
             // ---- LN1 + QKV + attention + out-projection + residual in one kernel: q, k, v, y stay on chip ----
             ProfScope ps(last_short ? P_ATTN_LAST : P_ATTN, s);
@@ -433,6 +462,13 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, false); else if (emb) MGPT_ATTN_BLOCK(5, false, true); else MGPT_ATTN_BLOCK(5, false, false); }
             else { if (last_short) MGPT_ATTN_BLOCK(2, true, false); else if (emb) MGPT_ATTN_BLOCK(2, false, true); else MGPT_ATTN_BLOCK(2, false, false); }
 #undef MGPT_ATTN_BLOCK
+            MGPT_LAUNCH_CHECK();
+        } else if (m->attn256 && proj_fused) {
+            // ---- the whole attention block (LN1, QKV, attention, out-projection, residual) in one persistent kernel: q, k, v, y stay on chip ----
+            ProfScope ps(P_ATTN, s);
+            hipLaunchKernelGGL((fastk::attn256o_kernel<T, NP>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
+                               m->attn256o_pk[l], m->attn256_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn256o_spill, rows,
+                               (unsigned long long *)nullptr);
             MGPT_LAUNCH_CHECK();
         } else if (m->attn256) {
             // ---- LN1 + QKV + attention in one kernel (q, k, v stay on chip) -> y operand planes for the out-projection ----
@@ -461,7 +497,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             a.N = C; a.o_hi = m->vt[0]; a.o_lo = m->vt[1];
             if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_VT>(a, C, s)) != MGPT_OK) return rc;
         }
-        if (!attn_block) {
+        if (!attn_block && !proj_fused) {
             const bool ls = last_short && m->pk_gemm;       // only token 255 of every row from here on
             if (!m->attn256) {
                 ProfScope ps(ls ? P_ATTN_LAST : P_ATTN, s);

@@ -1,0 +1,539 @@
+// gpt_kernels_c256a.h -- the whole attention block for n_embd = 256, 8 heads of 32 (MAPF-GPT-6M), gfx950:
+//     x <- x + c_proj(attention(LayerNorm(x)))                         (model.py:46-72, 102)
+// one kernel, PERSISTENT (grid = number of CUs, a workgroup walks rows b = blockIdx.x, + gridDim.x, ...), and the attention
+// output never exists as a matrix in HBM: round 3's attn256_kernel wrote the y operand planes (1 KiB per token) and an
+// HBM-bound packed GEMM (6.2 TB/s, 1.78 ms per 12 288-row launch) read them back together with x.
+//
+// Why the out-projection is a TAIL and not part of the head loop: a wave owns 32 tokens; the q|k|v projections need the
+// normalised rows as operand planes for every head (xn: 128 registers), the out-projection needs a 32 x 256 fp32 accumulator
+// block (128 registers).  256 tokens x (xn + accumulators) = 512 KiB = the CU's whole register file: the two cannot be live
+// together.  So a head's output tile (32 tokens x 32 d, 16 registers as split planes -- exactly the B operand of its c_proj
+// slice) is parked in a per-workgroup spill slab (224 KiB, written once and read once by the SAME wave, L2-resident: the slab
+// is re-used row after row), and after the last head -- xn is dead -- the planes of heads 0-6 come back into xn's registers
+// (requested before the last head's attention phase, which hides the round trip) and head 7's go there directly.  The
+// out-projection then has the shape of the q|k projection steps: operand planes of K = 256 in registers, c_proj.weight
+// through the same LDS ring, two output tiles per 4 stream steps on two accumulator chains, residual rows of those tiles
+// requested 4 steps before they are needed, x + acc / scale stored tile pair by tile pair.
+//
+// Stream: c_attn.weight * ln_1.weight (48 steps, as attn256_kernel) followed by c_proj.weight (16 steps), CYCLIC with period 64
+// steps per row through the 5-slot ring: the next row's first steps land during the tail.  All vector-memory operations of
+// the row loop are inline asm with hand-counted s_waitcnt (they retire in issue order: "at most N outstanding" with N = the
+// operations issued after the one needed is exact; a smaller N is always safe).  Per wave and row, in issue order:
+//     32 x-row loads | per head: 6 x 2 ring pieces, 4 spill stores (heads 0-6) | 28 spill loads | tail pseudo-head t = 0..3:
+//     [t = 0: 4 L2-prefetch touches of the next row] 8 residual loads, 4 x 2 ring pieces, 8 stores
+// Numerics: the same products and the same fp16 split of y as attn256_kernel + gemm_pk_kernel<EPI_RESID> (y in true units,
+// c_proj pre-scaled by a power of two, fp32 accumulation over k = head-major d); results per token do not depend on the grid.
+#pragma once
+#include "gpt_kernels_c256p.h"
+
+namespace mgpt {
+namespace fastk {
+
+constexpr int kA256oProjSteps = 16;
+constexpr int kA256oPeriod = 8 * kA256StepsPerHead + kA256oProjSteps;     // stream steps per row
+constexpr int kA256oSpillPerWg = 8 * 14 * 2 * 1024;                        // bytes (split mode): 8 waves x 14 k-steps x 2 planes x 1 KiB
+
+template <class T, int NP>
+__global__ __launch_bounds__(256) void pack_attn256o_kernel(const float *__restrict__ w_attn, const float *__restrict__ gain,
+                                                            const float *__restrict__ w_proj, uint16_t *__restrict__ out,
+                                                            float scale_a, float scale_p)
+{
+    constexpr int C = 256, NH = 8, QKV = NH * kA256StepsPerHead;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (period step, pair, lane)
+    if (gid >= (int64_t)kA256oPeriod * 8 * 64) return;
+    const int lane = (int)(gid & 63), ms = (int)((gid >> 6) & 7), G = (int)(gid >> 9);
+    const int i = lane & 31, h = lane >> 5;
+    float v[8];
+    if (G < QKV) {                                                        // as pack_attn256_kernel
+        const int head = G / kA256StepsPerHead, st = G - head * kA256StepsPerHead;
+        int which, ks;
+        if (st < 4) { which = ms & 1; ks = 4 * st + (ms >> 1); }
+        else { which = 2; ks = 8 * (st - 4) + ms; }
+        const float *row = w_attn + (size_t)(which * C + head * 32 + i) * C;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int g = 8 * (ks & 1) + e;
+            const int col = 32 * (ks >> 1) + (g & 3) + 8 * (g >> 2) + 4 * h;
+            v[e] = row[col] * gain[col] * scale_a;
+        }
+    } else {                                                              // c_proj: pseudo-head t = output tiles 2t, 2t+1; step j = k-steps 4j .. 4j+3
+        const int s = G - QKV, t = s >> 2, j = s & 3;
+        const int which = ms & 1, ks = 4 * j + (ms >> 1);
+        const float *row = w_proj + (size_t)(32 * (2 * t + which) + i) * C;   // c_proj.weight row = output feature (model.py:31, 70)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int g = 8 * (ks & 1) + e;
+            const int col = 32 * (ks >> 1) + (g & 3) + 8 * (g >> 2) + 4 * h;  // input feature = head (ks >> 1), d = tau(g, h): the y planes' k-slot order
+            v[e] = row[col] * scale_p;
+        }
+    }
+    u32x2 h0, l0, h1, l1;
+    split4<T, NP>(v, h0, l0);
+    split4<T, NP>(v + 4, h1, l1);
+    u32x4 hi, lo;
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+    uint16_t *dst = out + (((size_t)G * 8 + ms) * NP) * 512 + (size_t)lane * 8;
+    *reinterpret_cast<u32x4 *>(dst) = hi;
+    if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
+}
+
+// STAMPS (tools/bench_probes/check_attn256o.hip only): wave 0 of every workgroup leaves {entry cycles, entry 100-MHz ticks, cycles in
+// the prologues, in the q|k|v projection steps, in the attention phases (k / v barrier included), in the tail steps, in the
+// tail epilogues, exit ticks} summed over its rows.
+template <class T, int NP, int STAMPS = 0>
+__global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv_scale,
+                                                          float scale_log2e, float inv_proj, unsigned char *__restrict__ spill,
+                                                          int n_rows, unsigned long long *stamps = nullptr)
+{
+    constexpr int C = 256, KS = 16, NH = 8, HS = 32, NW = 8;
+    static_assert(NP == 2 || NP == 1, "planes");
+    constexpr int MS = 8;                                  // fragment pairs per step
+    constexpr int STEP = MS * NP * 1024;
+    constexpr int NSLOT = 5;
+    constexpr int PW = MS * NP / NW;                       // direct-to-LDS loads per wave per step (2 in the split mode)
+    constexpr int KROW = 80, VROW = 528;                   // padded LDS rows (bytes): conflict-free b128 reads
+    constexpr int NSPILL = 2 * NP;                         // spill stores per head per wave (16 bytes per lane each)
+    constexpr int NYLD = 14 * NP;                          // spill loads per row per wave
+    constexpr int NPF = 4;                                 // L2-prefetch touches of the next row per wave
+    static_assert(PW >= 1, "a wave moves at least one piece per step");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [NSLOT][STEP] ring | sK [NP][256][KROW] | sV [NP][32][VROW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tok0 = wave * 32;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(size_t)smem + lane16;
+    const unsigned sK = (unsigned)(size_t)smem + NSLOT * STEP, sV = sK + NP * kT * KROW;
+    // Global addresses are (wave-uniform 64-bit base in SGPRs) + (one of two 32-bit lane offsets) + immediate: 64-bit per-lane
+    // pointers for the x rows, the spill slab and the stream cost ~40 registers that this kernel does not have (first build:
+    // hipcc hoisted them out of the row loop and spilled 242 dwords per lane to scratch)
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(wave * PW) * 1024;   // wave-uniform
+    unsigned char *sp_wave = spill + ((size_t)blockIdx.x * NW + wave) * (size_t)(14 * NP * 1024);              // this wave's slab (uniform)
+    const unsigned xoff = (unsigned)(r * 32 + h * 16);     // chunk-major x: lane (r, h) owns the 16 bytes at r * 32 + h * 16 of every 1-KiB chunk
+    const int n_mine = n_rows > (int)blockIdx.x ? (n_rows - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = 0;
+    auto phase = [&](int i) {                              // STAMPS: cycles since the previous call go to ts[i]
+        if constexpr (STAMPS != 0) { const unsigned long long t = __builtin_readcyclecounter(); ts[i] += t - t_mark; t_mark = t; }
+    };
+    if constexpr (STAMPS != 0) { ts[0] = __builtin_readcyclecounter(); ts[1] = wall_clock64(); t_mark = ts[0]; }
+    if (n_mine == 0) return;
+
+    // ---- ring: slot of stream step G = G % 5, carried in two scalars; the source is cyclic with period 64 ----
+    int r_issue = 0;
+    int slot_cur = 0, slot_prev = NSLOT - 1;
+    unsigned cur_addr = 0, nxt_addr = 0;
+    auto issue = [&](int slot) {
+        const unsigned char *src = wbase + (size_t)r_issue * STEP;
+        unsigned char *dst = smem + (size_t)slot * STEP + (size_t)(wave * PW) * 1024;
+#pragma unroll
+        for (int i = 0; i < PW; i++) dma_piece(src + lane16, dst, std::integral_constant<int, 0>{}, i);
+        r_issue = r_issue + 1 == kA256oPeriod ? 0 : r_issue + 1;
+    };
+#pragma unroll
+    for (int G = 0; G < NSLOT - 1; G++) issue(G);
+    // top of stream step G, part 1: this wave's pieces of step G + 1 have landed (PENDING = vector-memory operations of this wave
+    // issued after them), every LDS access of the step before is done, barrier
+    auto sync_wait = [&](auto pending_c) {
+        vm_wait<decltype(pending_c)::value>();
+        __builtin_amdgcn_s_barrier();
+    };
+    // part 2: the slot of step G - 1 is refilled with step G + 4; addresses of this step's and the next step's slots
+    auto sync_issue = [&]() {
+        issue(slot_prev);
+        const int slot_next = slot_cur + 1 == NSLOT ? 0 : slot_cur + 1;
+        cur_addr = lds0 + (unsigned)slot_cur * STEP;
+        nxt_addr = lds0 + (unsigned)slot_next * STEP;
+        slot_prev = slot_cur;
+        slot_cur = slot_next;
+    };
+    u32x4 wb[2][2][2];                                     // weight fragments: [set][pair 2c / 2c+1][plane]
+    auto lds_frag = [&](unsigned addr, auto off_c, u32x4 &dst) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off_c)::value) : "memory");
+    };
+    auto lds_pair = [&](unsigned slot_addr, auto ms_c, u32x4 (&dst)[2]) {
+        constexpr int ms = decltype(ms_c)::value;
+        lds_frag(slot_addr, std::integral_constant<int, ms * NP * 1024>{}, dst[0]);
+        if (NP == 2) lds_frag(slot_addr, std::integral_constant<int, (ms * NP + 1) * 1024>{}, dst[1]);
+        else dst[1] = dst[0];
+    };
+    // chunk c of a step uses pairs 2c, 2c+1 (set c & 1), requested one chunk earlier; it requests the pairs of the next chunk
+    // (chunk 3: the first pairs of the NEXT step, whose slot has landed -- the stream is cyclic, there always is one; NEXT = false
+    //  only in a row's last step: the first pairs of the next row's first step are requested after its prologue instead, so that
+    //  their 16 registers are not live across the 128-register LayerNorm)
+    auto chunk_begin = [&](auto c_c, auto next_c) {
+        constexpr int c = decltype(c_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (c < 3) { lds_pair(cur_addr, std::integral_constant<int, 2 * c + 2>{}, wb[(c + 1) & 1][0]); lds_pair(cur_addr, std::integral_constant<int, 2 * c + 3>{}, wb[(c + 1) & 1][1]); }
+        else if (decltype(next_c)::value) { lds_pair(nxt_addr, std::integral_constant<int, 0>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, 1>{}, wb[0][1]); }
+        __builtin_amdgcn_sched_barrier(0);                 // the requests stay in front of this chunk's MFMAs
+    };
+    auto pin6 = [&]() {
+#pragma unroll
+        for (int n = 0; n < (NP == 2 ? 6 : 2); n++) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto pack_octet = [&](const f32x16 &v, int m, u32x4 (&dst)[2]) {
+#pragma unroll
+        for (int wd = 0; wd < 4; wd++) {
+            unsigned a, b2;
+            split2p<T, NP>(v[8 * m + 2 * wd], v[8 * m + 2 * wd + 1], a, b2);
+            dst[0][wd] = a; dst[1][wd] = b2;
+        }
+    };
+    // (LDS writes and global accesses below are written out with immediate offsets: no per-offset address registers.
+    //  Global accesses use the saddr form: vdata, voffset (32-bit lane offset), saddr (uniform base), immediate.
+    //  s_nop after a store: a store of more than 8 bytes reads its data registers after issue, and hipcc cannot see through asm.)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto half_swap = [&](float v, float &lower, float &upper) {
+        lower = v; upper = v;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lower), "+v"(upper));
+    };
+    auto other_half_max = [&](float v) { float a, b2; half_swap(v, a, b2); return fmaxf(a, b2); };
+    auto other_half_sum = [&](float v) { float a, b2; half_swap(v, a, b2); return a + b2; };
+    const float sc2 = scale_log2e * inv_scale * inv_scale; // softmax exponent scale for q.k in weight-scaled units
+    const unsigned kw_addr = sK + (unsigned)(tok0 + r) * KROW + h * 16;                   // this lane's key row (write side)
+    const unsigned vw_addr = sV + (unsigned)r * VROW + (unsigned)wave * 64 + h * 16;      // this lane's d row, this wave's keys
+    const unsigned kr_addr = sK + (unsigned)r * KROW + h * 16;                            // read side: key r of a tile
+    const unsigned vr_addr = sV + (unsigned)r * VROW + h * 16;                            // read side: d = r
+
+    u32x4 xn[KS][2];                                       // operand planes: LayerNorm(x) during the heads, y during the tail
+
+    // one q|k-shaped step: k-steps 4j .. 4j+3 of the planes in xn against pairs (2c, 2c+1) -> two accumulator chains
+    // (qa / ka live at kernel scope and are captured directly: handed to this lambda as reference PARAMETERS, hipcc sank the
+    //  whole second chain -- 48 MFMAs -- behind the four steps and kept its 128 registers of weight fragments alive in scratch)
+    f32x16 qa, ka;
+    auto step_pair = [&](auto j_c, auto pending_c, auto &&after_barrier, auto next_c) {
+        constexpr int j = decltype(j_c)::value;
+        sync_wait(pending_c);
+        after_barrier();
+        sync_issue();
+        auto chunk = [&](auto c_c) {
+            constexpr int c = decltype(c_c)::value;
+            chunk_begin(c_c, next_c);
+            constexpr int ks = 4 * j + c;
+            if (NP == 2) {
+                qa = T::mfma(wb[c & 1][0][1], xn[ks][0], qa); ka = T::mfma(wb[c & 1][1][1], xn[ks][0], ka);
+                qa = T::mfma(wb[c & 1][0][0], xn[ks][1], qa); ka = T::mfma(wb[c & 1][1][0], xn[ks][1], ka);
+            }
+            qa = T::mfma(wb[c & 1][0][0], xn[ks][0], qa); ka = T::mfma(wb[c & 1][1][0], xn[ks][0], ka);
+            pin6();
+            asm volatile("" : "+v"(qa), "+v"(ka));         // both chains are pinned to this chunk (hipcc otherwise sinks a whole chain -- and
+                                                           // the weight fragments it needs -- to the chain's first use, see above)
+        };
+        chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
+    };
+    auto nothing = [&]() {};
+    // every step but a row's first finds its first pairs requested by chunk 3 of the step before; a row's first step reads them after
+    // the prologue from nxt_addr (the slot of the step about to run).  For the very first row that is slot 0: all priming pieces
+    // landed for every wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    nxt_addr = lds0;
+    using P4 = std::integral_constant<int, PW * (NSLOT - 3)>;               // only the pieces of the two later steps may be in flight
+    using P4S = std::integral_constant<int, PW * (NSLOT - 3) + NSPILL>;     // ... and the spill stores of the head before
+
+#pragma unroll 1
+    for (int k = 0; k < n_mine; k++) {
+        const int64_t b = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
+        // x is chunk-major (xt_off): [32-token tile][C / 8 chunks][32 tokens][8 floats]; lane (r, h) owns the 16 bytes at
+        // r * 32 + h * 16 of every 1-KiB chunk, so that a wave's load or store is 1 KiB contiguous
+        unsigned char *xw = reinterpret_cast<unsigned char *>(x + (b * kT + tok0) * C);   // this wave's 32-token tile (uniform), 32 KiB
+        // ---- prologue: this lane's token, LayerNorm (two-pass, model.py:19-20), operand planes ----
+        {
+            f32x4 xr[32];                                  // xr[4 j + gq] = features 32 j + 8 gq + 4 h .. + 3 (chunk 4 j + gq)
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const unsigned char *xq = xw + (i >> 2) * 4096;   // (13-bit immediate offsets: four chunks per base)
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr[i]) : "v"(xoff), "s"(xq), "n"((i & 3) * 1024) : "memory");
+            }
+            // everything older (ring pieces, the previous row's last stores) retires with them: vmcnt(0)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) : : "memory");
+            asm volatile("" : "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]), "+v"(xr[15]));
+            asm volatile("" : "+v"(xr[16]), "+v"(xr[17]), "+v"(xr[18]), "+v"(xr[19]), "+v"(xr[20]), "+v"(xr[21]), "+v"(xr[22]), "+v"(xr[23]));
+            asm volatile("" : "+v"(xr[24]), "+v"(xr[25]), "+v"(xr[26]), "+v"(xr[27]), "+v"(xr[28]), "+v"(xr[29]), "+v"(xr[30]), "+v"(xr[31]));
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; i++) s += (xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3]);
+            s = other_half_sum(s);
+            const float mean = s * (1.0f / (float)C);
+            float qv = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float d = xr[i][e] - mean; xr[i][e] = d; qv = fmaf(d, d, qv); }   // (the centred row is kept)
+            qv = other_half_sum(qv);
+            const float rstd = rsqrtf(qv * (1.0f / (float)C) + 1e-5f);
+            // (x - mean) * rstd; ln_1.weight is part of the weight stream (pack_attn256o_kernel)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                float v0[4], v1[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { v0[e] = xr[2 * ks][e] * rstd; v1[e] = xr[2 * ks + 1][e] * rstd; }
+                u32x2 h0, l0, h1, l1;
+                split4p<T, NP>(v0, h0, l0);
+                split4p<T, NP>(v1, h1, l1);
+                xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
+                xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
+            }
+        }
+        // the first pairs of the row's first step (its slot landed for every wave before the barrier of the step before)
+        lds_pair(nxt_addr, I0{}, wb[0][0]);
+        lds_pair(nxt_addr, I1{}, wb[0][1]);
+        phase(2);
+
+        // ---- one head; LASTH (head 7): its output planes stay in registers (xn[14], xn[15]) and the planes of heads 0-6 are
+        //      requested from the spill slab before its attention phase (xn is dead after the v steps) ----
+        auto head = [&](int hd, auto last_c) {
+            constexpr bool LASTH = decltype(last_c)::value;
+            // ---- steps 0-3: q and k tiles (swapped: lane = token, registers = d) ----
+#pragma unroll
+            for (int g = 0; g < 16; g++) { qa[g] = 0.f; ka[g] = 0.f; }
+            // (steps 0-2: the spill stores of the head before are younger than the pieces waited for; for head 0 nothing is in
+            //  flight at all after the prologue's vmcnt(0), so the larger count is safe there too)
+            step_pair(I0{}, P4S{}, nothing, std::true_type{});
+            step_pair(I1{}, P4S{}, nothing, std::true_type{});
+            step_pair(I2{}, P4S{}, nothing, std::true_type{});
+            step_pair(I3{}, P4{}, nothing, std::true_type{});
+            u32x4 qf[2][2];                                // B operand of S^T = K Q^T: [k-step][plane]
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) pack_octet(qa, ks, qf[ks]);
+            {   // k -> sK[pl][key = tok0 + r][octet ks][half h]   (all waves passed this head's step syncs: the head before -- or the
+                // row before -- has finished its attention everywhere)
+                u32x4 kp[2][2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) pack_octet(ka, ks, kp[ks]);
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++)
+                        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(kw_addr), "v"(kp[ks][pl]), "n"(pl * kT * KROW + ks * 32) : "memory");
+            }
+            // ---- steps 4-5: v tile (natural: lane = d, registers = tokens), two chains ----
+            f32x16 va, vb;
+#pragma unroll
+            for (int g = 0; g < 16; g++) { va[g] = 0.f; vb[g] = 0.f; }
+            auto step_v = [&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                sync_wait(P4{});
+                sync_issue();
+                auto chunk = [&](auto c_c) {
+                    constexpr int c = decltype(c_c)::value;
+                    chunk_begin(c_c, std::true_type{});
+                    constexpr int ks = 8 * j + 2 * c;
+                    if (NP == 2) {
+                        va = T::mfma(xn[ks][1], wb[c & 1][0][0], va); vb = T::mfma(xn[ks + 1][1], wb[c & 1][1][0], vb);
+                        va = T::mfma(xn[ks][0], wb[c & 1][0][1], va); vb = T::mfma(xn[ks + 1][0], wb[c & 1][1][1], vb);
+                    }
+                    va = T::mfma(xn[ks][0], wb[c & 1][0][0], va); vb = T::mfma(xn[ks + 1][0], wb[c & 1][1][0], vb);
+                    pin6();
+                    asm volatile("" : "+v"(va), "+v"(vb));
+                };
+                chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
+            };
+            step_v(I0{});
+            step_v(I1{});
+            if constexpr (LASTH) {
+                // the normalised rows are dead: their registers take the y planes of heads 0-6 back (this wave's own stores,
+                // complete since the step waits above; L2-resident).  Needed at the first tail step, one attention phase away.
+#pragma unroll
+                for (int ks = 0; ks < 14; ks++)
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++) {
+                        const unsigned char *p = sp_wave + (size_t)(ks >> 1) * (size_t)(2 * NP * 1024);   // head ks >> 1 (13-bit immediate offsets)
+                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xn[ks][pl]) : "v"(lane16), "s"(p), "n"(((ks & 1) * NP + pl) * 1024) : "memory");
+                    }
+            }
+            {   // v^T -> sV[pl][d = r][(wave, octet mm)][half h]
+#pragma unroll
+                for (int g = 0; g < 16; g++) va[g] += vb[g];
+                u32x4 vp[2][2];
+#pragma unroll
+                for (int mm = 0; mm < 2; mm++) pack_octet(va, mm, vp[mm]);
+#pragma unroll
+                for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++)
+                        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(vw_addr), "v"(vp[mm][pl]), "n"(pl * HS * VROW + mm * 32) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            phase(3);
+            __builtin_amdgcn_s_barrier();                  // k, v^T of the head complete
+
+            // ---- attention of this wave's 32 queries against the 256 keys of the head ----
+            f32x16 o;
+#pragma unroll
+            for (int g = 0; g < 16; g++) o[g] = 0.f;
+            float m_run = -INFINITY, l_run = 0.f;
+            {
+                u32x4 kf[2][2], vf[2][2];
+                auto load_k = [&](int kt) {                // K fragments of key tile kt: [k-step][plane]
+                    const unsigned a = kr_addr + (unsigned)kt * (32 * KROW);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][0]) : "v"(a) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(kf[1][0]) : "v"(a) : "memory");
+                    if (NP == 2) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][1]) : "v"(a), "n"(kT * KROW) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][1]) : "v"(a), "n"(kT * KROW + 32) : "memory");
+                    } else { kf[0][1] = kf[0][0]; kf[1][1] = kf[1][0]; }
+                };
+                load_k(0);
+#pragma unroll 1
+                for (int kt = 0; kt < kT / 32; kt++) {
+                    f32x16 sc;
+#pragma unroll
+                    for (int g = 0; g < 16; g++) sc[g] = 0.f;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) sc = mma<T, NP>(kf[ks], qf[ks], sc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // V^T fragments of this tile, then K of the next one (both land during the softmax arithmetic)
+                    {
+                        const unsigned a = vr_addr + (unsigned)kt * 64;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[0][0]) : "v"(a) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(vf[1][0]) : "v"(a) : "memory");
+                        if (NP == 2) {
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[0][1]) : "v"(a), "n"(HS * VROW) : "memory");
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[1][1]) : "v"(a), "n"(HS * VROW + 32) : "memory");
+                        } else { vf[0][1] = vf[0][0]; vf[1][1] = vf[1][0]; }
+                    }
+                    if (kt + 1 < kT / 32) load_k(kt + 1);
+                    // sc[g] = S[query r][key 32 kt + tau(g, h)]  (times 1/inv_scale^2)
+                    float mx = sc[0];
+#pragma unroll
+                    for (int g = 1; g < 16; g++) mx = fmaxf(mx, sc[g]);
+                    mx = other_half_max(mx);
+                    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {        // some query's running max moved: rescale (wave-uniform branch)
+                        const float m_new = fmaxf(m_run, mx);
+                        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
+                        l_run *= alpha;
+#pragma unroll
+                        for (int g = 0; g < 16; g++) o[g] *= alpha;
+                        m_run = m_new;
+                    }
+                    const float nm = -m_run * sc2;
+                    float psum = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        sc[g] = __builtin_amdgcn_exp2f(fmaf(sc[g], sc2, nm));
+                        psum += sc[g];
+                    }
+                    l_run += other_half_sum(psum);
+                    u32x4 pf[2][2];
+#pragma unroll
+                    for (int mm = 0; mm < 2; mm++) pack_octet(sc, mm, pf[mm]);
+                    if (kt + 1 < kT / 32) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NP) : "memory");   // v^T fragments landed, K of the next tile may fly
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mm = 0; mm < 2; mm++) o = mma<T, NP>(vf[mm], pf[mm], o);
+                }
+            }
+            // ---- y planes of the head: o[g] = O[query r][d = tau(g, h)] / l, times the v projection's weight scale: register
+            //      octet kk = k-step 2 hd + kk of the out-projection's B operand ----
+            {
+                const float inv = inv_scale / l_run;
+#pragma unroll
+                for (int g = 0; g < 16; g++) o[g] *= inv;
+                if constexpr (LASTH) {
+                    pack_octet(o, 0, xn[14]);
+                    pack_octet(o, 1, xn[15]);
+                } else {
+                    u32x4 yp[2][2];
+                    pack_octet(o, 0, yp[0]);
+                    pack_octet(o, 1, yp[1]);
+                    unsigned char *p = sp_wave + (size_t)hd * (size_t)(2 * NP * 1024);
+#pragma unroll
+                    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                        for (int pl = 0; pl < NP; pl++)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(lane16), "v"(yp[kk][pl]), "s"(p), "n"((kk * NP + pl) * 1024) : "memory");
+                }
+            }
+            phase(4);
+        };
+#pragma unroll 1
+        for (int hd = 0; hd < NH - 1; hd++) head(hd, std::false_type{});
+        head(NH - 1, std::true_type{});
+
+        // ---- tail: x <- x + y c_proj^T.  Pseudo-head t = output tiles 2t, 2t+1 (features 64 t .. 64 t + 63) over K = 256 in
+        //      four q|k-shaped steps; the residual rows of the two tiles are requested at its first step ----
+        const int64_t b_next = (k + 1 < n_mine) ? b + gridDim.x : b;      // (always a valid row: the touches are counted below)
+        const unsigned char *pf_base = reinterpret_cast<const unsigned char *>(x + (b_next * kT + tok0) * C);   // (uniform)
+        auto tail = [&](int t, auto first_c, auto last_c) {
+            constexpr bool FIRST = decltype(first_c)::value, LASTT = decltype(last_c)::value;
+#pragma unroll
+            for (int g = 0; g < 16; g++) { qa[g] = 0.f; ka[g] = 0.f; }
+            f32x4 xs[2][4];                                // residual pieces of the two tiles: [tile][gq]
+            float touch[NPF] = {0.f, 0.f, 0.f, 0.f};       // destinations of the prefetch touches: live until the loads have retired
+            unsigned char *xp = xw + (size_t)t * 8192;     // tile 2t: chunks 8t .. 8t+3, tile 2t+1: chunks 8t+4 .. 8t+7 (+4 KiB)
+            constexpr int OTHERS = 8 + (FIRST ? NPF : 0);  // vector-memory operations of this pseudo-head's first step besides ring pieces
+            auto requests = [&]() {
+                if constexpr (FIRST) {
+                    // touch the next row's 32 KiB of this wave (one dword per 128-byte line): the prologue's loads then come from L2 /
+                    // the memory-side cache instead of queueing behind every other CU's row burst
+                    unsigned loff = lane16;                // one 128-byte line per lane; recomputed here (as a row-loop invariant hipcc kept it
+                    asm volatile("" : "+v"(loff));         //  in scratch and reloaded it behind a vmcnt(0) that drained the ring)
+                    loff <<= 3;
+#pragma unroll
+                    for (int i = 0; i < NPF; i++)
+                        asm volatile("global_load_dword %0, %1, %2" : "=v"(touch[i]) : "v"(loff), "s"(pf_base + (size_t)i * 8192) : "memory");
+                }
+#pragma unroll
+                for (int w2 = 0; w2 < 2; w2++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++)
+                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xs[w2][gq]) : "v"(xoff), "s"(xp + w2 * 4096), "n"(gq * 1024) : "memory");
+            };
+            // step 0: pieces waited for are followed by 2 x PW pieces and [FIRST: the 28 spill loads | else: the 8 stores of the pseudo-head before]
+            step_pair(I0{}, std::integral_constant<int, 2 * PW + (FIRST ? NYLD : 8)>{}, requests, std::true_type{});
+            step_pair(I1{}, std::integral_constant<int, 2 * PW + 8 + OTHERS>{}, nothing, std::true_type{});
+            step_pair(I2{}, std::integral_constant<int, 2 * PW + 8 + OTHERS>{}, nothing, std::true_type{});
+            step_pair(I3{}, P4{}, nothing, std::integral_constant<bool, !LASTT>{});
+            phase(5);
+            // ---- epilogue of the two tiles: x + acc / scale (the residual loads are older than this pseudo-head's ring pieces) ----
+            asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[0][2]), "+v"(xs[0][3]), "+v"(xs[1][0]), "+v"(xs[1][1]), "+v"(xs[1][2]), "+v"(xs[1][3])
+                         : [n] "n"(4 * PW) : "memory");
+            if constexpr (FIRST) asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));   // (retired: older than the residual loads)
+#pragma unroll
+            for (int w2 = 0; w2 < 2; w2++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = fmaf((w2 == 0 ? qa : ka)[4 * gq + e], inv_proj, xs[w2][gq][e]);
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(xoff), "v"(v), "s"(xp + w2 * 4096), "n"(gq * 1024) : "memory");
+                }
+            phase(6);
+        };
+        // the planes of heads 0-6 must have landed before the first tail MFMA reads them.  Everything in flight here -- three steps
+        // of ring pieces and the 28 spill loads -- was issued at least one attention phase ago, so vmcnt(0) costs nothing and makes
+        // the first pseudo-head's step waits trivially safe.
+        {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0][0]), "+v"(xn[0][1]), "+v"(xn[1][0]), "+v"(xn[1][1]), "+v"(xn[2][0]), "+v"(xn[2][1]), "+v"(xn[3][0]), "+v"(xn[3][1]),
+                         "+v"(xn[4][0]), "+v"(xn[4][1]), "+v"(xn[5][0]), "+v"(xn[5][1]), "+v"(xn[6][0]), "+v"(xn[6][1]) : : "memory");
+            asm volatile("" : "+v"(xn[7][0]), "+v"(xn[7][1]), "+v"(xn[8][0]), "+v"(xn[8][1]), "+v"(xn[9][0]), "+v"(xn[9][1]), "+v"(xn[10][0]), "+v"(xn[10][1]),
+                         "+v"(xn[11][0]), "+v"(xn[11][1]), "+v"(xn[12][0]), "+v"(xn[12][1]), "+v"(xn[13][0]), "+v"(xn[13][1]));
+        }
+        tail(0, std::true_type{}, std::false_type{});
+#pragma unroll 1
+        for (int t = 1; t < 3; t++) tail(t, std::false_type{}, std::false_type{});
+        tail(3, std::false_type{}, std::true_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no direct-to-LDS load may outlive the workgroup
+    if constexpr (STAMPS != 0) {
+        if (tid == 0) {
+            ts[7] = wall_clock64();
+#pragma unroll
+            for (int i = 0; i < 8; i++) stamps[(size_t)blockIdx.x * 8 + i] = ts[i];
+        }
+    }
+}
+
+}  // namespace fastk
+}  // namespace mgpt
