@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void pack_attn256o_kernel(const float *__restr
 
 // STAMPS (tools/bench_probes/check_attn256o.hip only): wave 0 of every workgroup leaves {entry cycles, entry 100-MHz ticks, cycles in
 // the prologues, in the q|k|v projection steps, in the attention phases (k / v barrier included), in the tail steps, in the
-// tail epilogues, exit ticks} summed over its rows.
+// tail epilogues, exit ticks} summed over its rows.  STAMPS == 2: waves 0 and 4 leave the step-phase cycles (sphase below).
 template <class T, int NP, int STAMPS = 0>
 __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv_scale,
                                                           float scale_log2e, float inv_proj, unsigned char *__restrict__ spill,
@@ -114,8 +114,14 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
     const unsigned xoff = (unsigned)(r * 32 + h * 16);     // chunk-major x: lane (r, h) owns the 16 bytes at r * 32 + h * 16 of every 1-KiB chunk
     const int n_mine = n_rows > (int)blockIdx.x ? (n_rows - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = 0;
-    auto phase = [&](int i) {                              // STAMPS: cycles since the previous call go to ts[i]
-        if constexpr (STAMPS != 0) { const unsigned long long t = __builtin_readcyclecounter(); ts[i] += t - t_mark; t_mark = t; }
+    auto phase = [&](int i) {                              // STAMPS == 1: cycles since the previous call go to ts[i]
+        if constexpr (STAMPS == 1) { const unsigned long long t = __builtin_readcyclecounter(); ts[i] += t - t_mark; t_mark = t; }
+    };
+    // STAMPS == 2, waves 0 AND 4: ts[2] / ts[4] = wait + barrier + piece issue / the four chunks of the q|k-shaped steps (projection
+    // steps 0-3 of every head and the 16 tail steps: 48 per row), ts[3] / ts[5] = the same of the v steps (16 per row)
+    auto smark = [&]() { if constexpr (STAMPS == 2) t_mark = __builtin_readcyclecounter(); };
+    auto sphase = [&](int i) {
+        if constexpr (STAMPS == 2) { const unsigned long long t = __builtin_readcyclecounter(); ts[i] += t - t_mark; t_mark = t; }
     };
     if constexpr (STAMPS != 0) { ts[0] = __builtin_readcyclecounter(); ts[1] = wall_clock64(); t_mark = ts[0]; }
     if (n_mine == 0) return;
@@ -197,10 +203,9 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
     auto other_half_max = [&](float v) { float a, b2; half_swap(v, a, b2); return fmaxf(a, b2); };
     auto other_half_sum = [&](float v) { float a, b2; half_swap(v, a, b2); return a + b2; };
     const float sc2 = scale_log2e * inv_scale * inv_scale; // softmax exponent scale for q.k in weight-scaled units
-    const unsigned kw_addr = sK + (unsigned)(tok0 + r) * KROW + h * 16;                   // this lane's key row (write side)
-    const unsigned vw_addr = sV + (unsigned)r * VROW + (unsigned)wave * 64 + h * 16;      // this lane's d row, this wave's keys
-    const unsigned kr_addr = sK + (unsigned)r * KROW + h * 16;                            // read side: key r of a tile
-    const unsigned vr_addr = sV + (unsigned)r * VROW + h * 16;                            // read side: d = r
+    // (the four K / V^T lane addresses are recomputed at the top of every head from lane16 through an opaque copy: as row-loop
+    //  invariants they cost four registers that this kernel does not have -- one variant of it kept one in scratch, and the
+    //  reload put a compiler vmcnt(0), which drains the ring, in front of every attention phase)
 
     u32x4 xn[KS][2];                                       // operand planes: LayerNorm(x) during the heads, y during the tail
 
@@ -210,9 +215,11 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
     f32x16 qa, ka;
     auto step_pair = [&](auto j_c, auto pending_c, auto &&after_barrier, auto next_c) {
         constexpr int j = decltype(j_c)::value;
+        smark();
         sync_wait(pending_c);
         after_barrier();
         sync_issue();
+        sphase(2);
         auto chunk = [&](auto c_c) {
             constexpr int c = decltype(c_c)::value;
             chunk_begin(c_c, next_c);
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                                                            // the weight fragments it needs -- to the chain's first use, see above)
         };
         chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
+        sphase(4);
     };
     auto nothing = [&]() {};
     // every step but a row's first finds its first pairs requested by chunk 3 of the step before; a row's first step reads them after
@@ -291,6 +299,13 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
         //      requested from the spill slab before its attention phase (xn is dead after the v steps) ----
         auto head = [&](int hd, auto last_c) {
             constexpr bool LASTH = decltype(last_c)::value;
+            unsigned l16 = lane16;
+            asm volatile("" : "+v"(l16));
+            const unsigned rr = (l16 >> 4) & 31u, hh = l16 >> 9;                                   // r, h of this lane
+            const unsigned kr_addr = sK + rr * KROW + hh * 16;                                    // read side: key r of a tile
+            const unsigned vr_addr = sV + rr * VROW + hh * 16;                                    // read side: d = r
+            const unsigned kw_addr = kr_addr + (unsigned)tok0 * KROW;                             // this lane's key row (write side)
+            const unsigned vw_addr = vr_addr + (unsigned)wave * 64;                               // this lane's d row, this wave's keys
             // ---- steps 0-3: q and k tiles (swapped: lane = token, registers = d) ----
 #pragma unroll
             for (int g = 0; g < 16; g++) { qa[g] = 0.f; ka[g] = 0.f; }
@@ -320,8 +335,10 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
             for (int g = 0; g < 16; g++) { va[g] = 0.f; vb[g] = 0.f; }
             auto step_v = [&](auto j_c) {
                 constexpr int j = decltype(j_c)::value;
+                smark();
                 sync_wait(P4{});
                 sync_issue();
+                sphase(3);
                 auto chunk = [&](auto c_c) {
                     constexpr int c = decltype(c_c)::value;
                     chunk_begin(c_c, std::true_type{});
@@ -335,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                     asm volatile("" : "+v"(va), "+v"(vb));
                 };
                 chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
+                sphase(5);
             };
             step_v(I0{});
             step_v(I1{});
@@ -527,10 +545,10 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no direct-to-LDS load may outlive the workgroup
     if constexpr (STAMPS != 0) {
-        if (tid == 0) {
+        if (lane == 0 && (wave == 0 || (STAMPS == 2 && wave == 4))) {
             ts[7] = wall_clock64();
 #pragma unroll
-            for (int i = 0; i < 8; i++) stamps[(size_t)blockIdx.x * 8 + i] = ts[i];
+            for (int i = 0; i < 8; i++) stamps[((size_t)blockIdx.x * (STAMPS == 2 ? 2 : 1) + (wave >> 2)) * 8 + i] = ts[i];
         }
     }
 }

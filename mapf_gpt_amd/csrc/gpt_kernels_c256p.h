@@ -118,6 +118,8 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave < 4;                        // wave-uniform
+    // (round 4: s_setprio for the consumers -- the longer chain of a step -- makes the kernel 3.6 % SLOWER, 57.6 -> 59.7 ms per cfg3
+    //  step at priority 1 or 3; for the producers it changes nothing: oldest-first issue, i.e. the producers ahead, is what works)
     const int pair = wave & 3;
     const int r = lane & 31, h = lane >> 5;
     const unsigned lane16 = (unsigned)lane * 16u;

@@ -814,6 +814,8 @@ extern "C" int mgpt_tokenizer_generate_observations(mgpt_tokenizer *t, uint8_t *
     const int kpp = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 8 ? 8 : kp <= 16 ? 16 : 32;
     // rows per wavefront: 16 (more bytes in flight, records staged once per 64 rows) when the launch still fills the GPU
     const bool big = (int64_t)t->n_inst * cdiv(t->n_agents, 64) >= 4096;
+    // (round 4, tools/tok_cfg4_time.py: 8 rows per wavefront -- every wave resident in ONE generation on cfg4's 65 536-row launch --
+    //  is not faster, 22.9 vs 21.2 us: the kernel is instruction-issue bound, ~15.5 us per 65 536 rows of 128 agents + ~5.5 us fixed)
     const int apb = big ? 64 : 16;
     const int chunks = cdiv(t->n_agents, apb);
     const size_t smem = kLutBytes + (size_t)apb * 16 + (size_t)t->n_agents * 16 + (size_t)kpp * 64 * 4 + 4 * kRowImage +

@@ -17,6 +17,7 @@ static float gauss(uint64_t &st)
 }
 int main(int argc, char **argv)
 {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int rows = argc > 1 ? atoi(argv[1]) : 12288;
     const size_t M = (size_t)rows * 256;
     int dev = 0; hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
@@ -74,5 +75,21 @@ int main(int argc, char **argv)
            grid, rows_per_wg, tot / grid / rows_per_wg, pro / grid / rows_per_wg, qkv / grid / rows_per_wg, qkv / grid / rows_per_wg / 8,
            att / grid / rows_per_wg, att / grid / rows_per_wg / 8, tl / grid / rows_per_wg, tl / grid / rows_per_wg / 16, ep / grid / rows_per_wg,
            tot / rt / 10.0);
+    {   // STAMPS == 2: where a q|k-shaped step's cycles go (projection steps 0-3 of every head + the 16 tail steps = 48 per row), waves 0 and 4
+        auto k2 = &attn256o_kernel<F16T, 2, 2>;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        unsigned long long *st2; hipMalloc(&st2, (size_t)grid * 128);
+        k2<<<grid, 512, lds>>>(x, ws, isa, sl2, isp * 1e-3f, spill, rows, st2);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> g((size_t)grid * 16);
+        hipMemcpy(g.data(), st2, g.size() * 8, hipMemcpyDeviceToHost);
+        for (int w = 0; w < 2; w++) {
+            double a[8] = {0};
+            for (int b = 0; b < grid; b++) for (int i = 2; i < 7; i++) a[i] += (double)g[((size_t)b * 2 + w) * 8 + i];
+            const double steps = (double)grid * rows_per_wg * 48;
+            printf("step phases, wave %d: q|k-shaped steps (48 per row): wait + barrier + piece issue %.0f, four chunks %.0f | v steps (16 per row): %.0f, %.0f  [%s]\n",
+                   4 * w, a[2] / steps, a[4] / steps, a[3] / steps * 3, a[5] / steps * 3, hipGetErrorString(hipGetLastError()));
+        }
+    }
     return 0;
 }
