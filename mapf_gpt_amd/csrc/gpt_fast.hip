@@ -28,6 +28,10 @@ constexpr bool kAttn256Fused = false;
 constexpr bool kAttn256Fused = true;
 #endif
 
+// rows up to which the C = 64 / 160 attention block runs head-parallel: beyond ~164 rows of 5 heads the (row, head) workgroups
+// need more rounds on 256 CUs than one workgroup per row takes (25 us against 80 us per workgroup, profiles/r02_cfg1_step_trace.txt)
+constexpr int kSmallRows = 128;
+
 struct PlaneSet {           // one weight matrix [N][K] as 16-bit planes
     uint16_t *hi = nullptr, *lo = nullptr;
     float inv_scale = 1.f;
@@ -70,6 +74,9 @@ struct ModeState {          // one precision mode
     float *x_head = nullptr;                   // x_tiled: the last-token rows in plain row-major order for the head kernel
     bool x_tiled = false;                      // residual stream chunk-major (fastk::xt_off): the C = 256 kernels
     uint16_t *y_last = nullptr;                // packed-GEMM path: attention output of token 255 of every row, PK planes [rows_pad][C]
+    // small launches of the register-resident path (rows <= kSmallRows: one environment, BASELINE cfg1): attn_block_kernel<HP> runs one
+    // workgroup per (row, head) and leaves the heads' c_proj contributions here, [n_head][kSmallRows * 256 * C] fp32 in x's layout
+    float *head_parts = nullptr;
     // PK GEMM path (C % 256 == 0: 6M, 85M): weights as MFMA-fragment streams, activations produced in the same layout
     bool pk_gemm = false;
     std::vector<uint16_t *> attn_pk2, proj_pk2, fc_pk2, proj2_pk2;   // [row tile][k-step][plane][lane][8]
@@ -227,7 +234,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         }
         const int pkt = (int)(frags * NP * 1024 * 3) + fastk::kGeluLutN * 8;
 #define MGPT_MLP_ATTR(CT_, NW_) \
-    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, CT_, NW_>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt))
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, CT_, NW_, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt)); \
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, CT_, NW_, CT_>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt))
         if (C == 160) { MGPT_MLP_ATTR(5, 8); MGPT_MLP_ATTR(5, 4); MGPT_MLP_ATTR(5, 2); }
         else { MGPT_MLP_ATTR(2, 8); MGPT_MLP_ATTR(2, 4); MGPT_MLP_ATTR(2, 2); }
 #undef MGPT_MLP_ATTR
@@ -255,12 +263,15 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             }
             // attn_block_kernel's dynamic LDS limit is a per-device function attribute: set it for this model's device
             const int lds = (int)((size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 4);
-#define MGPT_ATTN_LDS(CT_, LAST_, EMB_)                                                                                      \
-    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, CT_, true, LAST_, EMB_>), \
+#define MGPT_ATTN_LDS(CT_, LAST_, EMB_, HP_)                                                                                      \
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_block_kernel<T, NP, CT_, true, LAST_, EMB_, HP_>), \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds))
-            if (C == 160) { MGPT_ATTN_LDS(5, false, false); MGPT_ATTN_LDS(5, true, false); MGPT_ATTN_LDS(5, false, true); }
-            else { MGPT_ATTN_LDS(2, false, false); MGPT_ATTN_LDS(2, true, false); MGPT_ATTN_LDS(2, false, true); }
+            if (C == 160) { MGPT_ATTN_LDS(5, false, false, false); MGPT_ATTN_LDS(5, true, false, false); MGPT_ATTN_LDS(5, false, true, false);
+                            MGPT_ATTN_LDS(5, false, false, true); MGPT_ATTN_LDS(5, true, false, true); }
+            else { MGPT_ATTN_LDS(2, false, false, false); MGPT_ATTN_LDS(2, true, false, false); MGPT_ATTN_LDS(2, false, true, false);
+                   MGPT_ATTN_LDS(2, false, false, true); MGPT_ATTN_LDS(2, true, false, true); }
 #undef MGPT_ATTN_LDS
+            if (m->mlp_fused) MGPT_HIP(hipMalloc(&m->head_parts, (size_t)g->nh * kSmallRows * kT * C * sizeof(float)));
         }
     }
     m->pk_gemm = (C == 256 || C == 512 || C == 768 || C == 1024);
@@ -342,6 +353,7 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     (void)hipFree(m->x_last);
     (void)hipFree(m->x_head);
     (void)hipFree(m->y_last);
+    (void)hipFree(m->head_parts);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
 }
@@ -421,8 +433,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     int rc;
     // register-resident path (C = 64, 160; head size 32): a layer is attn_block_kernel + mlp_fused_kernel
     const bool attn_block = m->qkv_fused && g->hs == 32 && m->mlp_fused;
+    // small launch: the heads of a row run on different CUs (attn_block_kernel<HP>), their partial sums are folded by the next kernel
+    const bool head_par = attn_block && rows <= kSmallRows && m->head_parts != nullptr;
+    const int64_t part_stride = (int64_t)kSmallRows * kT * C;
     // the first attention block forms x = wte[token] + wpe[position] itself (no embedding kernel, no first read of x)
-    const bool embed_fused = attn_block && g->L > 1;
+    const bool embed_fused = attn_block && g->L > 1 && !head_par;
     if (m->x_tiled && !embed_fused) {
         ProfScope ps(P_EMBED, s);
         hipLaunchKernelGGL(fastk::embed_tiled_kernel, dim3((unsigned)(M / 32)), dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, C);
@@ -454,15 +469,24 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             // ---- LN1 + QKV + attention + out-projection + residual in one kernel: q, k, v, y stay on chip ----
             ProfScope ps(last_short ? P_ATTN_LAST : P_ATTN, s);
             const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 4;   // K, V^T planes + 4 weight packet slots
-#define MGPT_ATTN_BLOCK(CT_, LAST_, EMB_)                                                                                        \
-    hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, true, LAST_, EMB_>), dim3((unsigned)rows), dim3(512), lds, s, g->x, \
-                       P + lo.ln1, m->qkv_pk[l], m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e, m->proj_pk[l],     \
-                       m->proj[l].inv_scale, m->stats, m->x_last, d_tokens, P + g->off_wte, P + g->off_wpe)
+#define MGPT_ATTN_BLOCK(CT_, LAST_, EMB_, HP_)                                                                                              \
+    hipLaunchKernelGGL((fastk::attn_block_kernel<T, NP, CT_, true, LAST_, EMB_, HP_>), dim3((unsigned)(HP_ ? rows * g->nh : rows)), dim3(512), \
+                       lds, s, g->x, P + lo.ln1, m->qkv_pk[l], m->attn[l].inv_scale, m->y[0], m->y[1], g->nh, scale_log2e, m->proj_pk[l],     \
+                       m->proj[l].inv_scale, m->stats, m->x_last, d_tokens, P + g->off_wte, P + g->off_wpe, m->head_parts, part_stride)
             const bool emb = embed_fused && l == 0;
-            if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, false); else if (emb) MGPT_ATTN_BLOCK(5, false, true); else MGPT_ATTN_BLOCK(5, false, false); }
-            else { if (last_short) MGPT_ATTN_BLOCK(2, true, false); else if (emb) MGPT_ATTN_BLOCK(2, false, true); else MGPT_ATTN_BLOCK(2, false, false); }
+            if (head_par) {
+                if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, false, true); else MGPT_ATTN_BLOCK(5, false, false, true); }
+                else { if (last_short) MGPT_ATTN_BLOCK(2, true, false, true); else MGPT_ATTN_BLOCK(2, false, false, true); }
+            } else if (C == 160) { if (last_short) MGPT_ATTN_BLOCK(5, true, false, false); else if (emb) MGPT_ATTN_BLOCK(5, false, true, false); else MGPT_ATTN_BLOCK(5, false, false, false); }
+            else { if (last_short) MGPT_ATTN_BLOCK(2, true, false, false); else if (emb) MGPT_ATTN_BLOCK(2, false, true, false); else MGPT_ATTN_BLOCK(2, false, false, false); }
 #undef MGPT_ATTN_BLOCK
             MGPT_LAUNCH_CHECK();
+            if (head_par && last_short) {
+                // new row of token 255 = its residual row + the heads' contributions (compact partial sums), padding rows zero
+                hipLaunchKernelGGL(fastk::gather_last_kernel, dim3((unsigned)cdiv64((int64_t)rows_pad * (C / 4), 256)), dim3(256), 0, s, g->x, m->x_last, rows,
+                                   rows_pad, C, 1, m->head_parts, g->nh, part_stride);
+                MGPT_LAUNCH_CHECK();
+            }
         } else if (m->attn256 && proj_fused) {
             // ---- the whole attention block (LN1, QKV, attention, out-projection, residual) in one persistent kernel: q, k, v, y stay on chip ----
             ProfScope ps(P_ATTN, s);
@@ -545,13 +569,20 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                 const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 3 + fastk::kGeluLutN * 8;
                 // 32 tokens per wave whatever the block size: small launches (cfg1: 32 rows = 32 blocks of 256 tokens) take
                 // fewer waves per block so that the tokens spread over more CUs; results do not depend on the choice
-#define MGPT_MLP(CT_, NW_)                                                                                                           \
-    hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, CT_, NW_>), dim3((unsigned)(mlp_M / (32 * NW_))), dim3(64 * NW_), lds, s, mlp_x, \
-                       P + lo.ln2, m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M, m->gelu_lut)
+#define MGPT_MLP_(CT_, NW_, NF_)                                                                                                     \
+    hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, CT_, NW_, NF_>), dim3((unsigned)(mlp_M / (32 * NW_))), dim3(64 * NW_), lds, s, mlp_x, \
+                       P + lo.ln2, m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M, m->gelu_lut, \
+                       m->head_parts, part_stride)
+#define MGPT_MLP(CT_, NW_) do { if (fold_parts) MGPT_MLP_(CT_, NW_, CT_); else MGPT_MLP_(CT_, NW_, 0); } while (0)
+                // (one wave per workgroup -- 256 workgroups for cfg1's 8192 tokens -- is slower: 63 us per launch against 52, round 4)
                 const int nw = (mlp_M >= (int64_t)256 * m->n_cu) ? 8 : (mlp_M >= (int64_t)128 * m->n_cu ? 4 : 2);
+                // (the heads' partial sums = n_head buffers, and n_head == C / 32 for the shapes of this path;
+                //  the last layer's compact rows were folded by gather_last_kernel)
+                const bool fold_parts = head_par && !last_short;
                 if (C == 160) { if (nw == 8) MGPT_MLP(5, 8); else if (nw == 4) MGPT_MLP(5, 4); else MGPT_MLP(5, 2); }
                 else { if (nw == 8) MGPT_MLP(2, 8); else if (nw == 4) MGPT_MLP(2, 4); else MGPT_MLP(2, 2); }
 #undef MGPT_MLP
+#undef MGPT_MLP_
             }
             MGPT_LAUNCH_CHECK();
             continue;

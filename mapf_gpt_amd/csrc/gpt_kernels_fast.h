@@ -209,8 +209,11 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
 // padding rows up to rows_pad (they go through the compact GEMMs and the MLP and must stay finite whatever ran before)
 // (tiled: both x and x_last are chunk-major, xt_off below)
 __device__ __forceinline__ int64_t xt_off(int64_t m, int n, int C);
+// fold (small launches): n_fold compact partial sums (the last-token contributions of a head-parallel attn_block_kernel<LAST>, in
+// x_last's own layout, fold_stride floats apart) are added in index order
 __global__ __launch_bounds__(256) void gather_last_kernel(const float *__restrict__ x, float *__restrict__ x_last, int rows,
-                                                          int rows_pad, int C, int tiled)
+                                                          int rows_pad, int C, int tiled, const float *__restrict__ fold = nullptr,
+                                                          int n_fold = 0, int64_t fold_stride = 0)
 {
     const int c4n = C >> 2;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -218,8 +221,12 @@ __global__ __launch_bounds__(256) void gather_last_kernel(const float *__restric
     const int b = (int)(i / c4n), c4 = (int)(i - (int64_t)b * c4n);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int64_t m = (int64_t)b * kT + kT - 1;
-    if (b < rows) v = *reinterpret_cast<const f32x4 *>(x + (tiled ? xt_off(m, 4 * c4, C) : m * C + 4 * c4));
-    *reinterpret_cast<f32x4 *>(x_last + (tiled ? xt_off(b, 4 * c4, C) : (int64_t)b * C + 4 * c4)) = v;
+    const int64_t o = tiled ? xt_off(b, 4 * c4, C) : (int64_t)b * C + 4 * c4;
+    if (b < rows) {
+        v = *reinterpret_cast<const f32x4 *>(x + (tiled ? xt_off(m, 4 * c4, C) : m * C + 4 * c4));
+        for (int p = 0; p < n_fold; p++) v += *reinterpret_cast<const f32x4 *>(fold + (size_t)p * fold_stride + o);
+    }
+    *reinterpret_cast<f32x4 *>(x_last + o) = v;
 }
 
 // chunk-major rows -> plain rows (the compact last-token matrix in front of the head kernel)
@@ -1165,12 +1172,16 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float *__restrict__
 
 
 // (C = 64, 160: the 2M and tiny shapes; C = 256 has its own pipelined kernel in gpt_kernels_c256.h)
-template <class T, int NP, int CT, int NW = 8, int NBUF = 3, int NCH = 2>
+template <class T, int NP, int CT, int NW = 8, int NFOLD = 0, int NBUF = 3, int NCH = 2>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                             const uint16_t *__restrict__ wpk, float inv1, float inv2,
                                                             float2 *__restrict__ stats_out, int M,
-                                                            const float2 *__restrict__ gelu_lut)
+                                                            const float2 *__restrict__ gelu_lut,
+                                                            const float *__restrict__ fold = nullptr, int64_t fold_stride = 0)
 {
+    // NFOLD > 0 (small launches, after a head-parallel attn_block_kernel): NFOLD partial sums in x's layout, fold_stride floats
+    // apart, are added to the row in index order before anything else and the sum is written back (a token has ONE owner here).
+    // A compile-time count: every load of the fold is in flight at once (as a run-time loop hipcc serialised them, +23 us per launch)
     constexpr int C = CT * 32, KS = C / 16, NT = 4 * CT;
     constexpr int LUT_BYTES = kGeluLutN * 8;               // the Phi table sits behind the ring: [NBUF][PKT][LUT]
     static_assert((LUT_BYTES / 1024) % NW == 0, "every wave stages the same number of table pieces");
@@ -1220,8 +1231,29 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
         for (int gq = 0; gq < 4; gq++) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(xt + (4 * j + gq) * 256);
             acc[j][4 * gq] = v[0]; acc[j][4 * gq + 1] = v[1]; acc[j][4 * gq + 2] = v[2]; acc[j][4 * gq + 3] = v[3];
-            s += (v[0] + v[1]) + (v[2] + v[3]);
         }
+    if constexpr (NFOLD > 0) {
+        const float *fp = fold + (xt - x);
+#pragma unroll
+        for (int p = 0; p < NFOLD; p++) {
+            f32x4 t[4 * CT];
+#pragma unroll
+            for (int c = 0; c < 4 * CT; c++) t[c] = *reinterpret_cast<const f32x4 *>(fp + (size_t)p * fold_stride + c * 256);
+#pragma unroll
+            for (int c = 0; c < 4 * CT; c++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[c >> 2][4 * (c & 3) + e] += t[c][e];
+        }
+#pragma unroll
+        for (int c = 0; c < 4 * CT; c++) {
+            const f32x4 v = {acc[c >> 2][4 * (c & 3)], acc[c >> 2][4 * (c & 3) + 1], acc[c >> 2][4 * (c & 3) + 2], acc[c >> 2][4 * (c & 3) + 3]};
+            *reinterpret_cast<f32x4 *>(xt + c * 256) = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) s += (acc[j][4 * gq] + acc[j][4 * gq + 1]) + (acc[j][4 * gq + 2] + acc[j][4 * gq + 3]);
     s += __shfl_xor(s, 32);
     const float mean = s / (float)C;
     float q = 0.f;
@@ -1477,7 +1509,12 @@ __global__ __launch_bounds__(256) void pack_cols_perm_kernel(const float *__rest
 // the new row of token 255 goes to the compact buffer x_last[row][C] (the MLP and the head then run on that).
 // EMBED (first layer): the residual row is not read from x but formed here as wte[token] + wpe[position]
 // (model.py:171-175), which removes the embedding kernel's write and this kernel's first read of x.
-template <class T, int NP, int CT, bool PROJ, bool LAST = false, bool EMBED = false>
+// HP (head-parallel, small launches: needs PROJ, excludes EMBED): one workgroup per (row, head) instead of per row -- with a few dozen
+// rows (one environment: BASELINE cfg1) a row's five heads run on five CUs at once instead of one after the other on one.  The
+// workgroup forms the row's LayerNorm itself, runs its head and writes that head's c_proj contribution (times the projection's
+// 1 / scale) to part_out + head * part_stride in x's own layout (LAST: the compact last-token layout); x is NOT touched -- the
+// next kernel (mlp_fused_kernel's / gather_last_kernel's fold arguments) adds the partial sums in head order.
+template <class T, int NP, int CT, bool PROJ, bool LAST = false, bool EMBED = false, bool HP = false>
 __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                              const uint16_t *__restrict__ wpk, float inv_scale,
                                                              uint16_t *__restrict__ y_hi, uint16_t *__restrict__ y_lo,
@@ -1485,10 +1522,12 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
                                                              const uint16_t *__restrict__ ppk, float inv_scale_p,
                                                              float2 *__restrict__ stats_out, float *__restrict__ x_last,
                                                              const uint8_t *__restrict__ tokens, const float *__restrict__ wte,
-                                                             const float *__restrict__ wpe)
+                                                             const float *__restrict__ wpe, float *__restrict__ part_out = nullptr,
+                                                             int64_t part_stride = 0)
 {
     static_assert(!EMBED || (PROJ && !LAST), "EMBED is the first layer of a model with more than one layer");
     static_assert(!LAST || PROJ, "LAST implies PROJ");
+    static_assert(!HP || (PROJ && !EMBED), "HP writes c_proj partial sums and reads x");
     constexpr int C = CT * 32, KS = C / 16, NW = 8, HS = 32;
     constexpr int F = KS * NP, PKT = F * 1024, PER_WAVE = (F + NW - 1) / NW;
     constexpr int KROW = 80, VROW = 528;                                  // padded LDS rows (bytes): conflict-free b128 reads
@@ -1498,7 +1537,8 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
     unsigned char *sW = sV + NP * HS * VROW;                              // [4][PKT]: q, k, v packets of the head, c_proj slice
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t b = blockIdx.x;
+    const int64_t b = HP ? blockIdx.x / n_head : blockIdx.x;
+    const int hd_lo = HP ? (int)(blockIdx.x - b * n_head) : 0, hd_hi = HP ? hd_lo + 1 : n_head;     // heads of this workgroup
     const int tok0 = wave * 32;
     float *xt = x + (b * kT + tok0) * C + r * 8 + 4 * h;                 // chunk-major x (xt_off): chunk c = 4 j + gq at xt + c * 256
     const float *erow = EMBED ? wte + (size_t)tokens[b * kT + tok0 + r] * C : nullptr;   // token embedding row of this lane's token
@@ -1525,7 +1565,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
 #pragma unroll
         for (int which = 0; which < 3; which++) dma(wsrc + (size_t)(which * CT + hd_) * PKT, which);
     };
-    issue_qkv(0);
+    issue_qkv(hd_lo);
 
     // ---- LayerNorm of this lane's token, operand planes in registers ----
     u32x4 xn[KS][2];
@@ -1617,7 +1657,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
 
     sync_all();                                                            // A(0)
 #pragma unroll 1
-    for (int hd = 0; hd < n_head; hd++) {
+    for (int hd = hd_lo; hd < hd_hi; hd++) {
         if (PROJ) dma(psrc + (size_t)hd * PKT, 3);                         // c_proj slice of this head (needed after the attention)
         f32x16 tile;
         u32x4 qf[2][2];                                                   // B operand of S^T = K Q^T: [k-step][plane]
@@ -1647,7 +1687,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
                 *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VROW + r * VROW + (wave * 2 + mm) * 32 + h * 16) = vp[pl];
         }
         sync_all();                                                        // B(hd)
-        if (hd + 1 < n_head) issue_qkv(hd + 1);                            // flies during the attention below
+        if (hd + 1 < hd_hi) issue_qkv(hd + 1);                             // flies during the attention below
 
         // ---- attention of this wave's 32 queries against the 256 keys of the head ----
         f32x16 o;
@@ -1735,6 +1775,21 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(float *__restrict__ 
         // ---- residual add, store, LayerNorm statistics of the new row (as the GEMM / MLP epilogues) ----
         // LAST: only token 255 (lanes 31 and 63 of the last wave) is kept, in the compact buffer
         const bool keep = !LAST || r == 31;
+        if constexpr (HP) {
+            // this head's c_proj contribution, in true units, where the residual row would go (in the head's own partial buffer)
+            float *prow = part_out + (size_t)hd_lo * part_stride +
+                          (LAST ? (b >> 5) * 32 * C + (b & 31) * 8 + 4 * h : (b * kT + tok0) * C + r * 8 + 4 * h);
+#pragma unroll
+            for (int j = 0; j < CT; j++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = pacc[j][4 * gq + e] * inv_scale_p;
+                    if (keep) *reinterpret_cast<f32x4 *>(prow + (4 * j + gq) * 256) = v;
+                }
+            return;
+        }
         // (LAST: row b of the compact matrix, chunk-major as well: tile b / 32, token b % 32)
         float *orow = LAST ? x_last + (b >> 5) * 32 * C + (b & 31) * 8 + 4 * h : xt;
         float s2 = 0.f;

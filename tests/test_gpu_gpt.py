@@ -172,3 +172,24 @@ def test_other_shapes_take_the_generic_chain(n_head, n_embd, precision, tol):
     ref = gpt_oracle.forward_logits(sd, args, rows, dtype=torch.float64).numpy()
     err = np.abs(logits - ref).max()
     assert np.isfinite(logits).all() and err <= tol, f"C={n_embd} heads={n_head} {precision}: max |dlogit| = {err:.3e}"
+
+
+@pytest.mark.parametrize("name,precision", [("2M", "f16x3"), ("2M", "bf16"), ("tiny", "f16x3")])
+def test_head_parallel_small_launch_vs_row_per_workgroup_path(name, precision):
+    """Round 4: launches of <= 128 rows of the C = 64 / 160 shapes run the attention block head-parallel (one workgroup per
+    (row, head), the heads' c_proj contributions folded in head order by the next kernel) -- the way one environment (BASELINE
+    cfg1) is served.  The same rows inside a 160-row launch take the row-per-workgroup kernels.  Same products, another
+    summation order of the residual stream: the two must agree to fp32 rounding and both must sit within 1e-5 of the fp32 port
+    (the f16x3 mode; bf16: its own class)."""
+    from mapf_gpt_amd.model import build_model
+    rows = np.load(os.path.join(GOLDEN, "gptbig_2M_s1.npz"))["tokens"][:160]
+    net = build_model(name, seed=0, max_rows=160, precision=precision)
+    big = net.logits_tokens(torch.from_numpy(rows).cuda()).cpu().numpy()
+    for n_small in (1, 40, 128):
+        small = net.logits_tokens(torch.from_numpy(np.ascontiguousarray(rows[:n_small])).cuda()).cpu().numpy()
+        d = np.abs(small - big[:n_small]).max()
+        assert d <= (2e-6 if precision == "f16x3" else 5e-2), f"{name} {precision} {n_small} rows: head-parallel vs fused {d:.3e}"
+    if precision == "f16x3":
+        sd, args = weights.synthetic_state_dict(name, seed=0), weights.model_args(name)
+        ref = gpt_oracle.forward_logits(sd, args, rows[:40]).numpy()
+        assert np.abs(small[:40] - ref).max() <= TOL and np.abs(big[:40] - ref).max() <= TOL
