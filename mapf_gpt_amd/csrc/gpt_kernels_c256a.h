@@ -20,7 +20,7 @@
 // the row loop are inline asm with hand-counted s_waitcnt (they retire in issue order: "at most N outstanding" with N = the
 // operations issued after the one needed is exact; a smaller N is always safe).  Per wave and row, in issue order:
 //     32 x-row loads | per head: 6 x 2 ring pieces, 4 spill stores (heads 0-6) | 28 spill loads | tail pseudo-head t = 0..3:
-//     [t = 0: 4 L2-prefetch touches of the next row] 8 residual loads, 4 x 2 ring pieces, 8 stores
+//     8 residual loads, 4 x 2 ring pieces, 8 stores
 // Numerics: the same products and the same fp16 split of y as attn256_kernel + gemm_pk_kernel<EPI_RESID> (y in true units,
 // c_proj pre-scaled by a power of two, fp32 accumulation over k = head-major d); results per token do not depend on the grid.
 #pragma once
@@ -95,7 +95,6 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
     constexpr int KROW = 80, VROW = 528;                   // padded LDS rows (bytes): conflict-free b128 reads
     constexpr int NSPILL = 2 * NP;                         // spill stores per head per wave (16 bytes per lane each)
     constexpr int NYLD = 14 * NP;                          // spill loads per row per wave
-    constexpr int NPF = 4;                                 // L2-prefetch touches of the next row per wave
     static_assert(PW >= 1, "a wave moves at least one piece per step");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [NSLOT][STEP] ring | sK [NP][256][KROW] | sV [NP][32][VROW]
@@ -481,27 +480,17 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
 
         // ---- tail: x <- x + y c_proj^T.  Pseudo-head t = output tiles 2t, 2t+1 (features 64 t .. 64 t + 63) over K = 256 in
         //      four q|k-shaped steps; the residual rows of the two tiles are requested at its first step ----
-        const int64_t b_next = (k + 1 < n_mine) ? b + gridDim.x : b;      // (always a valid row: the touches are counted below)
-        const unsigned char *pf_base = reinterpret_cast<const unsigned char *>(x + (b_next * kT + tok0) * C);   // (uniform)
+        // (Touching the next row's lines from here -- one dword per 128-byte line, so that the prologue's loads would come from L2 -- was
+        //  built and measured in round 4: the lines do not survive in the 4-MiB L2 next to 7 MiB of spill slab per XCD, the counters show
+        //  the row fetched twice (+3.2 GB per launch), and the kernel is 2 % SLOWER with the touches: 57.7 vs 56.5 ms per cfg3 step.)
         auto tail = [&](int t, auto first_c, auto last_c) {
             constexpr bool FIRST = decltype(first_c)::value, LASTT = decltype(last_c)::value;
 #pragma unroll
             for (int g = 0; g < 16; g++) { qa[g] = 0.f; ka[g] = 0.f; }
             f32x4 xs[2][4];                                // residual pieces of the two tiles: [tile][gq]
-            float touch[NPF] = {0.f, 0.f, 0.f, 0.f};       // destinations of the prefetch touches: live until the loads have retired
             unsigned char *xp = xw + (size_t)t * 8192;     // tile 2t: chunks 8t .. 8t+3, tile 2t+1: chunks 8t+4 .. 8t+7 (+4 KiB)
-            constexpr int OTHERS = 8 + (FIRST ? NPF : 0);  // vector-memory operations of this pseudo-head's first step besides ring pieces
+            constexpr int OTHERS = 8;                      // vector-memory operations of this pseudo-head's first step besides ring pieces
             auto requests = [&]() {
-                if constexpr (FIRST) {
-                    // touch the next row's 32 KiB of this wave (one dword per 128-byte line): the prologue's loads then come from L2 /
-                    // the memory-side cache instead of queueing behind every other CU's row burst
-                    unsigned loff = lane16;                // one 128-byte line per lane; recomputed here (as a row-loop invariant hipcc kept it
-                    asm volatile("" : "+v"(loff));         //  in scratch and reloaded it behind a vmcnt(0) that drained the ring)
-                    loff <<= 3;
-#pragma unroll
-                    for (int i = 0; i < NPF; i++)
-                        asm volatile("global_load_dword %0, %1, %2" : "=v"(touch[i]) : "v"(loff), "s"(pf_base + (size_t)i * 8192) : "memory");
-                }
 #pragma unroll
                 for (int w2 = 0; w2 < 2; w2++)
 #pragma unroll
@@ -517,7 +506,6 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
             // ---- epilogue of the two tiles: x + acc / scale (the residual loads are older than this pseudo-head's ring pieces) ----
             asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[0][2]), "+v"(xs[0][3]), "+v"(xs[1][0]), "+v"(xs[1][1]), "+v"(xs[1][2]), "+v"(xs[1][3])
                          : [n] "n"(4 * PW) : "memory");
-            if constexpr (FIRST) asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));   // (retired: older than the residual loads)
 #pragma unroll
             for (int w2 = 0; w2 < 2; w2++)
 #pragma unroll

@@ -19,13 +19,13 @@ def table(path):
 KEYS = [  # (json key, kernel substring, grid, note)
     ("cfg3_f16x3_gpt_mlp_fused", "mlp256p_kernel<mgpt::fastk::F16T, 2, 0>", 131072,
      "mlp256p_kernel (persistent, 256 workgroups x 512 threads): x rows read by the producer for LayerNorm and again by the consumer for the "
-     "residual add (2 x 3.22 GB), the 2.2 MB cyclic weight stream per 128-token block served by L2, one write of x"),
-    ("cfg3_f16x3_gpt_attention", "attn256_kernel<mgpt::fastk::F16T, 2, false, 0", 6291456,
-     "attn256_kernel: one read of x (3.22 GB), y operand planes out (2 x 1.61 GB); q, k, v stay on chip"),
+     "residual add (2 x 3.22 GB; the second read comes ~90 us after the first, inside the 256-MiB memory-side cache's reach, and is still "
+     "counted: FETCH_SIZE tallies L2 <-> fabric requests), the 2.2 MB cyclic weight stream per 128-token block served by L2, one write of x"),
+    ("cfg3_f16x3_gpt_attention", "attn256o_kernel<mgpt::fastk::F16T, 2, 0>", 131072,
+     "attn256o_kernel (persistent, whole attention block): x read for LayerNorm (3.22 GB) and again for the residual add, x written; the y planes "
+     "go to the 56-MiB spill slab (written and read back by the same wave, L2 / memory-side cache) instead of a 3.22-GB y matrix + GEMM"),
     ("cfg3_f16x3_gpt_attention_last_layer", "attn256_kernel<mgpt::fastk::F16T, 2, true, 0", 6291456,
      "last layer: all of x read for K/V, only token 255's output row written"),
-    ("cfg3_f16x3_gpt_gemm_attn_proj", "gemm_pk_kernel<mgpt::fastk::F16T, 2, 2, 8", 6291456,
-     "out-projection GEMM: y planes (3.22 GB) + x (3.22 GB) in, x out: HBM-bound"),
     ("cfg3_tok_generate_observations", "tokens_kernel<4, 4>", 196608, "cfg3's own launch: 64 instances x 192 agents"),
     ("cfg4_tok_generate_observations_65536_rows", "tokens_kernel<2, 4>", 1048576, "cfg4 per-GPU shard: 512 instances x 128 agents, per-instance maps"),
     ("tok_generate_observations_524160_rows", "tokens_kernel<4, 16>", 2096640, "2730 instances x 192 agents on the warehouse map"),
