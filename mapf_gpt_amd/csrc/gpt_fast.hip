@@ -14,6 +14,7 @@
 #include "gpt_kernels_c256.h"
 #include "gpt_kernels_c256p.h"
 #include "gpt_kernels_c256a.h"
+#include "gpt_kernels_c160p.h"
 
 using namespace mgpt;
 
@@ -77,6 +78,9 @@ struct ModeState {          // one precision mode
     // small launches of the register-resident path (rows <= kSmallRows: one environment, BASELINE cfg1): attn_block_kernel<HP> runs one
     // workgroup per (row, head) and leaves the heads' c_proj contributions here, [n_head][kSmallRows * 256 * C] fp32 in x's layout
     float *head_parts = nullptr;
+    // ... and the MLP block of those launches (C = 160): mlp160p_kernel's cyclic stream per layer and the scale c_fc * ln_2 was packed with
+    std::vector<uint16_t *> mlp160_pk;
+    std::vector<float> mlp160_inv1;
     // PK GEMM path (C % 256 == 0: 6M, 85M): weights as MFMA-fragment streams, activations produced in the same layout
     bool pk_gemm = false;
     std::vector<uint16_t *> attn_pk2, proj_pk2, fc_pk2, proj2_pk2;   // [row tile][k-step][plane][lane][8]
@@ -272,6 +276,28 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                    MGPT_ATTN_LDS(2, false, false, true); MGPT_ATTN_LDS(2, true, false, true); }
 #undef MGPT_ATTN_LDS
             if (m->mlp_fused) MGPT_HIP(hipMalloc(&m->head_parts, (size_t)g->nh * kSmallRows * kT * C * sizeof(float)));
+            if (m->mlp_fused && C == 160) {
+                const size_t n16 = (size_t)fastk::kM5Period * 20 * NP * 512;
+                m->mlp160_pk.assign(g->L, nullptr);
+                m->mlp160_inv1.assign(g->L, 1.f);
+                for (int l = 0; l < g->L; l++) {
+                    MGPT_HIP(hipMalloc(&m->mlp160_pk[l], n16 * sizeof(uint16_t)));
+                    const LayerOff &lo = g->layers[l];
+                    std::vector<float> wg(4 * C * C);                       // the stream carries c_fc.weight * ln_2.weight: its own power-of-two scale
+                    for (size_t i = 0; i < wg.size(); i++) wg[i] = host[lo.fc_w + i] * host[lo.ln2 + i % C];
+                    const float sc1 = pick_scale(wg.data(), wg.size(), f16);
+                    m->mlp160_inv1[l] = 1.0f / sc1;
+                    ProfScope ps(P_PACK, nullptr);
+                    hipLaunchKernelGGL((fastk::pack_mlp160p_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)fastk::kM5Period * 20 * 64, 256)), dim3(256), 0,
+                                       nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, g->params + lo.ln2, m->mlp160_pk[l], sc1,
+                                       1.0f / m->proj2[l].inv_scale);
+                    MGPT_LAUNCH_CHECK();
+                }
+                MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp160p_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             fastk::kM5Lds<NP>));
+                MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp160p_kernel<T, NP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             fastk::kM5Lds<NP>));
+            }
         }
     }
     m->pk_gemm = (C == 256 || C == 512 || C == 768 || C == 1024);
@@ -354,6 +380,7 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     (void)hipFree(m->x_head);
     (void)hipFree(m->y_last);
     (void)hipFree(m->head_parts);
+    for (auto *p : m->mlp160_pk) (void)hipFree(p);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
 }
@@ -565,6 +592,16 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                     MGPT_LAUNCH_CHECK();
                     if ((rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
                 }
+            } else if (head_par && C == 160) {
+                // small launch: persistent producer / consumer blocks of 128 tokens (two waves per SIMD); the heads' partial sums are folded
+                // in (the last layer's compact rows were folded by gather_last_kernel)
+                const int n_blocks = (int)(mlp_M / 128);
+                if (last_short)
+                    hipLaunchKernelGGL((fastk::mlp160p_kernel<T, NP, 0>), dim3((unsigned)std::min(n_blocks, m->n_cu)), dim3(512), (size_t)fastk::kM5Lds<NP>, s,
+                                       mlp_x, m->mlp160_pk[l], m->mlp160_inv1[l], m->proj2[l].inv_scale, m->gelu_lut, n_blocks, (const float *)nullptr, (int64_t)0);
+                else
+                    hipLaunchKernelGGL((fastk::mlp160p_kernel<T, NP, 5>), dim3((unsigned)std::min(n_blocks, m->n_cu)), dim3(512), (size_t)fastk::kM5Lds<NP>, s,
+                                       mlp_x, m->mlp160_pk[l], m->mlp160_inv1[l], m->proj2[l].inv_scale, m->gelu_lut, n_blocks, m->head_parts, part_stride);
             } else {
                 const size_t lds = (size_t)(C / 16 + 2 * (C / 32)) * NP * 1024 * 3 + fastk::kGeluLutN * 8;
                 // 32 tokens per wave whatever the block size: small launches (cfg1: 32 rows = 32 blocks of 256 tokens) take
