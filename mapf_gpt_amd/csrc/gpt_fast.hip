@@ -15,6 +15,7 @@
 #include "gpt_kernels_c256p.h"
 #include "gpt_kernels_c256a.h"
 #include "gpt_kernels_c160p.h"
+#include "gpt_kernels_last.h"
 
 using namespace mgpt;
 
@@ -27,6 +28,12 @@ constexpr int kV = MGPT_VOCAB;
 constexpr bool kAttn256Fused = false;
 #else
 constexpr bool kAttn256Fused = true;
+#endif
+// -DMGPT_AB_NO_LAST1 keeps the last layer on the full attention kernels (attn256_kernel<LAST> / attn_block_kernel<LAST>)
+#ifdef MGPT_AB_NO_LAST1
+constexpr bool kLast1 = false;
+#else
+constexpr bool kLast1 = true;
 #endif
 
 // rows up to which the C = 64 / 160 attention block runs head-parallel: beyond ~164 rows of 5 heads the (row, head) workgroups
@@ -78,6 +85,7 @@ struct ModeState {          // one precision mode
     // small launches of the register-resident path (rows <= kSmallRows: one environment, BASELINE cfg1): attn_block_kernel<HP> runs one
     // workgroup per (row, head) and leaves the heads' c_proj contributions here, [n_head][kSmallRows * 256 * C] fp32 in x's layout
     float *head_parts = nullptr;
+    float *last1_wt = nullptr;                 // last layer, attn_last1_kernel: transposes of W_q, W_v, c_proj.weight (fp32)
     // ... and the MLP block of those launches (C = 160): mlp160p_kernel's cyclic stream per layer and the scale c_fc * ln_2 was packed with
     std::vector<uint16_t *> mlp160_pk;
     std::vector<float> mlp160_inv1;
@@ -300,6 +308,21 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             }
         }
     }
+    if (g->hs == 32 && (C == 256 || C == 160 || C == 64) && m->mlp_fused) {
+        // the last layer's attention block for token 255 alone (attn_last1_kernel): fp32 transposes of W_q, W_v and c_proj.weight
+        const LayerOff &lo = g->layers[g->L - 1];
+        MGPT_HIP(hipMalloc(&m->last1_wt, (size_t)3 * C * C * sizeof(float)));
+        const size_t srcs[3] = {lo.attn_w, lo.attn_w + (size_t)2 * C * C, lo.proj_w};
+        ProfScope ps(P_PACK, nullptr);
+        for (int i = 0; i < 3; i++) {
+            hipLaunchKernelGGL(fastk::transpose_kernel, dim3((unsigned)cdiv64((int64_t)C * C, 256)), dim3(256), 0, nullptr, g->params + srcs[i],
+                               m->last1_wt + (size_t)i * C * C, (int)C);
+            MGPT_LAUNCH_CHECK();
+        }
+        if (C == 256) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_last1_kernel<256, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fastk::kLast1Lds<256>));
+        else if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_last1_kernel<160, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fastk::kLast1Lds<160>));
+        else MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_last1_kernel<64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fastk::kLast1Lds<64>));
+    }
     m->pk_gemm = (C == 256 || C == 512 || C == 768 || C == 1024);
     if (m->pk_gemm) {
         auto pack = [&](std::vector<uint16_t *> &dst, size_t off, size_t R, size_t K, float scale, int l) -> int {
@@ -380,6 +403,7 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     (void)hipFree(m->x_head);
     (void)hipFree(m->y_last);
     (void)hipFree(m->head_parts);
+    (void)hipFree(m->last1_wt);
     for (auto *p : m->mlp160_pk) (void)hipFree(p);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
@@ -492,7 +516,18 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         const int rows_pad = ((rows + 255) / 256) * 256;
         // 6M shape, every layer but the last: attn256o_kernel does the out-projection and the residual add itself
         const bool proj_fused = m->attn256 && !last_short && kAttn256Fused;
-        if (attn_block) {
+        // last layer of a launch that fills the chip: the attention block of token 255 alone, without K and V (attn_last1_kernel)
+        const bool last1 = last_short && m->last1_wt != nullptr && m->x_tiled && !head_par && kLast1;
+        if (last1) {
+            ProfScope ps(P_ATTN_LAST, s);
+            const float *wk = P + lo.attn_w + (size_t)C * C;
+#define MGPT_LAST1(C_)                                                                                                                      \
+    hipLaunchKernelGGL((fastk::attn_last1_kernel<C_, 32>), dim3((unsigned)(rows_pad / fastk::kLast1R)), dim3(256 * fastk::last1_split(C_)), (size_t)fastk::kLast1Lds<C_>, s, g->x, P + lo.ln1, \
+                       wk, m->last1_wt, m->x_last, rows, scale_log2e)
+            if (C == 256) MGPT_LAST1(256); else if (C == 160) MGPT_LAST1(160); else MGPT_LAST1(64);
+#undef MGPT_LAST1
+            MGPT_LAUNCH_CHECK();
+        } else if (attn_block) {
             // ---- LN1 + QKV + attention + out-projection + residual in one kernel: q, k, v, y stay on chip ----
             ProfScope ps(last_short ? P_ATTN_LAST : P_ATTN, s);
             const size_t lds = (size_t)NP * (kT * 80 + 32 * 528) + (size_t)(C / 16) * NP * 1024 * 4;   // K, V^T planes + 4 weight packet slots
@@ -548,7 +583,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             a.N = C; a.o_hi = m->vt[0]; a.o_lo = m->vt[1];
             if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_VT>(a, C, s)) != MGPT_OK) return rc;
         }
-        if (!attn_block && !proj_fused) {
+        if (!attn_block && !proj_fused && !last1) {
             const bool ls = last_short && m->pk_gemm;       // only token 255 of every row from here on
             if (!m->attn256) {
                 ProfScope ps(ls ? P_ATTN_LAST : P_ATTN, s);
