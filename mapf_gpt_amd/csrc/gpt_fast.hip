@@ -15,6 +15,7 @@
 #include "gpt_kernels_c256p.h"
 #include "gpt_kernels_c256a.h"
 #include "gpt_kernels_c160p.h"
+#include "gpt_kernels_c160a.h"
 #include "gpt_kernels_last.h"
 
 using namespace mgpt;
@@ -30,6 +31,12 @@ constexpr bool kAttn256Fused = false;
 constexpr bool kAttn256Fused = true;
 #endif
 // -DMGPT_AB_NO_LAST1 keeps the last layer on the full attention kernels (attn256_kernel<LAST> / attn_block_kernel<LAST>)
+// -DMGPT_AB_NO_ATTN160O keeps the 2M shape's middle layers on attn_block_kernel
+#ifdef MGPT_AB_NO_ATTN160O
+constexpr bool kAttn160o = false;
+#else
+constexpr bool kAttn160o = true;
+#endif
 #ifdef MGPT_AB_NO_LAST1
 constexpr bool kLast1 = false;
 #else
@@ -85,6 +92,9 @@ struct ModeState {          // one precision mode
     // small launches of the register-resident path (rows <= kSmallRows: one environment, BASELINE cfg1): attn_block_kernel<HP> runs one
     // workgroup per (row, head) and leaves the heads' c_proj contributions here, [n_head][kSmallRows * 256 * C] fp32 in x's layout
     float *head_parts = nullptr;
+    std::vector<uint16_t *> attn160o_pk;        // C = 160: attn160o_kernel's stream per layer (c_attn * ln_1 | c_proj), its 1 / scale, spill slab
+    std::vector<float> attn160_inv;
+    unsigned char *attn160o_spill = nullptr;
     float *last1_wt = nullptr;                 // last layer, attn_last1_kernel: transposes of W_q, W_v, c_proj.weight (fp32)
     // ... and the MLP block of those launches (C = 160): mlp160p_kernel's cyclic stream per layer and the scale c_fc * ln_2 was packed with
     std::vector<uint16_t *> mlp160_pk;
@@ -301,6 +311,25 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                        1.0f / m->proj2[l].inv_scale);
                     MGPT_LAUNCH_CHECK();
                 }
+                // the attention block as one persistent kernel (layers that neither gather the embedding nor are the last)
+                m->attn160o_pk.assign(g->L, nullptr);
+                m->attn160_inv.assign(g->L, 1.f);
+                for (int l = 0; l < g->L; l++) {
+                    MGPT_HIP(hipMalloc(&m->attn160o_pk[l], (size_t)fastk::kA160oPeriod * fastk::kA160oFrags * NP * 512 * sizeof(uint16_t)));
+                    const LayerOff &lo = g->layers[l];
+                    std::vector<float> wg(3 * C * C);                       // c_attn.weight * ln_1.weight: its own power-of-two scale
+                    for (size_t i = 0; i < wg.size(); i++) wg[i] = host[lo.attn_w + i] * host[lo.ln1 + i % C];
+                    const float sca = pick_scale(wg.data(), wg.size(), f16);
+                    m->attn160_inv[l] = 1.0f / sca;
+                    ProfScope ps(P_PACK, nullptr);
+                    hipLaunchKernelGGL((fastk::pack_attn160o_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)fastk::kA160oPeriod * fastk::kA160oFrags * 64, 256)),
+                                       dim3(256), 0, nullptr, g->params + lo.attn_w, g->params + lo.ln1, g->params + lo.proj_w, m->attn160o_pk[l], sca,
+                                       1.0f / m->proj[l].inv_scale);
+                    MGPT_LAUNCH_CHECK();
+                }
+                MGPT_HIP(hipMalloc(&m->attn160o_spill, (size_t)m->n_cu * fastk::kA160oSpillPerWg<NP>));
+                MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn160o_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             fastk::kA160oLds<NP>));
                 MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp160p_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              fastk::kM5Lds<NP>));
                 MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp160p_kernel<T, NP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -404,6 +433,8 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     (void)hipFree(m->y_last);
     (void)hipFree(m->head_parts);
     (void)hipFree(m->last1_wt);
+    for (auto p : m->attn160o_pk) (void)hipFree(p);
+    (void)hipFree(m->attn160o_spill);
     for (auto *p : m->mlp160_pk) (void)hipFree(p);
     for (int p = 0; p < 2; p++) { (void)hipFree(m->qk[p]); (void)hipFree(m->vt[p]); (void)hipFree(m->y[p]); (void)hipFree(m->hbuf[p]); }
     *m = ModeState();
@@ -526,6 +557,12 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                        wk, m->last1_wt, m->x_last, rows, scale_log2e)
             if (C == 256) MGPT_LAST1(256); else if (C == 160) MGPT_LAST1(160); else MGPT_LAST1(64);
 #undef MGPT_LAST1
+            MGPT_LAUNCH_CHECK();
+        } else if (attn_block && C == 160 && !head_par && !last_short && !(embed_fused && l == 0) && m->attn160o_spill != nullptr && kAttn160o) {
+            // ---- the 2M shape's attention block as one persistent kernel (attn160o_kernel) ----
+            ProfScope ps(P_ATTN, s);
+            hipLaunchKernelGGL((fastk::attn160o_kernel<T, NP>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)fastk::kA160oLds<NP>, s, g->x,
+                               m->attn160o_pk[l], m->attn160_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn160o_spill, rows);
             MGPT_LAUNCH_CHECK();
         } else if (attn_block) {
             // ---- LN1 + QKV + attention + out-projection + residual in one kernel: q, k, v, y stay on chip ----
