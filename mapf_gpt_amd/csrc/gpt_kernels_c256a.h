@@ -434,6 +434,13 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                         m_run = m_new;
                     }
                     const float nm = -m_run * sc2;
+                    // (Two variants of this loop were built and measured in round 4, A/B in one box, cfg3 attention ms per step:
+                    //  v_pk_fma_f32 / v_pk_add_f32 on score pairs, 15 instructions fewer per key tile: 54.5 against 53.9;
+                    //  software pipelining -- the S MFMAs of tile kt + 1 issued before the softmax arithmetic of tile kt, the second
+                    //  score block in the 16 registers of the next step's prefetched weight fragments, bit-identical results: 54.2
+                    //  against 54.0.  Neither the count of full-rate VALU instructions nor the MFMA / VALU order inside a wave
+                    //  bounds this phase: the second wave of the SIMD already fills the gaps, and what is saved in cycles comes
+                    //  back as a lower clock (HISTORY.md section 12, round 3).)
                     float psum = 0.f;
 #pragma unroll
                     for (int g = 0; g < 16; g++) {
