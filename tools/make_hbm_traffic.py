@@ -24,8 +24,8 @@ KEYS = [  # (json key, kernel substring, grid, note)
     ("cfg3_f16x3_gpt_attention", "attn256o_kernel<mgpt::fastk::F16T, 2, 0>", 131072,
      "attn256o_kernel (persistent, whole attention block): x read for LayerNorm (3.22 GB) and again for the residual add, x written; the y planes "
      "go to the 56-MiB spill slab (written and read back by the same wave, L2 / memory-side cache) instead of a 3.22-GB y matrix + GEMM"),
-    ("cfg3_f16x3_gpt_attention_last_layer", "attn256_kernel<mgpt::fastk::F16T, 2, true, 0", 6291456,
-     "last layer: all of x read for K/V, only token 255's output row written"),
+    ("cfg3_f16x3_gpt_attention_last_layer", "attn_last1_kernel<256, 32>", 1572864,
+     "last layer (attn_last1_kernel): all of x read once, only token 255's new row written (compact)"),
     ("cfg3_tok_generate_observations", "tokens_kernel<4, 4>", 196608, "cfg3's own launch: 64 instances x 192 agents"),
     ("cfg4_tok_generate_observations_65536_rows", "tokens_kernel<2, 4>", 1048576, "cfg4 per-GPU shard: 512 instances x 128 agents, per-instance maps"),
     ("tok_generate_observations_524160_rows", "tokens_kernel<4, 16>", 2096640, "2730 instances x 192 agents on the warehouse map"),
