@@ -25,6 +25,8 @@
 //     4 .. 21         c_fc(tile R - 2), GELU(R - 3)                 c_proj(tile R - 4)
 // Every LDS / global access inside the block loop is inline asm with hand-counted s_waitcnt (see gpt_kernels_c256p.h).
 // x is chunk-major (xt_off).  Results per token do not depend on the grid or on the block a token falls in.
+// (Round 4: touching every line of the stream up front -- all first-touch misses of the block in flight at once -- makes the small
+//  launch SLOWER, 0.50 against 0.46 ms per cfg1 step under the profiler: the 1.6 us per step are not L2 misses.)
 #pragma once
 #include "gpt_kernels_c256p.h"
 
