@@ -37,6 +37,11 @@ constexpr bool kAttn160o = false;
 #else
 constexpr bool kAttn160o = true;
 #endif
+#ifdef MGPT_AB_NO_LAST1_TAIL
+constexpr bool kLast1Tail = false;
+#else
+constexpr bool kLast1Tail = true;
+#endif
 #ifdef MGPT_AB_NO_LAST1
 constexpr bool kLast1 = false;
 #else
@@ -340,17 +345,25 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
     if (g->hs == 32 && (C == 256 || C == 160 || C == 64) && m->mlp_fused) {
         // the last layer's attention block for token 255 alone (attn_last1_kernel): fp32 transposes of W_q, W_v and c_proj.weight
         const LayerOff &lo = g->layers[g->L - 1];
-        MGPT_HIP(hipMalloc(&m->last1_wt, (size_t)3 * C * C * sizeof(float)));
-        const size_t srcs[3] = {lo.attn_w, lo.attn_w + (size_t)2 * C * C, lo.proj_w};
+        // (C = 160 / 64 also: c_fc.weight and mlp.c_proj.weight transposed, for the one-launch last layer + head of small launches)
+        const bool tail = C != 256;
+        MGPT_HIP(hipMalloc(&m->last1_wt, (size_t)(tail ? 11 : 3) * C * C * sizeof(float)));
+        struct { size_t off; int rows, cols; size_t dst; } mats[5] = {
+            {lo.attn_w, (int)C, (int)C, 0}, {lo.attn_w + (size_t)2 * C * C, (int)C, (int)C, (size_t)C * C}, {lo.proj_w, (int)C, (int)C, (size_t)2 * C * C},
+            {lo.fc_w, (int)(4 * C), (int)C, (size_t)3 * C * C}, {lo.proj2_w, (int)C, (int)(4 * C), (size_t)7 * C * C}};
         ProfScope ps(P_PACK, nullptr);
-        for (int i = 0; i < 3; i++) {
-            hipLaunchKernelGGL(fastk::transpose_kernel, dim3((unsigned)cdiv64((int64_t)C * C, 256)), dim3(256), 0, nullptr, g->params + srcs[i],
-                               m->last1_wt + (size_t)i * C * C, (int)C);
+        for (int i = 0; i < (tail ? 5 : 3); i++) {
+            hipLaunchKernelGGL(fastk::transpose_kernel, dim3((unsigned)cdiv64((int64_t)mats[i].rows * mats[i].cols, 256)), dim3(256), 0, nullptr,
+                               g->params + mats[i].off, m->last1_wt + mats[i].dst, mats[i].rows, mats[i].cols);
             MGPT_LAUNCH_CHECK();
         }
-        if (C == 256) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_last1_kernel<256, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fastk::kLast1Lds<256>));
-        else if (C == 160) MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_last1_kernel<160, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fastk::kLast1Lds<160>));
-        else MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_last1_kernel<64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, fastk::kLast1Lds<64>));
+#define MGPT_LAST1_LDS(C_, R_, TAIL_)                                                                                                          \
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_last1_kernel<C_, 32, R_, TAIL_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 fastk::kLast1Lds<C_, R_, TAIL_>))
+        if (C == 256) MGPT_LAST1_LDS(256, fastk::kLast1R, false);
+        else if (C == 160) { MGPT_LAST1_LDS(160, fastk::kLast1R, false); MGPT_LAST1_LDS(160, 1, true); }
+        else { MGPT_LAST1_LDS(64, fastk::kLast1R, false); MGPT_LAST1_LDS(64, 1, true); }
+#undef MGPT_LAST1_LDS
     }
     m->pk_gemm = (C == 256 || C == 512 || C == 768 || C == 1024);
     if (m->pk_gemm) {
@@ -549,6 +562,21 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         const bool proj_fused = m->attn256 && !last_short && kAttn256Fused;
         // last layer of a launch that fills the chip: the attention block of token 255 alone, without K and V (attn_last1_kernel)
         const bool last1 = last_short && m->last1_wt != nullptr && m->x_tiled && !head_par && kLast1;
+        // small launch (one environment): the last layer's attention block, its MLP block, ln_f and the head are ONE launch, one
+        // workgroup per row (attn_last1_kernel<.., 1, TAIL>), fp32 throughout; logits come straight out of it
+        const bool last_tail = last_short && head_par && m->last1_wt != nullptr && C != 256 && kLast1 && kLast1Tail;
+        if (last_tail) {
+            ProfScope ps(P_ATTN_LAST, s);
+            const float *wk = P + lo.attn_w + (size_t)C * C;
+#define MGPT_LAST1T(C_)                                                                                                                     \
+    hipLaunchKernelGGL((fastk::attn_last1_kernel<C_, 32, 1, true>), dim3((unsigned)rows), dim3(256 * fastk::last1_split(C_)),              \
+                       (size_t)(fastk::kLast1Lds<C_, 1, true>), s, g->x, P + lo.ln1, wk, m->last1_wt, (float *)nullptr, rows, scale_log2e,    \
+                       P + lo.ln2, P + g->off_lnf, P + g->off_wte, d_logits, kV)
+            if (C == 160) MGPT_LAST1T(160); else MGPT_LAST1T(64);
+#undef MGPT_LAST1T
+            MGPT_LAUNCH_CHECK();
+            return MGPT_OK;
+        }
         if (last1) {
             ProfScope ps(P_ATTN_LAST, s);
             const float *wk = P + lo.attn_w + (size_t)C * C;

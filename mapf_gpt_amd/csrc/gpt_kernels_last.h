@@ -29,8 +29,8 @@ constexpr int kLast1R = 4;                      // rows per workgroup
 // feature split: a token's normalised row is held by S threads (C / S registers each), the workgroup has 256 S threads
 constexpr int last1_split(int C) { return C >= 128 ? 2 : 1; }   // (4 for C = 256 spills under the 128-register cap of 16 waves and is 0.6 ms slower)
 
-template <int C>
-constexpr int kLast1Lds = (64 * (C + 4) + kLast1R * (C / 32) * C + last1_split(C) * (C / 32) * 256 + 3 * kLast1R * C + 2 * last1_split(C) * 256) * 4;
+template <int C, int R = kLast1R, bool TAIL = false>
+constexpr int kLast1Lds = (64 * (C + 4) + R * (C / 32) * C + last1_split(C) * (C / 32) * 256 + 3 * R * C + 2 * last1_split(C) * 256 + (TAIL ? 7 * C : 0)) * 4;
 
 // out[r] = sum_c wT[c][i] * vec_r[c] for the R rows and output i = tid (tid < C) (vec_r = vec + r * VS, + the head offset
 // of output i when PER_HEAD).  Thread (ig = tid & 63, cq = tid >> 6) accumulates outputs 4 ig .. 4 ig + 3 over the cq-th
@@ -82,15 +82,85 @@ __device__ __forceinline__ void last1_matvec(const float *__restrict__ wT, const
     __syncthreads();
 }
 
-template <int C, int HS>
+// One row: dst[o] = sum_k wT[k][o] * vec[k], o < O (wT row-major [K][O], vec and dst in LDS).  Wave cq takes the cq-th of NQ slices of
+// k, lane ig the outputs 256 p + 4 ig .. + 3 of pass p; the NQ partial sums meet in `part` ([NQ][O] floats of LDS) and are added in
+// index order.  Ends with a barrier: dst is complete, `part` may be reused.
+template <int K, int O, int NQ>
+__device__ __forceinline__ void last1_matvec1(const float *__restrict__ wT, const float *vec, float *part, float *dst, int tid)
+{
+    constexpr int KQ = K / NQ;
+    static_assert(KQ % 4 == 0 && O % 4 == 0, "slices of whole float4s");
+    const int ig = tid & 63, cq = tid >> 6;
+#pragma unroll 1
+    for (int o0 = 4 * ig; o0 < O; o0 += 256) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        const float *w = wT + (cq * KQ) * O + o0;
+        const float *v = vec + cq * KQ;
+#pragma unroll 4
+        for (int k4 = 0; k4 < KQ / 4; k4++) {
+            f32x4 wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) wv[k] = *reinterpret_cast<const f32x4 *>(w + (4 * k4 + k) * O);
+            const f32x4 x4 = *reinterpret_cast<const f32x4 *>(v + 4 * k4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                a0 = fmaf(wv[k][0], x4[k], a0); a1 = fmaf(wv[k][1], x4[k], a1);
+                a2 = fmaf(wv[k][2], x4[k], a2); a3 = fmaf(wv[k][3], x4[k], a3);
+            }
+        }
+        f32x4 a; a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
+        *reinterpret_cast<f32x4 *>(part + cq * O + o0) = a;
+    }
+    __syncthreads();
+    for (int o = tid; o < O; o += 64 * NQ) {
+        float a = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) a += part[q * O + o];
+        dst[o] = a;
+    }
+    __syncthreads();
+}
+
+// LayerNorm of an LDS-resident row by wave 0 (two-pass, eps 1e-5, gain, no bias: model.py:20); ends with a barrier
+template <int C>
+__device__ __forceinline__ void last1_ln_row(const float *src, const float *__restrict__ gain, float *dst, int tid)
+{
+    if (tid < 64) {
+        float v[(C + 63) / 64], s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < (C + 63) / 64; k++) { v[k] = tid + 64 * k < C ? src[tid + 64 * k] : 0.0f; s += v[k]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / C);
+        float q2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < (C + 63) / 64; k++) { v[k] -= mean; if (tid + 64 * k < C) q2 = fmaf(v[k], v[k], q2); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
+        const float rstd = rsqrtf(q2 * (1.0f / C) + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < (C + 63) / 64; k++)
+            if (tid + 64 * k < C) dst[tid + 64 * k] = v[k] * rstd * gain[tid + 64 * k];
+    }
+    __syncthreads();
+}
+
+// R rows per workgroup.  TAIL (needs R == 1; small launches, one environment): the workgroup goes on with the rest of the network for
+// its row -- the last layer's MLP block (LayerNorm, c_fc, exact-erf GELU, c_proj, residual: model.py:84-89, 103) as fp32 matrix-vector
+// products, ln_f and the tied lm_head (model.py:178, 186) -- and writes logits[row][V]: the last layer and the head are ONE launch.
+// w_t then continues with the transposes of c_fc.weight ([C][4C]) and of mlp.c_proj.weight ([4C][C]).
+template <int C, int HS, int R = kLast1R, bool TAIL = false>
 __global__ __launch_bounds__(256 * last1_split(C))
 void attn_last1_kernel(const float *__restrict__ x, const float *__restrict__ gain, const float *__restrict__ w_k,
-                       const float *__restrict__ w_t, float *__restrict__ x_last, int n_rows, float scale_log2e)
+                       const float *__restrict__ w_t, float *__restrict__ x_last, int n_rows, float scale_log2e,
+                       const float *__restrict__ gain2 = nullptr, const float *__restrict__ gainf = nullptr,
+                       const float *__restrict__ wte = nullptr, float *__restrict__ logits = nullptr, int V = 0)
 {
     static_assert(C % 32 == 0 && C <= 256 && HS == 32, "one thread per feature, 32-wide heads");
     constexpr int S = last1_split(C), NW = 4 * S, CS = C / S;          // waves; features per thread in the token phases
-    constexpr int NH = C / HS, T = 256, TQ = 64, XS = C + 4, R = kLast1R;
-    static_assert(NW * R * C <= TQ * XS && R <= 4 && CS % 8 == 0 && TQ % (4 * S) == 0, "the partial sums alias xT; one wave per row in phase 0");
+    constexpr int NH = C / HS, T = 256, TQ = 64, XS = C + 4;
+    static_assert(!TAIL || R == 1, "the tail runs one row per workgroup");
+    static_assert(NW * R * C <= TQ * XS && (!TAIL || NW * 4 * C <= TQ * XS) && R <= 4 && CS % 8 == 0 && TQ % (4 * S) == 0, "the partial sums alias xT; one wave per row in phase 0");
     extern __shared__ float sm_last1[];
     float *xT = sm_last1;               // [TQ][XS]: normalised rows of 64 tokens, padded so that a wave's b128 row writes spread over the banks
     float *part = xT;                   // [NW][R][C]: partial sums of the matrix-vector products (never live together with xT)
@@ -100,11 +170,12 @@ void attn_last1_kernel(const float *__restrict__ x, const float *__restrict__ ga
     float *qS = v1 + R * C;             // [R][C]: q * scale * log2(e)
     float *yS = qS + R * C;             // [R][C]: y
     float *lnS = yS + R * C;            // [2][S][T]: LayerNorm partial sums
+    float *tl = lnS + 2 * S * T;        // TAIL: x_last row [C] | LN2 row [C] | hidden [4C] | final row [C]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tok = tid & 255, sp = tid >> 8;                          // token phases: token, feature slice [sp CS, sp CS + CS)
     const int64_t b0 = (int64_t)blockIdx.x * R;
     if (b0 >= n_rows) {
-        if (tid < C) {
+        if (!TAIL && tid < C) {
 #pragma unroll
             for (int r = 0; r < R; r++) x_last[xt_off(b0 + r, tid, C)] = 0.0f;
         }
@@ -329,19 +400,44 @@ void attn_last1_kernel(const float *__restrict__ x, const float *__restrict__ ga
     {
         float o[R];
         last1_matvec<C, R, HS, NW, false>(w_t + 2 * C * C, yS, C, part, tid, o);
-        if (tid < C) {
+        if constexpr (!TAIL) {
+            if (tid < C) {
 #pragma unroll
-            for (int r = 0; r < R; r++)
-                x_last[xt_off(b0 + r, tid, C)] = r < nr ? x[xt_off((b0 + r) * T + T - 1, tid, C)] + o[r] : 0.0f;
+                for (int r = 0; r < R; r++)
+                    x_last[xt_off(b0 + r, tid, C)] = r < nr ? x[xt_off((b0 + r) * T + T - 1, tid, C)] + o[r] : 0.0f;
+            }
+        } else {
+            if (tid < C) tl[tid] = x[xt_off(b0 * T + T - 1, tid, C)] + o[0];
+        }
+    }
+    if constexpr (TAIL) {
+        float *xl = tl, *xn2 = tl + C, *hS = tl + 2 * C, *xf = tl + 6 * C;
+        __syncthreads();
+        // ---- MLP block of the row: x + c_proj(GELU(c_fc(LayerNorm(x)))) ----
+        last1_ln_row<C>(xl, gain2, xn2, tid);
+        last1_matvec1<C, 4 * C, NW>(w_t + 3 * C * C, xn2, part, hS, tid);
+        for (int j = tid; j < 4 * C; j += 64 * NW) { const float v = hS[j]; hS[j] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+        __syncthreads();
+        last1_matvec1<4 * C, C, NW>(w_t + 3 * C * C + 4 * C * C, hS, part, xf, tid);
+        if (tid < C) xf[tid] += xl[tid];
+        __syncthreads();
+        // ---- ln_f and the tied head ----
+        last1_ln_row<C>(xf, gainf, xn2, tid);
+        for (int v = tid; v < V; v += 64 * NW) {
+            const float *wr = wte + (size_t)v * C;
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int c = 0; c < C; c++) acc = fmaf(wr[c], xn2[c], acc);
+            logits[(size_t)b0 * V + v] = acc;
         }
     }
 }
 
-// dst[c][r] = src[r][c] for an n x n fp32 matrix (model build, once)
-__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, float *__restrict__ dst, int n)
+// dst[c][r] = src[r][c] for a rows x cols fp32 matrix (model build, once)
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, float *__restrict__ dst, int rows, int cols)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n * n) dst[(i % n) * n + i / n] = src[i];
+    if (i < rows * cols) dst[(i % cols) * rows + i / cols] = src[i];
 }
 
 }  // namespace fastk
