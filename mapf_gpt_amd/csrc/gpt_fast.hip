@@ -37,6 +37,12 @@ constexpr bool kAttn160o = false;
 #else
 constexpr bool kAttn160o = true;
 #endif
+// -DMGPT_AB_NO_LN_FOLD keeps ln_pack_kernel in the one-plane packed-GEMM chain
+#ifdef MGPT_AB_NO_LN_FOLD
+constexpr bool kLnFold = false;
+#else
+constexpr bool kLnFold = true;
+#endif
 #ifdef MGPT_AB_NO_LAST1_TAIL
 constexpr bool kLast1Tail = false;
 #else
@@ -108,6 +114,12 @@ struct ModeState {          // one precision mode
     bool pk_gemm = false;
     std::vector<uint16_t *> attn_pk2, proj_pk2, fc_pk2, proj2_pk2;   // [row tile][k-step][plane][lane][8]
     uint16_t *apk = nullptr;                   // LayerNorm'ed rows in PK layout, [M/32][C/16][NP][512]
+    // folded LayerNorm (GemmArgs in gpt_kernels_fast.h; one-plane mode of the packed-GEMM chain): apk holds the RAW rows, written by the
+    // residual epilogues; W * ln.weight packings, their column sums, the epilogues' partial row sums
+    bool ln_fold = false;
+    std::vector<uint16_t *> attn_pk2g, fc_pk2g;
+    std::vector<float *> attn_cs, fc_cs;
+    float2 *ln_parts = nullptr;                // [C / 128][M]
 };
 
 struct FastState {
@@ -393,6 +405,30 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                      lds + fastk::kGeluLutN * 8));
         if (!(C == 256 && m->mlp_fused && g->hs == 32 && g->nh == 8))      // LayerNorm planes of the GEMM chain (the 6M kernels normalise in registers)
             MGPT_HIP(hipMalloc(&m->apk, (size_t)g->max_rows * kT * C * NP * sizeof(uint16_t)));
+        // one-plane mode of the full chain (no fused kernels): LayerNorm folded into the GEMMs (GemmArgs) -- ln_pack_kernel, which
+        // re-reads every residual row to normalise it (8 % of an 85M step), runs once per forward instead of twice per layer
+        m->ln_fold = kLnFold && NP == 1 && !m->mlp_fused && m->apk != nullptr;
+        if (m->ln_fold) {
+            m->attn_pk2g.assign(g->L, nullptr); m->fc_pk2g.assign(g->L, nullptr); m->attn_cs.assign(g->L, nullptr); m->fc_cs.assign(g->L, nullptr);
+            auto packg = [&](std::vector<uint16_t *> &dst, std::vector<float *> &cs, size_t off, size_t goff, size_t R, size_t K, float scale, int l) -> int {
+                MGPT_HIP(hipMalloc(&dst[l], R * K * NP * sizeof(uint16_t)));
+                MGPT_HIP(hipMalloc(&cs[l], R * sizeof(float)));
+                ProfScope ps(P_PACK, nullptr);
+                hipLaunchKernelGGL((fastk::pack_pk_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)(R / 32) * (K / 16) * 64, 256)), dim3(256), 0,
+                                   nullptr, g->params + off, dst[l], (int)R, (int)K, scale, g->params + goff);
+                MGPT_LAUNCH_CHECK();
+                hipLaunchKernelGGL((fastk::colsum_pk_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)R, 256)), dim3(256), 0, nullptr, g->params + off,
+                                   g->params + goff, cs[l], (int)R, (int)K, scale);
+                MGPT_LAUNCH_CHECK();
+                return MGPT_OK;
+            };
+            for (int l = 0; l < g->L; l++) {
+                const LayerOff &lo = g->layers[l];
+                if ((rc = packg(m->attn_pk2g, m->attn_cs, lo.attn_w, lo.ln1, 3 * C, C, 1.0f / m->attn[l].inv_scale, l)) != MGPT_OK) return rc;
+                if ((rc = packg(m->fc_pk2g, m->fc_cs, lo.fc_w, lo.ln2, 4 * C, C, 1.0f / m->fc[l].inv_scale, l)) != MGPT_OK) return rc;
+            }
+            MGPT_HIP(hipMalloc(&m->ln_parts, (size_t)(C / 128) * g->max_rows * kT * sizeof(float2)));
+        }
     }
     {
         const size_t nl = (size_t)((g->max_rows + 255) / 256) * 256 * C;
@@ -446,6 +482,11 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     (void)hipFree(m->y_last);
     (void)hipFree(m->head_parts);
     (void)hipFree(m->last1_wt);
+    for (auto p : m->attn_pk2g) (void)hipFree(p);
+    for (auto p : m->fc_pk2g) (void)hipFree(p);
+    for (auto p : m->attn_cs) (void)hipFree(p);
+    for (auto p : m->fc_cs) (void)hipFree(p);
+    (void)hipFree(m->ln_parts);
     for (auto p : m->attn160o_pk) (void)hipFree(p);
     (void)hipFree(m->attn160o_spill);
     for (auto *p : m->mlp160_pk) (void)hipFree(p);
@@ -546,6 +587,23 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         else hipLaunchKernelGGL((fastk::embed_stats_kernel<4>), grid, dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, m->stats, M, C);
         MGPT_LAUNCH_CHECK();
     }
+    // folded LayerNorm: (mean, rstd) of the rows the next GEMM normalises live in m->stats, their raw operand planes in m->apk
+    auto ln_finalize = [&](int64_t Mrows) -> int {
+        ProfScope ps(P_LAYERNORM, s);
+        hipLaunchKernelGGL(fastk::ln_finalize_kernel, dim3((unsigned)cdiv64(Mrows, 256)), dim3(256), 0, s, m->ln_parts, C / 128, Mrows, C, m->stats);
+        MGPT_LAUNCH_CHECK();
+        return MGPT_OK;
+    };
+    if (m->ln_fold) {                                          // the embedding rows: the one ln_pack_kernel launch of the forward (raw mode)
+        ProfScope ps(P_LAYERNORM, s);
+        const dim3 grid((unsigned)(M / 32));
+        const float *g0 = P + g->layers[0].ln1;
+        if (C == 256) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 4>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats);
+        else if (C == 512) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 8>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats);
+        else if (C == 768) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 12>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats);
+        else hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 16>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats);
+        MGPT_LAUNCH_CHECK();
+    }
     const float scale_log2e = (1.0f / sqrtf((float)g->hs)) * 1.44269504088896340736f;
     const size_t attn_lds = (size_t)NP * (kT * (g->hs + 8) * 2 + g->hs * (kT + 8) * 2);
     for (int l = 0; l < g->L; l++) {
@@ -632,14 +690,20 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                                    m->attn256_pk[l], m->attn256_inv[l], scale_log2e, m->y[0], (unsigned long long *)nullptr);
             MGPT_LAUNCH_CHECK();
         } else if (m->pk_gemm) {
-            if ((rc = launch_ln_pack<T, NP>(g->x, P + lo.ln1, m->apk, M, C, m->x_tiled ? 1 : 0, s)) != MGPT_OK) return rc;
+            // (folded LayerNorm: m->apk already holds the raw rows -- from the embedding or from the residual epilogue before -- and
+            //  m->stats their (mean, rstd); the W * ln_1.weight packing and its column sums do the rest in the epilogue)
+            if (!m->ln_fold && (rc = launch_ln_pack<T, NP>(g->x, P + lo.ln1, m->apk, M, C, m->x_tiled ? 1 : 0, s)) != MGPT_OK) return rc;
             ProfScope ps(P_GEMM_QKV, s);
             const size_t tile_halves = (size_t)(C / 16) * NP * 512;          // one 32-row tile of a PK matrix with K = C
-            a.a_hi = m->apk; a.w_hi = m->attn_pk2[l]; a.chunk_major = 1;
+            const uint16_t *wq = m->ln_fold ? m->attn_pk2g[l] : m->attn_pk2[l];
+            a.a_hi = m->apk; a.w_hi = wq; a.chunk_major = 1;
+            if (m->ln_fold) { a.ln_stats = m->stats; a.colsum = m->attn_cs[l]; }
             if ((rc = launch_gemm_pk<T, NP, fastk::EPI_QK>(a, s)) != MGPT_OK) return rc;
-            a.w_hi = m->attn_pk2[l] + (size_t)(2 * C / 32) * tile_halves;    // rows 2C.. of c_attn.weight: V
+            a.w_hi = wq + (size_t)(2 * C / 32) * tile_halves;                // rows 2C.. of c_attn.weight: V
+            if (m->ln_fold) a.colsum = m->attn_cs[l] + 2 * C;
             a.N = C; a.o_hi = m->vt[0]; a.o_lo = m->vt[1];
             if ((rc = launch_gemm_pk<T, NP, fastk::EPI_VT>(a, s)) != MGPT_OK) return rc;
+            a.ln_stats = nullptr; a.colsum = nullptr;
         } else {
             ProfScope ps(P_GEMM_QKV, s);
             if ((rc = launch_gemm16<T, NP, fastk::PRO_LN, fastk::EPI_QK>(a, C, s)) != MGPT_OK) return rc;
@@ -674,7 +738,9 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             ProfScope ps(ls ? P_GEMM_PROJ_LAST : P_GEMM_PROJ, s);
             if (m->pk_gemm) {
                 a.w_hi = m->proj_pk2[l];
+                if (m->ln_fold) { a.raw_out = m->apk; a.rsum_out = m->ln_parts; }      // the rows ln_2 normalises: planes + partial sums
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
+                a.raw_out = nullptr; a.rsum_out = nullptr;
             } else if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
         if (!fused_stats(C) && !m->pk_gemm && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
@@ -726,20 +792,26 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         }
         if (m->pk_gemm) {
             // ---- LN2 -> PK planes; FC + GELU -> hidden PK planes; proj2 + residual ----
-            if ((rc = launch_ln_pack<T, NP>(mlp_x, P + lo.ln2, m->apk, mlp_M, C, m->x_tiled ? 1 : 0, s)) != MGPT_OK) return rc;
+            if (m->ln_fold) { if ((rc = ln_finalize(mlp_M)) != MGPT_OK) return rc; }
+            else if ((rc = launch_ln_pack<T, NP>(mlp_x, P + lo.ln2, m->apk, mlp_M, C, m->x_tiled ? 1 : 0, s)) != MGPT_OK) return rc;
             a.M = (int)mlp_M;
-            a.a_hi = m->apk; a.K = C; a.N = 4 * C; a.w_hi = m->fc_pk2[l]; a.out_scale = m->fc[l].inv_scale;
+            a.a_hi = m->apk; a.K = C; a.N = 4 * C; a.w_hi = m->ln_fold ? m->fc_pk2g[l] : m->fc_pk2[l]; a.out_scale = m->fc[l].inv_scale;
             a.o_hi = m->hbuf[0]; a.o_pk = 1; a.gelu_lut = m->gelu_lut;
+            if (m->ln_fold) { a.ln_stats = m->stats; a.colsum = m->fc_cs[l]; }
             {
                 ProfScope ps(P_GEMM_FC, s);
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_GELU>(a, s)) != MGPT_OK) return rc;
             }
+            a.ln_stats = nullptr; a.colsum = nullptr;
             a.a_hi = m->hbuf[0]; a.K = 4 * C; a.N = C; a.w_hi = m->proj2_pk2[l]; a.out_scale = m->proj2[l].inv_scale;
             a.x_out = mlp_x; a.stats_out = nullptr;
+            const bool feeds_next = m->ln_fold && l + 1 < g->L;            // the rows the next layer's ln_1 normalises
+            if (feeds_next) { a.raw_out = m->apk; a.rsum_out = m->ln_parts; }
             {
                 ProfScope ps(P_GEMM_PROJ2, s);
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
             }
+            if (feeds_next && (rc = ln_finalize(mlp_M)) != MGPT_OK) return rc;
             continue;
         }
         // ---- LN2 + FC + GELU -> hidden planes ----

@@ -291,6 +291,13 @@ struct GemmArgs {
     int stagger;                                                     // gemm_pk_kernel: start-up spread of the CUs, x 64 cycles (see there)
     int x_tiled;                                                     // EPI_RESID: x_out is chunk-major (xt_off) instead of row-major
     unsigned *cu_arrivals;                                           // gemm_pk_kernel<.., NWV = 4>: per-CU arrival counters (see there) or NULL
+    // LayerNorm folded into the GEMM chain (one-plane mode, C > 256; gpt_fast.hip `ln_fold`): the A operand is the RAW residual row
+    // in operand planes and W carries ln.weight, so acc[m][n] = sum_k x[m][k] W'[n][k]; the consumer's epilogue forms
+    // rstd[m] * (acc - mean[m] * colsum[n]) = sum_k LayerNorm(x)[m][k] W[n][k].  No kernel reads x to normalise it.
+    const float2 *ln_stats;                                          // consumers (EPI_QK / EPI_VT / EPI_GELU): (mean, rstd) per row, or NULL
+    const float *colsum;                                             // consumers: sum over k of the packed (rounded, scaled) W'[n][k]
+    uint16_t *raw_out;                                               // EPI_RESID: operand planes (PK, K = N) of the new residual rows, or NULL
+    float2 *rsum_out;                                                // EPI_RESID: (sum, sum of squares) of the new rows per 128-column block: [N / 128][M]
 };
 
 // Chunk-major residual stream: x[M][C] stored as [M / 32][C / 8][32 tokens][8 floats].  A wave whose lane (r, h) owns token r
@@ -406,6 +413,22 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
         // v^T planes [rows][n_head][hs][256]
         const int64_t b = m0 >> 8;
         const int tb = (int)(m0 & (kT - 1));
+        if (p.ln_stats != nullptr) {                                           // folded LayerNorm (GemmArgs): registers = tokens here
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const float2 *st = p.ln_stats + m0 + (wm * TM + i) * 32 + 8 * gq + 4 * h;
+                    const f32x4 s01 = *reinterpret_cast<const f32x4 *>(st), s23 = *reinterpret_cast<const f32x4 *>(st + 2);
+                    const float mean[4] = {s01[0], s01[2], s23[0], s23[2]}, rstd[4] = {s01[1], s01[3], s23[1], s23[3]};
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        const float cs = p.colsum[n0 + (wn * TN + j) * 32 + r];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[i][j][4 * gq + e] = rstd[e] * fmaf(-mean[e], cs, acc[i][j][4 * gq + e]);
+                    }
+                }
+        }
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int n = n0 + (wn * TN + j) * 32 + r;                         // column inside V (n_base handled by the W pointer)
@@ -428,9 +451,24 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
         }
     } else {
         // swapped: lane = token m, registers = 4 consecutive output columns per quad
-        float rsum[TM];
+        float rsum[TM], rsq[TM];
 #pragma unroll
-        for (int i = 0; i < TM; i++) rsum[i] = 0.f;
+        for (int i = 0; i < TM; i++) { rsum[i] = 0.f; rsq[i] = 0.f; }
+        if (EPI != EPI_RESID && p.ln_stats != nullptr) {                       // folded LayerNorm (GemmArgs): lane = token
+            // (hoisting the column sums of a tile out of the row loop -- 16 registers -- made the epilogues slower, round 4)
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const float2 st = p.ln_stats[m0 + (wm * TM + i) * 32 + r];
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const f32x4 cs = *reinterpret_cast<const f32x4 *>(p.colsum + n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[i][j][4 * gq + e] = st.y * fmaf(-st.x, cs[e], acc[i][j][4 * gq + e]);
+                    }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int64_t m = m0 + (wm * TM + i) * 32 + r;
@@ -459,7 +497,20 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
                             *reinterpret_cast<f32x4 *>(p.x_out + (p.x_tiled ? xt_off(m, n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h, p.N)
                                                                              : m * p.N + n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h)) = c;
                             rsum[i] += (c[0] + c[1]) + (c[2] + c[3]);
+                            if (p.raw_out != nullptr) {                        // the next GEMM's A operand: the raw row in operand planes
+                                rsq[i] += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+                                const int n = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h;
+                                const float v[4] = {c[0], c[1], c[2], c[3]};
+                                u32x2 hi, lo;
+                                split4<T, NP>(v, hi, lo);
+                                *reinterpret_cast<u32x2 *>(p.raw_out + pk_off(m, n, 0, p.N >> 4, NP)) = hi;
+                                if (NP == 2) *reinterpret_cast<u32x2 *>(p.raw_out + pk_off(m, n, 1, p.N >> 4, NP)) = lo;
+                            }
                         }
+                }
+                if (p.rsum_out != nullptr) {                                   // this wave's 128 columns of the row: one partial, fixed place
+                    const float s1 = rsum[i] + __shfl_xor(rsum[i], 32), s2 = rsq[i] + __shfl_xor(rsq[i], 32);
+                    if (h == 0) p.rsum_out[(size_t)((n0 + wn * TN * 32) >> 7) * (size_t)p.M + m] = make_float2(s1, s2);
                 }
                 continue;
             }
@@ -706,7 +757,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p)
 // ---------------------------------------------------------------------------------------------
 template <class T, int NP>
 __global__ __launch_bounds__(256) void pack_pk_kernel(const float *__restrict__ w, uint16_t *__restrict__ out, int R, int K,
-                                                      float scale)
+                                                      float scale, const float *__restrict__ gain = nullptr)
 {
     const int KS = K >> 4;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (row tile, k-step, lane)
@@ -716,6 +767,11 @@ __global__ __launch_bounds__(256) void pack_pk_kernel(const float *__restrict__ 
     float v0[4], v1[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) { v0[e] = src[e] * scale; v1[e] = src[4 + e] * scale; }
+    if (gain != nullptr) {                                                // W * ln.weight (folded LayerNorm, GemmArgs)
+        const float *gk = gain + ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v0[e] = src[e] * gk[e] * scale; v1[e] = src[4 + e] * gk[4 + e] * scale; }
+    }
     u32x2 h0, l0, h1, l1;
     split4<T, NP>(v0, h0, l0);
     split4<T, NP>(v1, h1, l1);
@@ -727,13 +783,48 @@ __global__ __launch_bounds__(256) void pack_pk_kernel(const float *__restrict__ 
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
 }
 
+// colsum[n] = sum_k of the values pack_pk_kernel stored for row n (W[n][k] * gain[k] * scale rounded to the operand type, hi + lo):
+// what sum_k x[m][k] W'[n][k] yields for a row of ones -- the mean term of the folded LayerNorm (GemmArgs).  One thread per row,
+// k in index order.
+template <class T, int NP>
+__global__ __launch_bounds__(256) void colsum_pk_kernel(const float *__restrict__ w, const float *__restrict__ gain, float *__restrict__ colsum,
+                                                        int R, int K, float scale)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= R) return;
+    const float *src = w + (size_t)n * K;
+    float s = 0.f;
+    for (int k = 0; k < K; k++) {
+        const float v = src[k] * gain[k] * scale;
+        const uint16_t hi = T::cvt(v);
+        float r = T::back(hi);
+        if (NP == 2) r += T::back(T::cvt(v - r));
+        s += r;
+    }
+    colsum[n] = s;
+}
+
+// (mean, rstd) of every row from the per-128-column partial sums an EPI_RESID epilogue left (GemmArgs::rsum_out), added in block order
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2 *__restrict__ parts, int n_parts, int64_t M, int C, float2 *__restrict__ stats)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = 0; q < n_parts; q++) { const float2 v = parts[(size_t)q * M + m]; s1 += v.x; s2 += v.y; }
+    const float mean = s1 / (float)C;
+    const float var = fmaxf(s2 / (float)C - mean * mean, 0.f);
+    stats[m] = make_float2(mean, rsqrtf(var + 1e-5f));
+}
+
 // LayerNorm + split into PK operand planes, statistics computed here: a workgroup owns one 32-token tile, every lane
 // keeps its share of the row (C/8 floats) in registers between the mean, the centred variance (two-pass, as
 // model.py:19-20 / F.layer_norm) and the normalisation, so x is read exactly once; wave w writes the whole 1 KiB
 // fragments of k-steps w, w+4, ...
 template <class T, int NP, int KSW>                        // KSW = k-steps per wave = C / 64
+// raw_stats != NULL (folded LayerNorm, GemmArgs: used once per forward, for the embedding rows): the planes carry the RAW row and
+// (mean, rstd) go to raw_stats instead.
 __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ x, const float *__restrict__ gain,
-                                                      uint16_t *__restrict__ out, int C, int tiled)
+                                                      uint16_t *__restrict__ out, int C, int tiled, float2 *__restrict__ raw_stats = nullptr)
 {
     __shared__ float red[2][8][32];
     const int KS = C >> 4;
@@ -779,6 +870,10 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
         float v0[4], v1[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) { v0[e] = (va[i][e] - mean) * rstd * ga[e]; v1[e] = (vb[i][e] - mean) * rstd * gb[e]; }
+        if (raw_stats != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v0[e] = va[i][e]; v1[e] = vb[i][e]; }
+        }
         u32x2 h0, l0, h1, l1;
         split4<T, NP>(v0, h0, l0);
         split4<T, NP>(v1, h1, l1);
@@ -789,6 +884,7 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
         *reinterpret_cast<u32x4 *>(dst) = hi;
         if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
     }
+    if (raw_stats != nullptr && wave == 0 && h == 0) raw_stats[m] = make_float2(mean, rstd);
 }
 
 // 8 waves of 64 x 128 (2 x 4 MFMA tiles, 256 registers, two waves per SIMD: the second wave on the SIMD covers part of the
