@@ -197,3 +197,22 @@ def test_head_parallel_small_launch_vs_row_per_workgroup_path(name, precision):
         sd, args = weights.synthetic_state_dict(name, seed=0), weights.model_args(name)
         ref = gpt_oracle.forward_logits(sd, args, rows[:40]).numpy()
         assert np.abs(small[:40] - ref).max() <= TOL and np.abs(big[:40] - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("name,precision", [("2M", "f16x3"), ("6M", "f16x3"), ("6M", "bf16")])
+def test_persistent_kernels_uneven_grid(name, precision):
+    """The persistent attention kernels (attn256o_kernel, attn160o_kernel; grid = min(rows, CUs), a workgroup walks rows b, b + grid, ...)
+    with a row count that is not a multiple of the grid: 600 rows on 256 CUs = 88 workgroups take 3 rows, 168 take 2, and the last
+    layer's attn_last1_kernel handles 150 workgroups of 4.  A row's logits are bit-identical to the same row in a 200-row launch (one
+    row per workgroup) and, in the 1e-5 mode, within the bar of the reference goldens."""
+    from mapf_gpt_amd.model import build_model
+    g = np.load(os.path.join(GOLDEN, f"gptbig_{name}_s1.npz"))
+    base = g["tokens"]                                                   # 256 distinct rows
+    rows = np.ascontiguousarray(np.concatenate([base, base[::-1], base[:88]]))        # 600 rows
+    net = build_model(name, seed=0, max_rows=600, precision=precision)
+    big = net.logits_tokens(torch.from_numpy(rows).cuda()).cpu().numpy()
+    small = net.logits_tokens(torch.from_numpy(np.ascontiguousarray(rows[:200])).cuda()).cpu().numpy()
+    assert np.array_equal(big[:200], small)
+    assert np.array_equal(big[256:512], big[:256][::-1]) and np.array_equal(big[512:], big[:88])
+    if precision == "f16x3":
+        assert np.abs(big[:256] - g["logits_f32"]).max() <= TOL
