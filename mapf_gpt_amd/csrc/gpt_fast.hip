@@ -403,6 +403,10 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      lds + fastk::kGeluLutN * 8));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 8, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds + 3072));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT, 8, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds + 3072));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     lds + fastk::kGeluLutN * 8 + 3072));
         if (!(C == 256 && m->mlp_fused && g->hs == 32 && g->nh == 8))      // LayerNorm planes of the GEMM chain (the 6M kernels normalise in registers)
             MGPT_HIP(hipMalloc(&m->apk, (size_t)g->max_rows * kT * C * NP * sizeof(uint16_t)));
         // one-plane mode of the full chain (no fused kernels): LayerNorm folded into the GEMMs (GemmArgs) -- ln_pack_kernel, which
@@ -526,8 +530,14 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
     a.n_tiles_n = a.N / 256;
     if (EPI == fastk::EPI_RESID) a.stats_out = nullptr;               // rows span two waves: stats come from row_stats_kernel
     const bool lut = EPI == fastk::EPI_GELU && a.gelu_lut != nullptr;
-    hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
-                       (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0), s, a, (unsigned long long *)nullptr);
+    if (EPI != fastk::EPI_RESID && a.ln_stats != nullptr) {          // folded LayerNorm (GemmArgs): the Phi table slot is always reserved
+        MGPT_REQUIRE(EPI != fastk::EPI_GELU || lut, MGPT_ERR_STATE, "%s", "folded LayerNorm: the GELU epilogue needs the Phi table");
+        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8, 0, true>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
+                           (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0) + 3072, s, a, (unsigned long long *)nullptr);
+    } else {
+        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
+                           (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0), s, a, (unsigned long long *)nullptr);
+    }
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }

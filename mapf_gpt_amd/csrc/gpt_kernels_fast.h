@@ -403,9 +403,11 @@ __device__ __forceinline__ size_t pk_off(int64_t m, int k, int pl, int KS, int N
 
 // Epilogues shared by gemm16_kernel and gemm_pk_kernel.  acc[i][j] is the 32x32 tile (row tile wm*TM+i, column
 // tile wn*TN+j) of the block; swapped orientation (EPI != EPI_VT): lane = token, registers = output columns.
-template <class T, int NP, int EPI, int TM, int TN, int WN>
+// LNF (gemm_pk_kernel, folded LayerNorm: GemmArgs): cs_addr = LDS address of this block's 256 column sums, followed by the (mean, rstd)
+// pairs of its 256 rows.
+template <class T, int NP, int EPI, int TM, int TN, int WN, bool LNF = false>
 __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn,
-                                                int r, int h, unsigned lut_addr = 0u)
+                                                int r, int h, unsigned lut_addr = 0u, unsigned cs_addr = 0u)
 {
     const float os = p.out_scale;
     if (EPI == EPI_VT) {
@@ -413,20 +415,25 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
         // v^T planes [rows][n_head][hs][256]
         const int64_t b = m0 >> 8;
         const int tb = (int)(m0 & (kT - 1));
-        if (p.ln_stats != nullptr) {                                           // folded LayerNorm (GemmArgs): registers = tokens here
+        if constexpr (LNF) {                                                   // folded LayerNorm (GemmArgs): registers = tokens here
+            float cs[TN];
+#pragma unroll
+            for (int j = 0; j < TN; j++) asm volatile("ds_read_b32 %0, %1" : "=v"(cs[j]) : "v"(cs_addr + (unsigned)((wn * TN + j) * 32 + r) * 4u) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {
-                    const float2 *st = p.ln_stats + m0 + (wm * TM + i) * 32 + 8 * gq + 4 * h;
-                    const f32x4 s01 = *reinterpret_cast<const f32x4 *>(st), s23 = *reinterpret_cast<const f32x4 *>(st + 2);
+                    f32x4 s01, s23;                                            // (mean, rstd) of 4 consecutive tokens, from the block's LDS copy
+                    const unsigned sa = cs_addr + 1024u + (unsigned)((wm * TM + i) * 32 + 8 * gq + 4 * h) * 8u;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(s01) : "v"(sa) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(s23) : "v"(sa) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s01), "+v"(s23) : : "memory");
                     const float mean[4] = {s01[0], s01[2], s23[0], s23[2]}, rstd[4] = {s01[1], s01[3], s23[1], s23[3]};
 #pragma unroll
-                    for (int j = 0; j < TN; j++) {
-                        const float cs = p.colsum[n0 + (wn * TN + j) * 32 + r];
+                    for (int j = 0; j < TN; j++)
 #pragma unroll
-                        for (int e = 0; e < 4; e++) acc[i][j][4 * gq + e] = rstd[e] * fmaf(-mean[e], cs, acc[i][j][4 * gq + e]);
-                    }
+                        for (int e = 0; e < 4; e++) acc[i][j][4 * gq + e] = rstd[e] * fmaf(-mean[e], cs[j], acc[i][j][4 * gq + e]);
                 }
         }
 #pragma unroll
@@ -454,24 +461,36 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
         float rsum[TM], rsq[TM];
 #pragma unroll
         for (int i = 0; i < TM; i++) { rsum[i] = 0.f; rsq[i] = 0.f; }
-        if (EPI != EPI_RESID && p.ln_stats != nullptr) {                       // folded LayerNorm (GemmArgs): lane = token
-            // (hoisting the column sums of a tile out of the row loop -- 16 registers -- made the epilogues slower, round 4)
+        f32x2 st[TM];                                                          // LNF: (mean, rstd) of this lane's tokens
 #pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const float2 st = p.ln_stats[m0 + (wm * TM + i) * 32 + r];
+        for (int i = 0; i < TM; i++) st[i] = (f32x2){0.f, 1.f};
+        if constexpr (LNF && EPI != EPI_RESID) {                               // folded LayerNorm (GemmArgs): lane = token
+            // the block's column sums sit in LDS (one 1-KiB piece fetched at kernel start): a column tile's four quads per round trip;
+            // acc <- acc - mean * colsum here, the factor rstd rides on the output scale below
 #pragma unroll
-                for (int j = 0; j < TN; j++)
+            for (int i = 0; i < TM; i++)
+                asm volatile("ds_read_b64 %0, %1" : "=v"(st[i]) : "v"(cs_addr + 1024u + (unsigned)((wm * TM + i) * 32 + r) * 8u) : "memory");
 #pragma unroll
-                    for (int gq = 0; gq < 4; gq++) {
-                        const f32x4 cs = *reinterpret_cast<const f32x4 *>(p.colsum + n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h);
+            for (int j = 0; j < TN; j++) {
+                f32x4 cs[4];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) acc[i][j][4 * gq + e] = st.y * fmaf(-st.x, cs[e], acc[i][j][4 * gq + e]);
-                    }
+                for (int gq = 0; gq < 4; gq++)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(cs[gq]) : "v"(cs_addr + (unsigned)((wn * TN + j) * 32 + 8 * gq + 4 * h) * 4u) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]) : : "memory");
+                if (j == 0) asm volatile("" : "+v"(st[0]), "+v"(st[TM - 1]));
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int g = 0; g < 16; g++) acc[i][j][g] = fmaf(-st[i][0], cs[g >> 2][g & 3], acc[i][j][g]);
+                // (volatile: the tile's arithmetic stays in front of the next tile's reads -- hipcc otherwise reads all 16 quads first and spills)
+                static_assert(TM == 2, "the pin below names both row tiles");
+                asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]));
             }
         }
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int64_t m = m0 + (wm * TM + i) * 32 + r;
+            const float osi = (LNF && EPI != EPI_RESID) ? os * st[i][1] : os;  // output scale of this lane's row
             if (EPI == EPI_RESID) {
                 // read-modify-write of the residual rows: the reads of two column tiles (8 x 16 B per lane) are all in flight
                 // before the first store -- one memory round trip per pair of tiles instead of one per 16-byte piece
@@ -523,7 +542,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
                     f32x2 tb[16];
 #pragma unroll
                     for (int g = 0; g < 16; g++) {
-                        v[g] = acc[i][j][g] * os;
+                        v[g] = acc[i][j][g] * osi;
                         const float tt = __builtin_amdgcn_fmed3f(fmaf(v[g], kGeluLutScale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.002f);
                         fr[g] = __builtin_amdgcn_fractf(tt);
                         asm volatile("ds_read_b64 %0, %1" : "=v"(tb[g]) : "v"(lut_addr + (unsigned)tt * 8u) : "memory");
@@ -555,8 +574,8 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {
                     const int n = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h;   // first of 4 consecutive columns
-                    float v[4] = {acc[i][j][4 * gq] * os, acc[i][j][4 * gq + 1] * os, acc[i][j][4 * gq + 2] * os,
-                                  acc[i][j][4 * gq + 3] * os};
+                    float v[4] = {acc[i][j][4 * gq] * osi, acc[i][j][4 * gq + 1] * osi, acc[i][j][4 * gq + 2] * osi,
+                                  acc[i][j][4 * gq + 3] * osi};
                     if (EPI == EPI_GELU) {
                         if (TM * TN >= 16) {          // one-wave-per-SIMD kernel: packed math
                             const f32x2 g0 = gelu_folded2((f32x2){v[0], v[1]}), g1 = gelu_folded2((f32x2){v[2], v[3]});
@@ -901,7 +920,9 @@ constexpr int gemm_pk_kps(int NP) { return 1; }
 constexpr int gemm_pk_nst(int NP, int NWV = 8, int EPI = 0) { return NWV == 8 ? (NP == 2 ? 4 : 6) : (NP == 2 ? 3 : (EPI == EPI_GELU ? 4 : 6)); }
 constexpr int gemm_pk_lds(int NP, int NWV = 8, int EPI = 0) { return gemm_pk_nst(NP, NWV, EPI) * (NWV + 8) * gemm_pk_kps(NP) * NP * 1024; }   // + the Phi table when used
 
-template <class T, int NP, int EPI, int NWV, int DBG = 0>
+// LNF (folded LayerNorm, GemmArgs): the block's 256 column sums and the (mean, rstd) of its 256 rows are three more 1-KiB pieces in LDS,
+// behind the ring and the Phi table.
+template <class T, int NP, int EPI, int NWV, int DBG = 0, bool LNF = false>
 __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsigned long long *stamps = nullptr)
 {
     static_assert(NWV == 8 || NWV == 4, "8 or 4 waves of 64 x 128");
@@ -957,6 +978,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
             __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)(wave + NWV * i) * 1024 + lane * 16),
                                              (lds_void_t *)(dst + (size_t)(wave + NWV * i) * 1024), 16, 0, 0);
         lut_addr = (unsigned)(size_t)dst;
+    }
+    unsigned cs_addr = 0u;
+    if constexpr (LNF) {                                   // (older than every ring piece too; wave 0 only: a wave's counted waits stay exact)
+        unsigned char *dst = smem + (size_t)NST * STAGE + (EPI == EPI_GELU ? kGeluLutN * 8 : 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.colsum + nt * 256) + lane * 16), (lds_void_t *)dst, 16, 0, 0);
+        if (wave == 1 || wave == 2)                        // (mean, rstd) of the block's 256 rows: 2 KiB
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.ln_stats + (size_t)mt * (AF * 32)) + (wave - 1) * 1024 + lane * 16),
+                                             (lds_void_t *)(dst + wave * 1024), 16, 0, 0);
+        cs_addr = (unsigned)(size_t)dst;
     }
 #pragma unroll
     for (int S = 0; S < NST - 1; S++) issue(S);            // K >= 16 * KPS * NST is checked by the launcher
@@ -1044,7 +1075,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
         }
     }
     if constexpr (DBG != 0) { asm volatile("s_nop 0" ::: "memory"); ts[3] = __builtin_readcyclecounter(); }
-    gemm16_epilogue<T, NP, EPI, TM, TN, 2>(p, acc, (int64_t)mt * (AF * 32), nt * 256, wm, wn, r, h, lut_addr);
+    gemm16_epilogue<T, NP, EPI, TM, TN, 2, LNF>(p, acc, (int64_t)mt * (AF * 32), nt * 256, wm, wn, r, h, lut_addr, cs_addr);
     if constexpr (DBG != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = __builtin_readcyclecounter(); ts[5] = wall_clock64();
