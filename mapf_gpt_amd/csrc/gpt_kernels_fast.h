@@ -1533,17 +1533,29 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(float *__restrict
     }
 
     // ---- residual add, store, LayerNorm statistics of the new row for the next kernel ----
+    // (the row's addresses are formed again here from an opaque copy of xt: as values shared with the prologue's loads hipcc kept five 64-bit
+    //  bases alive across the tile loop in scratch and reloaded them between the residual loads, one memory round trip per reload; and
+    //  all residual reads are in flight before the first store -- the stores to x would otherwise keep the next read from moving up)
+    //  (split mode; the one-plane variant never spilled and is 2.6 % faster with the plain read-modify-write loop: A/B, round 4)
+    float *xt2 = xt;
+    if (NP == 2) asm volatile("" : "+v"(xt2));
     float s2 = 0.f;
+    f32x4 cur[CT][4];
+    if (NP == 2) {
+#pragma unroll
+        for (int j = 0; j < CT; j++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) cur[j][gq] = *reinterpret_cast<const f32x4 *>(xt2 + (4 * j + gq) * 256);
+    }
 #pragma unroll
     for (int j = 0; j < CT; j++)
 #pragma unroll
         for (int gq = 0; gq < 4; gq++) {
-            f32x4 *dst = reinterpret_cast<f32x4 *>(xt + (4 * j + gq) * 256);
-            f32x4 cur = *dst;
+            f32x4 c = NP == 2 ? cur[j][gq] : *reinterpret_cast<const f32x4 *>(xt2 + (4 * j + gq) * 256);
 #pragma unroll
-            for (int e = 0; e < 4; e++) { cur[e] += acc[j][4 * gq + e] * inv2; acc[j][4 * gq + e] = cur[e]; }
-            *dst = cur;
-            s2 += (cur[0] + cur[1]) + (cur[2] + cur[3]);
+            for (int e = 0; e < 4; e++) { c[e] += acc[j][4 * gq + e] * inv2; acc[j][4 * gq + e] = c[e]; }
+            *reinterpret_cast<f32x4 *>(xt2 + (4 * j + gq) * 256) = c;
+            s2 += (c[0] + c[1]) + (c[2] + c[3]);
         }
     if (stats_out != nullptr) {
         s2 += __shfl_xor(s2, 32);
