@@ -43,6 +43,18 @@ constexpr bool kLnFold = false;
 #else
 constexpr bool kLnFold = true;
 #endif
+// -DMGPT_AB_NO_MLP160_HALF keeps 128-token blocks in mlp160p_kernel for every small launch
+// (-DMGPT_AB_NO_MLP160_QUARTER: no 32-token blocks)
+#ifdef MGPT_AB_NO_MLP160_QUARTER
+constexpr bool kMlp160Quarter = false;
+#else
+constexpr bool kMlp160Quarter = true;
+#endif
+#ifdef MGPT_AB_NO_MLP160_HALF
+constexpr bool kMlp160Half = false;
+#else
+constexpr bool kMlp160Half = true;
+#endif
 #ifdef MGPT_AB_NO_LAST1_TAIL
 constexpr bool kLast1Tail = false;
 #else
@@ -351,6 +363,10 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                              fastk::kM5Lds<NP>));
                 MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp160p_kernel<T, NP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              fastk::kM5Lds<NP>));
+                MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp160p_kernel<T, NP, 5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (fastk::kM5Lds<NP, 2>)));
+                MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp160p_kernel<T, NP, 5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (fastk::kM5Lds<NP, 1>)));
             }
         }
     }
@@ -775,6 +791,14 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                 if (last_short)
                     hipLaunchKernelGGL((fastk::mlp160p_kernel<T, NP, 0>), dim3((unsigned)std::min(n_blocks, m->n_cu)), dim3(512), (size_t)fastk::kM5Lds<NP>, s,
                                        mlp_x, m->mlp160_pk[l], m->mlp160_inv1[l], m->proj2[l].inv_scale, m->gelu_lut, n_blocks, (const float *)nullptr, (int64_t)0);
+                else if (mlp_M <= (int64_t)32 * m->n_cu && kMlp160Half && kMlp160Quarter)
+                    // ... or 32-token blocks, one producer and one consumer wave (cfg1's 8192 tokens: one block per CU)
+                    hipLaunchKernelGGL((fastk::mlp160p_kernel<T, NP, 5, 1>), dim3((unsigned)std::min((int)(mlp_M / 32), m->n_cu)), dim3(128), (size_t)(fastk::kM5Lds<NP, 1>), s,
+                                       mlp_x, m->mlp160_pk[l], m->mlp160_inv1[l], m->proj2[l].inv_scale, m->gelu_lut, (int)(mlp_M / 32), m->head_parts, part_stride);
+                else if (mlp_M <= (int64_t)64 * m->n_cu && kMlp160Half)
+                    // so few tokens that 128-token blocks would leave CUs idle (one environment): 64-token blocks, one wave per SIMD
+                    hipLaunchKernelGGL((fastk::mlp160p_kernel<T, NP, 5, 2>), dim3((unsigned)std::min((int)(mlp_M / 64), m->n_cu)), dim3(256), (size_t)(fastk::kM5Lds<NP, 2>), s,
+                                       mlp_x, m->mlp160_pk[l], m->mlp160_inv1[l], m->proj2[l].inv_scale, m->gelu_lut, (int)(mlp_M / 64), m->head_parts, part_stride);
                 else
                     hipLaunchKernelGGL((fastk::mlp160p_kernel<T, NP, 5>), dim3((unsigned)std::min(n_blocks, m->n_cu)), dim3(512), (size_t)fastk::kM5Lds<NP>, s,
                                        mlp_x, m->mlp160_pk[l], m->mlp160_inv1[l], m->proj2[l].inv_scale, m->gelu_lut, n_blocks, m->head_parts, part_stride);

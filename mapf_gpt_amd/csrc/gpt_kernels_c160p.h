@@ -36,8 +36,11 @@ namespace fastk {
 constexpr int kM5Period = 22;                   // stream steps per block
 constexpr int kM5Slots = 2;                     // LDS ring depth (steps)
 
-template <int NP>
-constexpr int kM5Lds = kM5Slots * 20 * NP * 1024 + kGeluLutN * 8 + 4 * 2 * 2 * NP * 1024;   // ring | Phi table | hidden hand-off
+// NPAIR = producer / consumer wave pairs of a workgroup = 32-token tiles of a block: 4 (128-token blocks, two waves per SIMD), 2 (64-token
+// blocks, one wave per SIMD) or 1 (32-token blocks) for launches so small that 128-token blocks would leave CUs idle: one environment
+// (cfg1, 8192 tokens) 36.7 -> ~30 us per launch with NPAIR = 2, a little less with 1 (a step is then latency, not matrix-pipe time)
+template <int NP, int NPAIR = 4>
+constexpr int kM5Lds = kM5Slots * 20 * NP * 1024 + kGeluLutN * 8 + NPAIR * 2 * 2 * NP * 1024;   // ring | Phi table | hidden hand-off
 
 // weight stream: [period step R][pair ms][plane][lane][8]; pairs 0-9 = c_fc k-steps (gain folded in), 10 + 2 j + kk = c_proj
 template <class T, int NP>
@@ -86,8 +89,8 @@ __global__ __launch_bounds__(256) void pack_mlp160p_kernel(const float *__restri
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
 }
 
-template <class T, int NP, int NFOLD = 0>
-__global__ __launch_bounds__(512, 2) void mlp160p_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv1,
+template <class T, int NP, int NFOLD = 0, int NPAIR = 4>
+__global__ __launch_bounds__(128 * NPAIR, 2) void mlp160p_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv1,
                                                          float inv2, const float2 *__restrict__ gelu_lut, int n_blocks,
                                                          const float *__restrict__ fold = nullptr, int64_t fold_stride = 0)
 {
@@ -95,7 +98,9 @@ __global__ __launch_bounds__(512, 2) void mlp160p_kernel(float *__restrict__ x, 
     constexpr int MS = 20;                                 // fragment pairs per step
     constexpr int STEP = MS * NP * 1024;                   // bytes per stream step
     constexpr int NSLOT = kM5Slots;
-    constexpr int PWP = MS * NP / 4;                       // direct-to-LDS pieces per PRODUCER wave per step (the consumers issue none)
+    static_assert(NPAIR == 4 || NPAIR == 2 || NPAIR == 1, "wave pairs");
+    constexpr int PWP = MS * NP / NPAIR;                   // direct-to-LDS pieces per PRODUCER wave per step (the consumers issue none)
+    constexpr int BLK = 32 * NPAIR;                        // tokens per block
     constexpr int LUT_BYTES = kGeluLutN * 8;
     constexpr int NM = (NP == 2 ? 6 : 2);                  // MFMAs per chunk (two fragment pairs)
     constexpr int NX = C / 8;                              // 16-byte row pieces per lane (chunks of the chunk-major row)
@@ -103,8 +108,8 @@ __global__ __launch_bounds__(512, 2) void mlp160p_kernel(float *__restrict__ x, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave < 4;                        // wave-uniform
-    const int pair = wave & 3;
+    const bool producer = wave < NPAIR;                    // wave-uniform
+    const int pair = producer ? wave : wave - NPAIR;
     const int r = lane & 31, h = lane >> 5;
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned lds0 = (unsigned)(size_t)smem + lane16;
@@ -130,10 +135,11 @@ __global__ __launch_bounds__(512, 2) void mlp160p_kernel(float *__restrict__ x, 
         r_issue = r_issue + 1 == kM5Period ? 0 : r_issue + 1;
     };
     {   // Phi table -> LDS (24 pieces of 1 KiB, 3 per wave); older than every ring piece
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(gelu_lut) + (size_t)wave * (LUT_BYTES / 8) + lane16;
+        constexpr int LW = LUT_BYTES / (2 * NPAIR);        // bytes of the table per wave
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(gelu_lut) + (size_t)wave * LW + lane16;
 #pragma unroll
-        for (int i = 0; i < LUT_BYTES / 8192; i++)
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024), (lds_void_t *)(smem + NSLOT * STEP + wave * (LUT_BYTES / 8) + i * 1024), 16, 0, 0);
+        for (int i = 0; i < LW / 1024; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024), (lds_void_t *)(smem + NSLOT * STEP + wave * LW + i * 1024), 16, 0, 0);
     }
     issue(0);
     if (!producer) {                                       // hidden hand-off starts as zeros (the first block has no predecessor)
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void mlp160p_kernel(float *__restrict__ x, 
         for (int k = 0; k < n_mine; k++) {
             // (k == 0: hB is zero, its GELU writes zero hidden planes -- what the consumer's first steps expect)
             const int64_t blk = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
-            float *xrow = x + (blk * 128 + pair * 32) * C + r * 8 + 4 * h;            // chunk-major: chunk c at xrow + c * 256
+            float *xrow = x + (blk * BLK + pair * 32) * C + r * 8 + 4 * h;            // chunk-major: chunk c at xrow + c * 256
             f32x4 xr[NX];                                  // raw row pieces: xr[c] = features 8 c + 4 h .. + 3
             // ---- step 0: GELU(tile 19 of the previous block); row loads ----
             sync(E0{});
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void mlp160p_kernel(float *__restrict__ x, 
         // steps 0 .. 3 of a period for the consumer: the block blk_prev is finished (c_proj of its tiles 18, 19, then the
         // residual add + store, acc = 0)
         auto finish_block = [&](int64_t blk_prev, auto first_pending_c) {
-            float *xrow = x + (blk_prev * 128 + pair * 32) * C + r * 8 + 4 * h;    // chunk-major, as in the producer
+            float *xrow = x + (blk_prev * BLK + pair * 32) * C + r * 8 + 4 * h;    // chunk-major, as in the producer
             step_pj(0, first_pending_c);                   // step 0: tile 18
             step_pj(1, E0{});                              // step 1: tile 19; every output tile is final after it
             sync(E0{});                                    // step 2: the residual rows are requested ...
