@@ -388,7 +388,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
 #define MGPT_LAST1_LDS(C_, R_, TAIL_)                                                                                                          \
     MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_last1_kernel<C_, 32, R_, TAIL_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  fastk::kLast1Lds<C_, R_, TAIL_>))
-        if (C == 256) MGPT_LAST1_LDS(256, fastk::kLast1R, false);
+        if (C == 256) { MGPT_LAST1_LDS(256, fastk::kLast1R, false); MGPT_LAST1_LDS(256, 1, false); }
         else if (C == 160) { MGPT_LAST1_LDS(160, fastk::kLast1R, false); MGPT_LAST1_LDS(160, 1, true); }
         else { MGPT_LAST1_LDS(64, fastk::kLast1R, false); MGPT_LAST1_LDS(64, 1, true); }
 #undef MGPT_LAST1_LDS
@@ -667,7 +667,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
 #define MGPT_LAST1(C_)                                                                                                                      \
     hipLaunchKernelGGL((fastk::attn_last1_kernel<C_, 32>), dim3((unsigned)(rows_pad / fastk::kLast1R)), dim3(256 * fastk::last1_split(C_)), (size_t)fastk::kLast1Lds<C_>, s, g->x, P + lo.ln1, \
                        wk, m->last1_wt, m->x_last, rows, scale_log2e)
-            if (C == 256) MGPT_LAST1(256); else if (C == 160) MGPT_LAST1(160); else MGPT_LAST1(64);
+            if (C == 256 && rows <= 2 * m->n_cu)
+                // few rows (one environment on the 6M shape): one row per workgroup, so that they spread over the CUs
+                hipLaunchKernelGGL((fastk::attn_last1_kernel<256, 32, 1, false>), dim3((unsigned)rows_pad), dim3(256 * fastk::last1_split(256)),
+                                   (size_t)(fastk::kLast1Lds<256, 1, false>), s, g->x, P + lo.ln1, wk, m->last1_wt, m->x_last, rows, scale_log2e);
+            else if (C == 256) MGPT_LAST1(256); else if (C == 160) MGPT_LAST1(160); else MGPT_LAST1(64);
 #undef MGPT_LAST1
             MGPT_LAUNCH_CHECK();
         } else if (attn_block && C == 160 && !head_par && !last_short && !(embed_fused && l == 0) && m->attn160o_spill != nullptr && kAttn160o) {
