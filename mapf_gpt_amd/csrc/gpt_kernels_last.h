@@ -402,9 +402,11 @@ void attn_last1_kernel(const float *__restrict__ x, const float *__restrict__ ga
         last1_matvec<C, R, HS, NW, false>(w_t + 2 * C * C, yS, C, part, tid, o);
         if constexpr (!TAIL) {
             if (tid < C) {
+                float xres[R];                              // the R residual values in flight together (rows past the end re-read the last one)
 #pragma unroll
-                for (int r = 0; r < R; r++)
-                    x_last[xt_off(b0 + r, tid, C)] = r < nr ? x[xt_off((b0 + r) * T + T - 1, tid, C)] + o[r] : 0.0f;
+                for (int r = 0; r < R; r++) xres[r] = x[xt_off((b0 + (r < nr ? r : nr - 1)) * T + T - 1, tid, C)];
+#pragma unroll
+                for (int r = 0; r < R; r++) x_last[xt_off(b0 + r, tid, C)] = r < nr ? xres[r] + o[r] : 0.0f;
             }
         } else {
             if (tid < C) tl[tid] = x[xt_off(b0 * T + T - 1, tid, C)] + o[0];
