@@ -249,8 +249,12 @@ __global__ __launch_bounds__(256) void embed_tiled_kernel(const uint8_t *__restr
     const int t = (int)(tok & (kT - 1)), id = tokens[tok];
     const float *pa = wte + (size_t)id * C + 4 * h, *pb = wpe + (size_t)t * C + 4 * h;
     float *px = x + (int64_t)blockIdx.x * 32 * C + r * 8 + 4 * h;
-    for (int c = wave; c < (C >> 3); c += 4)
-        *reinterpret_cast<f32x4 *>(px + c * 256) = *reinterpret_cast<const f32x4 *>(pa + 8 * c) + *reinterpret_cast<const f32x4 *>(pb + 8 * c);
+    // eight chunks per wave in flight (C = 256: the whole share of the wave), streaming stores (0.84 -> 0.75 ms per 12 288 rows, round 4)
+#pragma unroll 8
+    for (int c = wave; c < (C >> 3); c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(pa + 8 * c) + *reinterpret_cast<const f32x4 *>(pb + 8 * c);
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(px + c * 256));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
