@@ -427,7 +427,10 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             MGPT_HIP(hipMalloc(&m->apk, (size_t)g->max_rows * kT * C * NP * sizeof(uint16_t)));
         // one-plane mode of the full chain (no fused kernels): LayerNorm folded into the GEMMs (GemmArgs) -- ln_pack_kernel, which
         // re-reads every residual row to normalise it (8 % of an 85M step), runs once per forward instead of twice per layer
-        m->ln_fold = kLnFold && NP == 1 && !m->mlp_fused && m->apk != nullptr;
+        // (MGPT_LN_FOLD=0 in the environment keeps the normalised planes: the raw planes round x itself to bf16, so a residual stream whose
+        //  per-token mean is many times its standard deviation loses precision that LayerNorm-then-round keeps)
+        const char *fold_env = getenv("MGPT_LN_FOLD");
+        m->ln_fold = kLnFold && NP == 1 && !m->mlp_fused && m->apk != nullptr && !(fold_env != nullptr && fold_env[0] == '0');
         if (m->ln_fold) {
             m->attn_pk2g.assign(g->L, nullptr); m->fc_pk2g.assign(g->L, nullptr); m->attn_cs.assign(g->L, nullptr); m->fc_cs.assign(g->L, nullptr);
             auto packg = [&](std::vector<uint16_t *> &dst, std::vector<float *> &cs, size_t off, size_t goff, size_t R, size_t K, float scale, int l) -> int {
