@@ -132,6 +132,7 @@ struct ModeState {          // one precision mode
     std::vector<uint16_t *> attn_pk2g, fc_pk2g;
     std::vector<float *> attn_cs, fc_cs;
     float2 *ln_parts = nullptr;                // [C / 128][M]
+    float *ln_mean = nullptr;                  // [M]: the mean of every row at its latest LayerNorm = the shift of its operand planes (GemmArgs::shift)
 };
 
 struct FastState {
@@ -451,6 +452,10 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                 if ((rc = packg(m->fc_pk2g, m->fc_cs, lo.fc_w, lo.ln2, 4 * C, C, 1.0f / m->fc[l].inv_scale, l)) != MGPT_OK) return rc;
             }
             MGPT_HIP(hipMalloc(&m->ln_parts, (size_t)(C / 128) * g->max_rows * kT * sizeof(float2)));
+            // (the last layer's compact launch is padded to 256 rows and addresses token 255 of each: room and finite values for all of them)
+            const size_t n_mean = (size_t)((g->max_rows + 255) / 256) * 256 * kT;
+            MGPT_HIP(hipMalloc(&m->ln_mean, n_mean * sizeof(float)));
+            MGPT_HIP(hipMemset(m->ln_mean, 0, n_mean * sizeof(float)));
         }
     }
     {
@@ -510,6 +515,7 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     for (auto p : m->attn_cs) (void)hipFree(p);
     for (auto p : m->fc_cs) (void)hipFree(p);
     (void)hipFree(m->ln_parts);
+    (void)hipFree(m->ln_mean);
     for (auto p : m->attn160o_pk) (void)hipFree(p);
     (void)hipFree(m->attn160o_spill);
     for (auto *p : m->mlp160_pk) (void)hipFree(p);
@@ -617,9 +623,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         MGPT_LAUNCH_CHECK();
     }
     // folded LayerNorm: (mean, rstd) of the rows the next GEMM normalises live in m->stats, their raw operand planes in m->apk
-    auto ln_finalize = [&](int64_t Mrows) -> int {
+    // (compact = the last layer's rows: token 255 of every row; their means are not needed again)
+    auto ln_finalize = [&](int64_t Mrows, bool compact) -> int {
         ProfScope ps(P_LAYERNORM, s);
-        hipLaunchKernelGGL(fastk::ln_finalize_kernel, dim3((unsigned)cdiv64(Mrows, 256)), dim3(256), 0, s, m->ln_parts, C / 128, Mrows, C, m->stats);
+        hipLaunchKernelGGL(fastk::ln_finalize_kernel, dim3((unsigned)cdiv64(Mrows, 256)), dim3(256), 0, s, m->ln_parts, C / 128, Mrows, C, m->stats,
+                           m->ln_mean, compact ? kT : 1, compact ? kT - 1 : 0, compact ? 0 : 1);
         MGPT_LAUNCH_CHECK();
         return MGPT_OK;
     };
@@ -627,10 +635,10 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         ProfScope ps(P_LAYERNORM, s);
         const dim3 grid((unsigned)(M / 32));
         const float *g0 = P + g->layers[0].ln1;
-        if (C == 256) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 4>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats);
-        else if (C == 512) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 8>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats);
-        else if (C == 768) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 12>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats);
-        else hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 16>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats);
+        if (C == 256) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 4>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats, m->ln_mean);
+        else if (C == 512) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 8>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats, m->ln_mean);
+        else if (C == 768) hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 12>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats, m->ln_mean);
+        else hipLaunchKernelGGL((fastk::ln_pack_kernel<T, NP, 16>), grid, dim3(256), 0, s, g->x, g0, m->apk, C, m->x_tiled ? 1 : 0, m->stats, m->ln_mean);
         MGPT_LAUNCH_CHECK();
     }
     const float scale_log2e = (1.0f / sqrtf((float)g->hs)) * 1.44269504088896340736f;
@@ -771,9 +779,12 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             ProfScope ps(ls ? P_GEMM_PROJ_LAST : P_GEMM_PROJ, s);
             if (m->pk_gemm) {
                 a.w_hi = m->proj_pk2[l];
-                if (m->ln_fold) { a.raw_out = m->apk; a.rsum_out = m->ln_parts; }      // the rows ln_2 normalises: planes + partial sums
+                if (m->ln_fold) {                                                      // the rows ln_2 normalises: planes + partial sums
+                    a.raw_out = m->apk; a.rsum_out = m->ln_parts;
+                    a.shift = m->ln_mean; a.shift_stride = ls ? kT : 1; a.shift_offset = ls ? kT - 1 : 0;
+                }
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
-                a.raw_out = nullptr; a.rsum_out = nullptr;
+                a.raw_out = nullptr; a.rsum_out = nullptr; a.shift = nullptr;
             } else if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
         if (!fused_stats(C) && !m->pk_gemm && (rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
@@ -833,7 +844,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         }
         if (m->pk_gemm) {
             // ---- LN2 -> PK planes; FC + GELU -> hidden PK planes; proj2 + residual ----
-            if (m->ln_fold) { if ((rc = ln_finalize(mlp_M)) != MGPT_OK) return rc; }
+            if (m->ln_fold) { if ((rc = ln_finalize(mlp_M, last_short)) != MGPT_OK) return rc; }
             else if ((rc = launch_ln_pack<T, NP>(mlp_x, P + lo.ln2, m->apk, mlp_M, C, m->x_tiled ? 1 : 0, s)) != MGPT_OK) return rc;
             a.M = (int)mlp_M;
             a.a_hi = m->apk; a.K = C; a.N = 4 * C; a.w_hi = m->ln_fold ? m->fc_pk2g[l] : m->fc_pk2[l]; a.out_scale = m->fc[l].inv_scale;
@@ -847,12 +858,12 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             a.a_hi = m->hbuf[0]; a.K = 4 * C; a.N = C; a.w_hi = m->proj2_pk2[l]; a.out_scale = m->proj2[l].inv_scale;
             a.x_out = mlp_x; a.stats_out = nullptr;
             const bool feeds_next = m->ln_fold && l + 1 < g->L;            // the rows the next layer's ln_1 normalises
-            if (feeds_next) { a.raw_out = m->apk; a.rsum_out = m->ln_parts; }
+            if (feeds_next) { a.raw_out = m->apk; a.rsum_out = m->ln_parts; a.shift = m->ln_mean; a.shift_stride = 1; a.shift_offset = 0; }
             {
                 ProfScope ps(P_GEMM_PROJ2, s);
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
             }
-            if (feeds_next && (rc = ln_finalize(mlp_M)) != MGPT_OK) return rc;
+            if (feeds_next && (rc = ln_finalize(mlp_M, false)) != MGPT_OK) return rc;
             continue;
         }
         // ---- LN2 + FC + GELU -> hidden planes ----

@@ -302,6 +302,10 @@ struct GemmArgs {
     const float *colsum;                                             // consumers: sum over k of the packed (rounded, scaled) W'[n][k]
     uint16_t *raw_out;                                               // EPI_RESID: operand planes (PK, K = N) of the new residual rows, or NULL
     float2 *rsum_out;                                                // EPI_RESID: (sum, sum of squares) of the new rows per 128-column block: [N / 128][M]
+    // The planes carry x - shift[row]: the row's mean at the LayerNorm BEFORE (ln_finalize_kernel keeps it), so that what is rounded to
+    // the operand type is centred up to the drift of the mean across one residual update, not the raw value (a residual stream with
+    // |mean| >> std would otherwise lose |mean| / std of its bits); the consumer's mean term uses mean - shift.
+    const float *shift; int shift_stride, shift_offset;              // EPI_RESID: shift of row m = shift[m * shift_stride + shift_offset]
 };
 
 // Chunk-major residual stream: x[M][C] stored as [M / 32][C / 8][32 tokens][8 floats].  A wave whose lane (r, h) owns token r
@@ -496,6 +500,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
             const int64_t m = m0 + (wm * TM + i) * 32 + r;
             const float osi = (LNF && EPI != EPI_RESID) ? os * st[i][1] : os;  // output scale of this lane's row
             if (EPI == EPI_RESID) {
+                const float sh = (p.raw_out != nullptr && p.shift != nullptr) ? p.shift[m * p.shift_stride + p.shift_offset] : 0.f;
                 // read-modify-write of the residual rows: the reads of two column tiles (8 x 16 B per lane) are all in flight
                 // before the first store -- one memory round trip per pair of tiles instead of one per 16-byte piece
                 // (the stores to x_out would otherwise keep the compiler from moving the next read up)
@@ -523,7 +528,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
                             if (p.raw_out != nullptr) {                        // the next GEMM's A operand: the raw row in operand planes
                                 rsq[i] += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
                                 const int n = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h;
-                                const float v[4] = {c[0], c[1], c[2], c[3]};
+                                const float v[4] = {c[0] - sh, c[1] - sh, c[2] - sh, c[3] - sh};
                                 u32x2 hi, lo;
                                 split4<T, NP>(v, hi, lo);
                                 *reinterpret_cast<u32x2 *>(p.raw_out + pk_off(m, n, 0, p.N >> 4, NP)) = hi;
@@ -828,7 +833,10 @@ __global__ __launch_bounds__(256) void colsum_pk_kernel(const float *__restrict_
 }
 
 // (mean, rstd) of every row from the per-128-column partial sums an EPI_RESID epilogue left (GemmArgs::rsum_out), added in block order
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2 *__restrict__ parts, int n_parts, int64_t M, int C, float2 *__restrict__ stats)
+// mean_buf (GemmArgs::shift): on entry the shift the planes of these rows were written with (row m: mean_buf[m * stride + offset]), on exit
+// -- keep != 0 -- the rows' new mean, i.e. the shift of the next residual epilogue.  stats.x = mean - shift: what the consumer subtracts.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2 *__restrict__ parts, int n_parts, int64_t M, int C, float2 *__restrict__ stats,
+                                                          float *__restrict__ mean_buf, int stride, int offset, int keep)
 {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
@@ -836,7 +844,9 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2 *__restri
     for (int q = 0; q < n_parts; q++) { const float2 v = parts[(size_t)q * M + m]; s1 += v.x; s2 += v.y; }
     const float mean = s1 / (float)C;
     const float var = fmaxf(s2 / (float)C - mean * mean, 0.f);
-    stats[m] = make_float2(mean, rsqrtf(var + 1e-5f));
+    const float sh = mean_buf[m * stride + offset];
+    stats[m] = make_float2(mean - sh, rsqrtf(var + 1e-5f));
+    if (keep) mean_buf[m * stride + offset] = mean;
 }
 
 // LayerNorm + split into PK operand planes, statistics computed here: a workgroup owns one 32-token tile, every lane
@@ -844,10 +854,11 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2 *__restri
 // model.py:19-20 / F.layer_norm) and the normalisation, so x is read exactly once; wave w writes the whole 1 KiB
 // fragments of k-steps w, w+4, ...
 template <class T, int NP, int KSW>                        // KSW = k-steps per wave = C / 64
-// raw_stats != NULL (folded LayerNorm, GemmArgs: used once per forward, for the embedding rows): the planes carry the RAW row and
-// (mean, rstd) go to raw_stats instead.
+// raw_stats != NULL (folded LayerNorm, GemmArgs: used once per forward, for the embedding rows): the planes carry x - mean (no rstd, no
+// gain), raw_stats gets (0, rstd) and raw_mean the mean (= the shift of these planes, GemmArgs::shift).
 __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ x, const float *__restrict__ gain,
-                                                      uint16_t *__restrict__ out, int C, int tiled, float2 *__restrict__ raw_stats = nullptr)
+                                                      uint16_t *__restrict__ out, int C, int tiled, float2 *__restrict__ raw_stats = nullptr,
+                                                      float *__restrict__ raw_mean = nullptr)
 {
     __shared__ float red[2][8][32];
     const int KS = C >> 4;
@@ -893,9 +904,9 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
         float v0[4], v1[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) { v0[e] = (va[i][e] - mean) * rstd * ga[e]; v1[e] = (vb[i][e] - mean) * rstd * gb[e]; }
-        if (raw_stats != nullptr) {
+        if (raw_stats != nullptr) {                        // x - mean: shifted by the row's own mean (GemmArgs::shift), no rstd, no gain
 #pragma unroll
-            for (int e = 0; e < 4; e++) { v0[e] = va[i][e]; v1[e] = vb[i][e]; }
+            for (int e = 0; e < 4; e++) { v0[e] = va[i][e] - mean; v1[e] = vb[i][e] - mean; }
         }
         u32x2 h0, l0, h1, l1;
         split4<T, NP>(v0, h0, l0);
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
         *reinterpret_cast<u32x4 *>(dst) = hi;
         if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
     }
-    if (raw_stats != nullptr && wave == 0 && h == 0) raw_stats[m] = make_float2(mean, rstd);
+    if (raw_stats != nullptr && wave == 0 && h == 0) { raw_stats[m] = make_float2(0.f, rstd); raw_mean[m] = mean; }
 }
 
 // 8 waves of 64 x 128 (2 x 4 MFMA tiles, 256 registers, two waves per SIMD: the second wave on the SIMD covers part of the
