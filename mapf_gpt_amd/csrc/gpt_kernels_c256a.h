@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
             f32x16 va, vb;
 #pragma unroll
             for (int g = 0; g < 16; g++) { va[g] = 0.f; vb[g] = 0.f; }
-            auto step_v = [&](auto j_c) {
+            auto step_v = [&](auto j_c, auto next_c) {
                 constexpr int j = decltype(j_c)::value;
                 smark();
                 sync_wait(P4{});
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                 sphase(3);
                 auto chunk = [&](auto c_c) {
                     constexpr int c = decltype(c_c)::value;
-                    chunk_begin(c_c, std::true_type{});
+                    chunk_begin(c_c, next_c);
                     constexpr int ks = 8 * j + 2 * c;
                     if (NP == 2) {
                         va = T::mfma(xn[ks][1], wb[c & 1][0][0], va); vb = T::mfma(xn[ks + 1][1], wb[c & 1][1][0], vb);
@@ -353,8 +353,12 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                 chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
                 sphase(5);
             };
-            step_v(I0{});
-            step_v(I1{});
+            step_v(I0{}, std::true_type{});
+#ifdef MGPT_AB_ATTN_CLUMPED
+            step_v(I1{}, std::true_type{});
+#else
+            step_v(I1{}, std::false_type{});               // (the next step's first pairs are requested at the end of the attention phase)
+#endif
             if constexpr (LASTH) {
                 // the normalised rows are dead: their registers take the y planes of heads 0-6 back (this wave's own stores,
                 // complete since the step waits above; L2-resident).  Needed at the first tail step, one attention phase away.
@@ -384,9 +388,10 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
 
             // ---- attention of this wave's 32 queries against the 256 keys of the head ----
             f32x16 o;
+            float m_run = -INFINITY, l_run = 0.f;
+#ifdef MGPT_AB_ATTN_CLUMPED
 #pragma unroll
             for (int g = 0; g < 16; g++) o[g] = 0.f;
-            float m_run = -INFINITY, l_run = 0.f;
             {
                 u32x4 kf[2][2], vf[2][2];
                 auto load_k = [&](int kt) {                // K fragments of key tile kt: [k-step][plane]
@@ -458,6 +463,142 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                     for (int mm = 0; mm < 2; mm++) o = mma<T, NP>(vf[mm], pf[mm], o);
                 }
             }
+#else
+            {
+                // Round 5: the key-tile loop as a MODULO-SCHEDULED pipeline, placed one MFMA at a time.  Round 4's loop ran a tile as
+                // three clumps -- 6 S MFMAs, ~95 VALU of softmax, 6 PV MFMAs -- and on this chip clumped issue times ADD, also across
+                // the two waves of a SIMD (stamps: 1 700 - 1 940 cycles per tile pair = 768 of matrix pipe + ~900 of VALU issue), while
+                // ~6 VALU instructions per MFMA are free when they sit BETWEEN MFMAs (profiles/r02_probe_interleave.txt).  So tile kt's
+                // softmax arithmetic now rides under the MFMAs of its neighbours:
+                //     A   max of S(kt)                                   under   PV, second k-step, of tile kt - 1   (3 MFMAs)
+                //     R   rescale when some query's running max moved (rare, wave-uniform branch)
+                //     B1  exp2 / row sum of S(kt), split of octet 0      under   S(kt + 1) -> the other score block  (6 MFMAs)
+                //     B2  split of octet 1, running sum                  under   PV, first k-step, of tile kt        (3 MFMAs)
+                // Same products, same order of every accumulation as before (o: PV(kt - 1) completes before tile kt's rescale and
+                // PV(kt) follows; l: tile by tile), so the results are bit-identical to round 4's loop (-DMGPT_AB_ATTN_CLUMPED).
+                // Registers: two score blocks instead of one; the 16 registers come from NOT holding the next step's first weight
+                // fragments across the phase (they are requested under the last tile instead, see below).
+                // LDS reads of the phase return in issue order; per tile: V^T k-step 1 of tile kt (2 NP / 2... NP reads), K of tile
+                // kt + 2 (2 NP), V^T k-step 0 of tile kt + 1 (NP).  lgkmcnt(N): N = reads issued after the one needed.
+                u32x4 kf[2][2], vf[2][2], pf[2][2];
+                f32x16 sA, sB;                             // score blocks of the even / odd key tiles
+                constexpr int NM = NP == 2 ? 3 : 1;        // MFMAs per k-step
+                auto load_k = [&](auto kt_c) {             // K fragments of key tile kt: [k-step][plane]
+                    constexpr int off = decltype(kt_c)::value * (32 * KROW);
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][0]) : "v"(kr_addr), "n"(off) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][0]) : "v"(kr_addr), "n"(off + 32) : "memory");
+                    if (NP == 2) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][1]) : "v"(kr_addr), "n"(off + kT * KROW) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][1]) : "v"(kr_addr), "n"(off + kT * KROW + 32) : "memory");
+                    } else { kf[0][1] = kf[0][0]; kf[1][1] = kf[1][0]; }
+                };
+                auto load_v = [&](auto kt_c, auto mm_c) {  // V^T fragments of key tile kt, k-step mm: [plane]
+                    constexpr int off = decltype(kt_c)::value * 64 + decltype(mm_c)::value * 32, mm = decltype(mm_c)::value;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[mm][0]) : "v"(vr_addr), "n"(off) : "memory");
+                    if (NP == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[mm][1]) : "v"(vr_addr), "n"(off + HS * VROW) : "memory");
+                    else vf[mm][1] = vf[mm][0];
+                };
+                auto lgkm = [&](auto n_c) {
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(n_c)::value) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // NMF MFMAs, each followed by NV VALU instructions; what is left of the VALU work goes behind the last one
+                auto place = [&](auto nmf_c, auto nv_c) {
+#pragma unroll
+                    for (int n = 0; n < decltype(nmf_c)::value; n++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, decltype(nv_c)::value, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                using LK = std::integral_constant<int, 2 * NP>;       // reads of one K tile
+                using LV = std::integral_constant<int, NP>;           // reads of one V^T k-step
+                load_k(I0{});
+                lgkm(I0{});
+#pragma unroll
+                for (int g = 0; g < 16; g++) sA[g] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) sA = mma<T, NP>(kf[ks], qf[ks], sA);
+                __builtin_amdgcn_sched_barrier(0);
+                load_k(I1{});
+                load_v(I0{}, I0{});
+                auto tile = [&](auto kt_c, f32x16 &cur, f32x16 &nxt) {
+                    constexpr int kt = decltype(kt_c)::value;
+                    constexpr bool FIRSTT = kt == 0, LASTT = kt == kT / 32 - 1, HAS2 = kt + 2 < kT / 32;
+                    // ---- A: max of this tile's scores under the second k-step of the previous tile's PV ----
+                    // (reads issued after V^T k-step 1 of tile kt - 1: K of tile kt + 1, V^T k-step 0 of tile kt)
+                    if constexpr (!FIRSTT) lgkm(std::integral_constant<int, (LASTT ? 0 : LK::value) + LV::value>{});
+                    if constexpr (!FIRSTT) o = mma<T, NP>(vf[1], pf[1], o);
+                    // cur[g] = S[query r][key 32 kt + tau(g, h)]  (times 1 / inv_scale^2)
+                    float mx = cur[0];
+#pragma unroll
+                    for (int g = 1; g < 16; g++) mx = fmaxf(mx, cur[g]);
+                    mx = other_half_max(mx);
+                    place(std::integral_constant<int, FIRSTT ? 0 : NM>{}, std::integral_constant<int, 6>{});
+                    asm volatile("" : "+v"(o));
+                    load_v(kt_c, I1{});
+                    // ---- R ----
+                    if constexpr (FIRSTT) {
+                        m_run = mx;                        // (round 4's loop scaled o = 0 and l = 0 by exp2(-inf) = 0 here: the same values)
+                    } else if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {     // some query's running max moved: rescale (wave-uniform branch)
+                        const float m_new = fmaxf(m_run, mx);
+                        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
+                        l_run *= alpha;
+#pragma unroll
+                        for (int g = 0; g < 16; g++) o[g] *= alpha;
+                        m_run = m_new;
+                    }
+                    const float nm = -m_run * sc2;
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- B1: exponentials, row sum, split of octet 0 under S(kt + 1) ----
+                    // (reads issued after K of tile kt + 1: V^T k-step 0 and k-step 1 of tile kt)
+                    if constexpr (!LASTT) {
+                        lgkm(std::integral_constant<int, 2 * LV::value>{});
+#pragma unroll
+                        for (int g = 0; g < 16; g++) nxt[g] = 0.f;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ks++) nxt = mma<T, NP>(kf[ks], qf[ks], nxt);
+                    }
+                    float psum = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        cur[g] = __builtin_amdgcn_exp2f(fmaf(cur[g], sc2, nm));
+                        psum += cur[g];
+                    }
+                    pack_octet(cur, 0, pf[0]);
+                    place(std::integral_constant<int, LASTT ? 0 : 2 * NM>{}, std::integral_constant<int, 10>{});
+                    if constexpr (!LASTT) asm volatile("" : "+v"(nxt));
+                    if constexpr (HAS2) load_k(std::integral_constant<int, HAS2 ? kt + 2 : 0>{});
+                    // ---- B2: split of octet 1, running sum under the first k-step of this tile's PV ----
+                    // (reads issued after V^T k-step 0 of tile kt: V^T k-step 1 of tile kt, K of tile kt + 2)
+                    lgkm(std::integral_constant<int, LV::value + (HAS2 ? LK::value : 0)>{});
+                    if constexpr (FIRSTT) {                // (o starts here: a zero block held across the first tile cost 16 registers -- hipcc spilled it)
+#pragma unroll
+                        for (int g = 0; g < 16; g++) o[g] = 0.f;
+                    }
+                    o = mma<T, NP>(vf[0], pf[0], o);
+                    pack_octet(cur, 1, pf[1]);
+                    l_run += other_half_sum(psum);
+                    place(std::integral_constant<int, NM>{}, std::integral_constant<int, 6>{});
+                    asm volatile("" : "+v"(o));
+                    if constexpr (!LASTT) load_v(std::integral_constant<int, LASTT ? 0 : kt + 1>{}, I0{});
+                };
+                using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+                using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>; using K6 = std::integral_constant<int, 6>; using K7 = std::integral_constant<int, 7>;
+                static_assert(kT / 32 == 8, "eight key tiles");
+                tile(K0{}, sA, sB); tile(K1{}, sB, sA); tile(K2{}, sA, sB); tile(K3{}, sB, sA);
+                tile(K4{}, sA, sB); tile(K5{}, sB, sA); tile(K6{}, sA, sB); tile(K7{}, sB, sA);
+                // the second k-step of the last tile's PV; under it, the first pairs of the next stream step (the step after this
+                // phase; its slot landed for every wave before the last v step's barrier) -- round 4 requested them in that step's
+                // chunk 3 and held their 16 registers across the whole phase
+                lgkm(I0{});
+                o = mma<T, NP>(vf[1], pf[1], o);
+                __builtin_amdgcn_sched_barrier(0);
+                lds_pair(nxt_addr, I0{}, wb[0][0]);
+                lds_pair(nxt_addr, I1{}, wb[0][1]);
+            }
+#endif
             // ---- y planes of the head: o[g] = O[query r][d = tau(g, h)] / l, times the v projection's weight scale: register
             //      octet kk = k-step 2 hd + kk of the out-projection's B operand ----
             {

@@ -10,7 +10,7 @@ toolbox's result records, generate_observations.py:43-66).  Instances with CSR <
 all-pairs distance table of a map is built once and reused while consecutive instances share the map (:46-54).
 Lifelong logs ("global_lifelong_targets_xy", :55-60, 143-153) and the `mask_cost2go` ablation (:253-262) are handled on the
 device like the rest; the other three mask_* fields are carried by `InputParameters` but, as in the reference's dataset
-pipeline (whose C++ encoder ignores them), only the python `Encoder.mask` applies them (tokenizer.py:104-138).
+pipeline (whose C++ encoder ignores them), only the python `Encoder.mask` applies them (tokenizer.py:104-138; restated for the tests in oracle/dataset_encoder.py).
 Not supported: cost2go_radius != 5.
 """
 import ctypes
@@ -142,71 +142,3 @@ class ObservationGenerator:
             for g in gt_actions(rec["metrics"]["made_actions"]):
                 self.gt_actions.extend(g)
         return self.inputs, self.gt_actions
-
-
-class Encoder:
-    """Host-side vocabulary helper with the interface of the reference's python `Encoder` (dataset/tokenizer/tokenizer.py:30-185):
-    `encode(observation dict) -> list[int]` (positions and goals clamped to +-20, :55-60), `decode(ids) -> observation dict`.
-    `mask(ids)` applies the four mask_* ablations of the config exactly as tokenizer.py:104-138 does (encode and decode call it
-    when any flag is set).  Pure Python; useful for inspecting rows produced by the device tokenizers."""
-
-    def __init__(self, cfg=None):
-        self.cfg = cfg or InputParameters()
-        lim = self.cfg.cost2go_value_limit
-        self.coord_range = list(range(-lim, lim + 1)) + [-lim * 4, -lim * 2, lim * 2]                 # :33-39
-        self.actions_range = ["n", "w", "u", "d", "l", "r"]
-        self.next_action_range = [format(i, "04b") for i in range(16)]
-        self.vocab = {tok: i for i, tok in enumerate(self.coord_range + self.actions_range + self.next_action_range + ["!"])}
-        self.inverse_vocab = {i: tok for tok, i in self.vocab.items()}
-
-    def encode(self, observation):
-        lim = self.cfg.cost2go_value_limit
-        clamp = lambda v: max(-lim, min(lim, v))
-        out = [self.vocab[int(v)] for v in np.asarray(observation["cost2go"]).flatten()]
-        for a in observation["agents"]:
-            out += [self.vocab[clamp(a["relative_pos"][0])], self.vocab[clamp(a["relative_pos"][1])],
-                    self.vocab[clamp(a["relative_goal"][0])], self.vocab[clamp(a["relative_goal"][1])]]
-            out += [self.vocab[x] for x in a["previous_actions"]] + [self.vocab[a["next_action"]]]
-        out += [self.vocab["!"]] * (self.cfg.context_size - len(out))
-        return self.mask(out) if self._any_mask() else out
-
-    def _any_mask(self):
-        c = self.cfg
-        return c.mask_actions_history or c.mask_cost2go or c.mask_goal or c.mask_greed_action
-
-    def mask(self, ids):
-        """tokenizer.py:104-138, in place on a list of ids: history slots / goal pair / greedy-bits slot of all 13 records
-        -> '!'; mask_cost2go: every window token that is not the blocked one (-80) -> the token of 0."""
-        c = self.cfg
-        win = (2 * c.cost2go_radius + 1) ** 2
-        per = 5 + c.num_previous_actions
-        pad = self.vocab["!"]
-        if c.mask_actions_history:
-            for i in range(c.num_agents):
-                ids[win + i * per + 4: win + i * per + 4 + c.num_previous_actions] = [pad] * c.num_previous_actions
-        if c.mask_cost2go:
-            free, blocked = self.vocab[0], self.vocab[-c.cost2go_value_limit * 4]
-            for i in range(win):
-                if ids[i] != blocked:
-                    ids[i] = free
-        if c.mask_goal:
-            for i in range(c.num_agents):
-                ids[win + i * per + 2] = pad
-                ids[win + i * per + 3] = pad
-        if c.mask_greed_action:
-            for i in range(c.num_agents):
-                ids[win + i * per + 4 + c.num_previous_actions] = pad
-        return ids
-
-    def decode(self, idx):
-        idx = [int(i) & 0xff for i in np.asarray(idx).tolist()]
-        if self._any_mask():
-            idx = self.mask(idx)
-        side = 2 * self.cfg.cost2go_radius + 1
-        per = 4 + self.cfg.num_previous_actions + 1
-        agents = []
-        for i in range(self.cfg.num_agents):
-            t = [self.inverse_vocab[j] for j in idx[side * side + i * per: side * side + (i + 1) * per]]
-            agents.append({"relative_pos": (t[0], t[1]), "relative_goal": (t[2], t[3]), "previous_actions": t[4:-1], "next_action": t[-1]})
-        cost2go = np.array([self.inverse_vocab[j] for j in idx[: side * side]], dtype=object).reshape(side, side)
-        return {"agents": agents, "cost2go": cost2go}

