@@ -205,6 +205,12 @@ int mgpt_gpt_debug_copy(mgpt_gpt *gpt, int which, float *d_out, int64_t n_elem, 
  * 5/6 = attention output planes hi/lo; 7/8 = MLP hidden planes hi/lo (lo only for MGPT_PREC_F16X3). */
 int mgpt_gpt_debug_copy_raw(mgpt_gpt *gpt, int precision, int which, void *d_out, int64_t nbytes, void *stream);
 
+/* test/debug: event counters of the policy kernels since the last reset (synchronises the device).
+ * which 0 = waves of the C = 256 / C = 160 attention kernels that threw a head of the pipelined key-tile loop (one softmax reference
+ * per query and head) away and redid it with the exact running-maximum loop, because a half-row sum of exp2(s - ref) left the
+ * fp16 range of the P planes (mapf_gpt_amd/csrc/gpt_kernels_c256a.h).  reset != 0 zeroes the counter after reading it. */
+int mgpt_gpt_debug_counter(int which, uint64_t *value, int reset);
+
 /* mgpt_gpt_act with the RNG step read from device memory when the kernel runs (*d_step): for callers that replay the call
  * from a captured hipGraph, where a per-step scalar argument would be frozen */
 int mgpt_gpt_act_dev(mgpt_gpt *gpt, const uint8_t *d_tokens, int rows, int32_t *d_actions, float *d_logits,

@@ -77,6 +77,7 @@ SYMBOLS = {
     "mgpt_step_run": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "mgpt_gpt_debug_copy": (_i, [_vp, _i, _vp, _i64, _vp]),
     "mgpt_gpt_debug_copy_raw": (_i, [_vp, _i, _i, _vp, _i64, _vp]),
+    "mgpt_gpt_debug_counter": (_i, [_i, ctypes.POINTER(_u64), _i]),
     "mgpt_sample_actions": (_i, [_vp, _i, _vp, _i, _u64, _u64, _u64, _vp]),
     "mgpt_prof_enable": (_i, [_i]),
     "mgpt_prof_reset": (_i, []),
@@ -167,3 +168,10 @@ def prof_read():
     n = ctypes.c_int(cap)
     check(lib().mgpt_prof_read(names, ms, cnt, ctypes.byref(n)))
     return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n.value)}
+
+
+def debug_counter(which=0, reset=False):
+    """Event counter `which` of the policy kernels (include/mapf_gpt_amd.h: mgpt_gpt_debug_counter)."""
+    v = _u64(0)
+    check(lib().mgpt_gpt_debug_counter(int(which), ctypes.byref(v), 1 if reset else 0))
+    return int(v.value)

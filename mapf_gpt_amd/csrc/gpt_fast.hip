@@ -973,3 +973,18 @@ int gpt_fast_debug_copy(mgpt_gpt *g, int precision, int which, void *d_out, int6
     MGPT_HIP(hipMemcpyAsync(d_out, src, (size_t)nbytes, hipMemcpyDeviceToDevice, s));
     return MGPT_OK;
 }
+
+// test/debug: event counters of the fast-path kernels (include/mapf_gpt_amd.h)
+extern "C" int mgpt_gpt_debug_counter(int which, uint64_t *value, int reset)
+{
+    MGPT_REQUIRE(value && which == 0, MGPT_ERR_ARG, "debug counter %d does not exist", which);
+    MGPT_HIP(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    MGPT_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(mgpt::fastk::g_attn_fallbacks), sizeof(v)));
+    *value = (uint64_t)v;
+    if (reset) {
+        const unsigned long long z = 0;
+        MGPT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(mgpt::fastk::g_attn_fallbacks), &z, sizeof(z)));
+    }
+    return MGPT_OK;
+}

@@ -26,8 +26,23 @@
 #pragma once
 #include "gpt_kernels_c256p.h"
 
+// VALU instructions placed behind each MFMA of the attention phase's sub-blocks A / B1 / B2 (see the key-tile loop below)
+#ifndef MGPT_ATT_NVA
+#define MGPT_ATT_NVA 6
+#endif
+#ifndef MGPT_ATT_NVB1
+#define MGPT_ATT_NVB1 10
+#endif
+#ifndef MGPT_ATT_NVB2
+#define MGPT_ATT_NVB2 6
+#endif
+
 namespace mgpt {
 namespace fastk {
+
+// waves that threw a head of the pipelined attention loop away and redid it with the exact loop (attn256o_kernel below); read by
+// mgpt_debug_counter (tests: zero on the synthetic N(0, 0.02) checkpoints, non-zero when the scores are made to spread)
+__device__ unsigned long long g_attn_fallbacks = 0;
 
 constexpr int kA256oProjSteps = 16;
 constexpr int kA256oPeriod = 8 * kA256StepsPerHead + kA256oProjSteps;     // stream steps per row
@@ -114,9 +129,9 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
     const int n_mine = n_rows > (int)blockIdx.x ? (n_rows - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = 0;
     auto phase = [&](int i) {                              // STAMPS == 1: cycles since the previous call go to ts[i]
-        if constexpr (STAMPS == 1) { const unsigned long long t = __builtin_readcyclecounter(); ts[i] += t - t_mark; t_mark = t; }
+        if constexpr (STAMPS == 1 || STAMPS == 3) { const unsigned long long t = __builtin_readcyclecounter(); ts[i] += t - t_mark; t_mark = t; }
     };
-    // STAMPS == 2, waves 0 AND 4: ts[2] / ts[4] = wait + barrier + piece issue / the four chunks of the q|k-shaped steps (projection
+    // STAMPS == 3: as 1, left by wave 4 (the younger wave of SIMD 0) instead of wave 0.  STAMPS == 2, waves 0 AND 4: ts[2] / ts[4] = wait + barrier + piece issue / the four chunks of the q|k-shaped steps (projection
     // steps 0-3 of every head and the 16 tail steps: 48 per row), ts[3] / ts[5] = the same of the v steps (16 per row)
     auto smark = [&]() { if constexpr (STAMPS == 2) t_mark = __builtin_readcyclecounter(); };
     auto sphase = [&](int i) {
@@ -287,6 +302,9 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                 split4p<T, NP>(v1, h1, l1);
                 xn[ks][0][0] = h0[0]; xn[ks][0][1] = h0[1]; xn[ks][0][2] = h1[0]; xn[ks][0][3] = h1[1];
                 xn[ks][1][0] = l0[0]; xn[ks][1][1] = l0[1]; xn[ks][1][2] = l1[0]; xn[ks][1][3] = l1[1];
+                // (k-step by k-step: left to itself the scheduler runs the multiplies of several k-steps ahead of their splits, and with
+                //  the attention phase at 254 registers the allocator then spilled four quads of xn here)
+                if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // the first pairs of the row's first step (its slot landed for every wave before the barrier of the step before)
@@ -388,10 +406,18 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
 
             // ---- attention of this wave's 32 queries against the 256 keys of the head ----
             f32x16 o;
-            float m_run = -INFINITY, l_run = 0.f;
-#ifdef MGPT_AB_ATTN_CLUMPED
+            float l_run = 0.f;
+            // The EXACT loop (round 4): online softmax with a running maximum per query, one key tile after the other (6 S MFMAs, the
+            // softmax arithmetic, 6 PV MFMAs).  Since round 5 it is the FALLBACK of the pipelined loop below (and the whole phase under
+            // -DMGPT_AB_ATTN_CLUMPED): a wave whose scores outgrow the fp16 range of the P planes redoes its head here.
+            auto attention_exact = [&]() {
+                // (the start values come out of an opaque asm: as plain constants hipcc hoisted a zero block and -inf out of the ROW loop
+                //  -- this path being cold -- and paid for their 17 registers with spills in the LayerNorm prologue)
+                float m_run, zero;
+                asm volatile("v_mov_b32 %0, 0xff800000\n\tv_mov_b32 %1, 0" : "=v"(m_run), "=v"(zero));
+                l_run = zero;
 #pragma unroll
-            for (int g = 0; g < 16; g++) o[g] = 0.f;
+                for (int g = 0; g < 16; g++) o[g] = zero;
             {
                 u32x4 kf[2][2], vf[2][2];
                 auto load_k = [&](int kt) {                // K fragments of key tile kt: [k-step][plane]
@@ -463,7 +489,11 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                     for (int mm = 0; mm < 2; mm++) o = mma<T, NP>(vf[mm], pf[mm], o);
                 }
             }
-#else
+            };
+#if defined(MGPT_AB_ATTN_CLUMPED)
+            attention_exact();
+#elif defined(MGPT_AB_ATTN_RUNMAX)
+            float m_run = -INFINITY;
             {
                 // Round 5: the key-tile loop as a MODULO-SCHEDULED pipeline, placed one MFMA at a time.  Round 4's loop ran a tile as
                 // three clumps -- 6 S MFMAs, ~95 VALU of softmax, 6 PV MFMAs -- and on this chip clumped issue times ADD, also across
@@ -483,6 +513,14 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                 u32x4 kf[2][2], vf[2][2], pf[2][2];
                 f32x16 sA, sB;                             // score blocks of the even / odd key tiles
                 constexpr int NM = NP == 2 ? 3 : 1;        // MFMAs per k-step
+#ifdef MGPT_ABL_ATT                                        // tools/bench_probes/check_attn256o.hip only (results are wrong): 1 = no MFMAs, 2 = no softmax arithmetic in the phase
+                auto amma = [&](const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16 c) {
+                    if constexpr ((MGPT_ABL_ATT & 1) != 0) { asm volatile("" : "+v"(c)); return c; }
+                    else return mma<T, NP>(a, b, c);
+                };
+#else
+                auto amma = [&](const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16 c) { return mma<T, NP>(a, b, c); };
+#endif
                 auto load_k = [&](auto kt_c) {             // K fragments of key tile kt: [k-step][plane]
                     constexpr int off = decltype(kt_c)::value * (32 * KROW);
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][0]) : "v"(kr_addr), "n"(off) : "memory");
@@ -519,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
 #pragma unroll
                 for (int g = 0; g < 16; g++) sA[g] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++) sA = mma<T, NP>(kf[ks], qf[ks], sA);
+                for (int ks = 0; ks < 2; ks++) sA = amma(kf[ks], qf[ks], sA);
                 __builtin_amdgcn_sched_barrier(0);
                 load_k(I1{});
                 load_v(I0{}, I0{});
@@ -529,13 +567,15 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                     // ---- A: max of this tile's scores under the second k-step of the previous tile's PV ----
                     // (reads issued after V^T k-step 1 of tile kt - 1: K of tile kt + 1, V^T k-step 0 of tile kt)
                     if constexpr (!FIRSTT) lgkm(std::integral_constant<int, (LASTT ? 0 : LK::value) + LV::value>{});
-                    if constexpr (!FIRSTT) o = mma<T, NP>(vf[1], pf[1], o);
+                    if constexpr (!FIRSTT) o = amma(vf[1], pf[1], o);
                     // cur[g] = S[query r][key 32 kt + tau(g, h)]  (times 1 / inv_scale^2)
                     float mx = cur[0];
+#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
 #pragma unroll
                     for (int g = 1; g < 16; g++) mx = fmaxf(mx, cur[g]);
                     mx = other_half_max(mx);
-                    place(std::integral_constant<int, FIRSTT ? 0 : NM>{}, std::integral_constant<int, 6>{});
+#endif
+                    place(std::integral_constant<int, FIRSTT ? 0 : NM>{}, std::integral_constant<int, MGPT_ATT_NVA>{});
                     asm volatile("" : "+v"(o));
                     load_v(kt_c, I1{});
                     // ---- R ----
@@ -558,16 +598,22 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
 #pragma unroll
                         for (int g = 0; g < 16; g++) nxt[g] = 0.f;
 #pragma unroll
-                        for (int ks = 0; ks < 2; ks++) nxt = mma<T, NP>(kf[ks], qf[ks], nxt);
+                        for (int ks = 0; ks < 2; ks++) nxt = amma(kf[ks], qf[ks], nxt);
                     }
                     float psum = 0.f;
+#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
 #pragma unroll
                     for (int g = 0; g < 16; g++) {
                         cur[g] = __builtin_amdgcn_exp2f(fmaf(cur[g], sc2, nm));
                         psum += cur[g];
                     }
                     pack_octet(cur, 0, pf[0]);
-                    place(std::integral_constant<int, LASTT ? 0 : 2 * NM>{}, std::integral_constant<int, 10>{});
+#else
+                    psum = cur[3] + nm;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { pf[0][0][e] = __builtin_bit_cast(unsigned, cur[e]); pf[0][1][e] = __builtin_bit_cast(unsigned, cur[4 + e]); }
+#endif
+                    place(std::integral_constant<int, LASTT ? 0 : 2 * NM>{}, std::integral_constant<int, MGPT_ATT_NVB1>{});
                     if constexpr (!LASTT) asm volatile("" : "+v"(nxt));
                     if constexpr (HAS2) load_k(std::integral_constant<int, HAS2 ? kt + 2 : 0>{});
                     // ---- B2: split of octet 1, running sum under the first k-step of this tile's PV ----
@@ -577,10 +623,16 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
 #pragma unroll
                         for (int g = 0; g < 16; g++) o[g] = 0.f;
                     }
-                    o = mma<T, NP>(vf[0], pf[0], o);
+                    o = amma(vf[0], pf[0], o);
+#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
                     pack_octet(cur, 1, pf[1]);
                     l_run += other_half_sum(psum);
-                    place(std::integral_constant<int, NM>{}, std::integral_constant<int, 6>{});
+#else
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { pf[1][0][e] = __builtin_bit_cast(unsigned, cur[8 + e]); pf[1][1][e] = __builtin_bit_cast(unsigned, cur[12 + e]); }
+                    l_run += psum;
+#endif
+                    place(std::integral_constant<int, NM>{}, std::integral_constant<int, MGPT_ATT_NVB2>{});
                     asm volatile("" : "+v"(o));
                     if constexpr (!LASTT) load_v(std::integral_constant<int, LASTT ? 0 : kt + 1>{}, I0{});
                 };
@@ -593,8 +645,180 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                 // phase; its slot landed for every wave before the last v step's barrier) -- round 4 requested them in that step's
                 // chunk 3 and held their 16 registers across the whole phase
                 lgkm(I0{});
-                o = mma<T, NP>(vf[1], pf[1], o);
+                o = amma(vf[1], pf[1], o);
                 __builtin_amdgcn_sched_barrier(0);
+                lds_pair(nxt_addr, I0{}, wb[0][0]);
+                lds_pair(nxt_addr, I1{}, wb[0][1]);
+            }
+#else
+            {
+                // Round 5: the key-tile loop as a MODULO-SCHEDULED pipeline placed one MFMA at a time, with ONE reference per query.
+                // What the hardware does (tools/bench_probes/probe_interleave.hip, profiles/r05_probe_interleave.txt): the two waves of a
+                // SIMD TIME-SLICE -- a second wave adds 5-10 % of throughput, an MFMA of one wave never covers the VALU work of the other
+                // -- and inside ONE wave about six VALU instructions ride free behind every MFMA when they are placed BETWEEN MFMAs;
+                // beyond that every VALU instruction costs its 4 cycles and every MFMA ~15.  Round 4's loop ran a tile as three clumps
+                // (6 S MFMAs, ~95 VALU, 6 PV MFMAs: 1 700 - 1 940 cycles per tile pair of a SIMD, the sum of everything).  Two changes:
+                // (1) PIPELINE.  Tile kt's softmax arithmetic rides under the MFMAs of its neighbours:
+                //         B1  exp2, row sum, split of octet 0     under   PV k-step 1 of tile kt - 1 (3 MFMAs) and S(kt + 1) -> the other
+                //                                                         score block (6 MFMAs), two chains alternating
+                //         B2  split of octet 1, sums              under   PV k-step 0 of tile kt (3 MFMAs)
+                //     (-DMGPT_AB_ATTN_RUNMAX: the same with round 4's running maximum, bit-identical to round 4: 53.5 -> 51.2 ms of
+                //      attention per cfg3 step, profiles/r05_ab.txt).
+                // (2) FEWER VALU INSTRUCTIONS: the phase is VALU-issue bound (~95 per tile against 12 MFMAs), so the running maximum
+                //     goes (8 v_max3 + half swap + compare + branch per tile): every query takes the maximum of its FIRST key tile as
+                //     the reference of the whole head, p = exp2(s - ref) may exceed 1, and the cross-half sums of l are taken once per
+                //     head.  Softmax is shift-invariant, fp32 carries p, l and o up to 2^127; the one thing that is not free is the
+                //     fp16 range of the P planes (hi = fp16(p) <= 65504): a wave in which a lane's half-row sum reaches 60 000 (some
+                //     score more than ~11 nats above its query's first-tile maximum), or is not finite, throws its head away and
+                //     redoes it with attention_exact() (wave-uniform branch; K and V^T stay in LDS until the next head's writes, which
+                //     wait for every wave).  Deterministic per row: the decision depends on the wave's own 32 queries only.
+                // LDS reads of the phase return in issue order; per tile: [after B1a] V^T k-step 0 of tile kt (NP reads); [B1 end] V^T k-step
+                // 1 of tile kt (NP); [B2 end] K of tile kt + 2 (2 NP).  lgkmcnt(N): N = reads issued after the one needed.
+                u32x4 kf[2][2], vf[2][2], pf[2][2];
+                f32x16 sA, sB;                             // score blocks of the even / odd key tiles
+                constexpr int NM = NP == 2 ? 3 : 1;        // MFMAs per k-step
+#ifdef MGPT_ABL_ATT                                        // tools/bench_probes/check_attn256o.hip only (results are wrong): 1 = no MFMAs, 2 = no softmax arithmetic in the phase
+                auto amfma = [&](u32x4 a, u32x4 b2, f32x16 c) {
+                    if constexpr ((MGPT_ABL_ATT & 1) != 0) { asm volatile("" : "+v"(c)); return c; }
+                    else return T::mfma(a, b2, c);
+                };
+#else
+                auto amfma = [&](u32x4 a, u32x4 b2, f32x16 c) { return T::mfma(a, b2, c); };
+#endif
+                auto amma = [&](const u32x4 (&a)[2], const u32x4 (&b2)[2], f32x16 c) {     // = mma<T, NP>: small terms first
+                    if (NP == 2) { c = amfma(a[1], b2[0], c); c = amfma(a[0], b2[1], c); }
+                    return amfma(a[0], b2[0], c);
+                };
+                auto load_k = [&](auto kt_c) {             // K fragments of key tile kt: [k-step][plane]
+                    constexpr int off = decltype(kt_c)::value * (32 * KROW);
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][0]) : "v"(kr_addr), "n"(off) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][0]) : "v"(kr_addr), "n"(off + 32) : "memory");
+                    if (NP == 2) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][1]) : "v"(kr_addr), "n"(off + kT * KROW) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][1]) : "v"(kr_addr), "n"(off + kT * KROW + 32) : "memory");
+                    } else { kf[0][1] = kf[0][0]; kf[1][1] = kf[1][0]; }
+                };
+                auto load_v = [&](auto kt_c, auto mm_c) {  // V^T fragments of key tile kt, k-step mm: [plane]
+                    constexpr int off = decltype(kt_c)::value * 64 + decltype(mm_c)::value * 32, mm = decltype(mm_c)::value;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[mm][0]) : "v"(vr_addr), "n"(off) : "memory");
+                    if (NP == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[mm][1]) : "v"(vr_addr), "n"(off + HS * VROW) : "memory");
+                    else vf[mm][1] = vf[mm][0];
+                };
+                auto lgkm = [&](auto n_c) {
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(n_c)::value) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // NMF MFMAs, each followed by NV VALU instructions; what is left of the VALU work goes behind the last one
+                auto place = [&](auto nmf_c, auto nv_c) {
+#pragma unroll
+                    for (int n = 0; n < decltype(nmf_c)::value; n++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, decltype(nv_c)::value, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                using LK = std::integral_constant<int, 2 * NP>;       // reads of one K tile
+                using LV = std::integral_constant<int, NP>;           // reads of one V^T k-step
+                load_k(I0{});
+                lgkm(I0{});
+#pragma unroll
+                for (int g = 0; g < 16; g++) sA[g] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) sA = amma(kf[ks], qf[ks], sA);
+                __builtin_amdgcn_sched_barrier(0);
+                load_k(I1{});
+                // the reference of the head: the maximum of the query's first key tile.  sA[g] = S[query r][key tau(g, h)] (times 1 / inv_scale^2)
+                float nm;
+                {
+                    float mx = sA[0];
+#pragma unroll
+                    for (int g = 1; g < 16; g++) mx = fmaxf(mx, sA[g]);
+                    nm = -other_half_max(mx) * sc2;
+                }
+                float l_part = 0.f;                        // this lane's half of the row sum (all eight tiles)
+                auto tile = [&](auto kt_c, f32x16 &cur, f32x16 &nxt) {
+                    constexpr int kt = decltype(kt_c)::value;
+                    constexpr bool FIRSTT = kt == 0, LASTT = kt == kT / 32 - 1, HAS2 = kt + 2 < kT / 32;
+                    // ---- B1a: the second k-step of the previous tile's PV; the first exponentials ----
+                    // (read issued after V^T k-step 1 of tile kt - 1: K of tile kt + 1)
+#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
+                    if constexpr (!FIRSTT) {
+                        lgkm(std::integral_constant<int, LASTT ? 0 : LK::value>{});
+                        o = amma(vf[1], pf[1], o);
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            cur[g] = __builtin_amdgcn_exp2f(fmaf(cur[g], sc2, nm));
+                            l_part += cur[g];
+                        }
+                        place(std::integral_constant<int, NM>{}, std::integral_constant<int, 4>{});
+                        asm volatile("" : "+v"(o));
+                    }
+#else
+                    if constexpr (!FIRSTT) { lgkm(std::integral_constant<int, LASTT ? 0 : LK::value>{}); o = amma(vf[1], pf[1], o); __builtin_amdgcn_sched_barrier(0); }
+#endif
+                    // (V^T k-step 0 of THIS tile is requested only here, and K of tile kt + 2 only after B2: requested earlier their registers
+                    //  were live next to pf[1] / vf[1] above resp. next to the three P planes of B2, and xn paid for them with scratch)
+                    load_v(kt_c, I0{});
+                    // ---- B1b: the rest of the exponentials, row sum, split of octet 0 under S(kt + 1) ----
+                    // (read issued after K of tile kt + 1: V^T k-step 0 of tile kt)
+                    if constexpr (!LASTT) {
+                        lgkm(LV{});
+#pragma unroll
+                        for (int g = 0; g < 16; g++) nxt[g] = 0.f;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ks++) nxt = amma(kf[ks], qf[ks], nxt);
+                    }
+#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
+#pragma unroll
+                    for (int g = FIRSTT ? 0 : 4; g < 16; g++) {
+                        cur[g] = __builtin_amdgcn_exp2f(fmaf(cur[g], sc2, nm));
+                        l_part += cur[g];
+                    }
+                    pack_octet(cur, 0, pf[0]);
+#else
+                    l_part += cur[3] + nm;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { pf[0][0][e] = __builtin_bit_cast(unsigned, cur[e]); pf[0][1][e] = __builtin_bit_cast(unsigned, cur[4 + e]); }
+#endif
+                    place(std::integral_constant<int, LASTT ? 0 : 2 * NM>{}, std::integral_constant<int, MGPT_ATT_NVB1>{});
+                    if constexpr (!LASTT) asm volatile("" : "+v"(nxt));
+                    load_v(kt_c, I1{});
+                    // ---- B2: split of octet 1 under the first k-step of this tile's PV ----
+                    // (read issued after V^T k-step 0 of tile kt: V^T k-step 1 of tile kt)
+                    lgkm(LV{});
+                    if constexpr (FIRSTT) {                // (o starts here: a zero block held across the first tile cost 16 registers -- hipcc spilled it)
+#pragma unroll
+                        for (int g = 0; g < 16; g++) o[g] = 0.f;
+                    }
+                    o = amma(vf[0], pf[0], o);
+#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
+                    pack_octet(cur, 1, pf[1]);
+#else
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { pf[1][0][e] = __builtin_bit_cast(unsigned, cur[8 + e]); pf[1][1][e] = __builtin_bit_cast(unsigned, cur[12 + e]); }
+#endif
+                    place(std::integral_constant<int, NM>{}, std::integral_constant<int, MGPT_ATT_NVB2>{});
+                    asm volatile("" : "+v"(o));
+                    if constexpr (HAS2) load_k(std::integral_constant<int, HAS2 ? kt + 2 : 0>{});
+                };
+                using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+                using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>; using K6 = std::integral_constant<int, 6>; using K7 = std::integral_constant<int, 7>;
+                static_assert(kT / 32 == 8, "eight key tiles");
+                tile(K0{}, sA, sB); tile(K1{}, sB, sA); tile(K2{}, sA, sB); tile(K3{}, sB, sA);
+                tile(K4{}, sA, sB); tile(K5{}, sB, sA); tile(K6{}, sA, sB); tile(K7{}, sB, sA);
+                // the second k-step of the last tile's PV
+                lgkm(I0{});
+                o = amma(vf[1], pf[1], o);
+                __builtin_amdgcn_sched_barrier(0);
+                l_run = other_half_sum(l_part);
+                // every p is positive, so a half-row sum below 60 000 bounds every p of the lane; !(a < b) is also true for NaN
+                if (__builtin_amdgcn_ballot_w64(!(l_part < 60000.0f)) != 0) {
+                    if (lane == 0) atomicAdd(&g_attn_fallbacks, 1ull);
+                    attention_exact();
+                }
+                // the first pairs of the next stream step (the step after this phase; its slot landed for every wave before the last
+                // v step's barrier) -- round 4 requested them in that step's chunk 3 and held their 16 registers across the whole phase
                 lds_pair(nxt_addr, I0{}, wb[0][0]);
                 lds_pair(nxt_addr, I1{}, wb[0][1]);
             }
@@ -681,10 +905,10 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no direct-to-LDS load may outlive the workgroup
     if constexpr (STAMPS != 0) {
-        if (lane == 0 && (wave == 0 || (STAMPS == 2 && wave == 4))) {
+        if (lane == 0 && ((wave == 0 && STAMPS != 3) || (STAMPS == 2 && wave == 4) || (STAMPS == 3 && wave == 4))) {
             ts[7] = wall_clock64();
 #pragma unroll
-            for (int i = 0; i < 8; i++) stamps[((size_t)blockIdx.x * (STAMPS == 2 ? 2 : 1) + (wave >> 2)) * 8 + i] = ts[i];
+            for (int i = 0; i < 8; i++) stamps[((size_t)blockIdx.x * (STAMPS == 2 ? 2 : 1) + (STAMPS == 2 ? (wave >> 2) : 0)) * 8 + i] = ts[i];
         }
     }
 }

@@ -59,22 +59,29 @@ int main(int argc, char **argv)
         printf("attn256o_kernel: %.3f ms per %d-row launch (40 launches, grid %d)  [%s]\n", ms / 40, rows, grid, hipGetErrorString(hipGetLastError()));
     }
     unsigned long long *stp; hipMalloc(&stp, (size_t)grid * 64);
-    k1<<<grid, 512, lds>>>(x, ws, isa, sl2, isp * 1e-3f, spill, rows, stp);
+    const double rows_per_wg = (double)rows / grid;
+    for (int which = 0; which < 2; which++) {
+    if (which == 0) k1<<<grid, 512, lds>>>(x, ws, isa, sl2, isp * 1e-3f, spill, rows, stp);
+    else {
+        auto k3 = &attn256o_kernel<F16T, 2, 3>;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k3<<<grid, 512, lds>>>(x, ws, isa, sl2, isp * 1e-3f, spill, rows, stp);
+    }
     hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)grid * 8);
     hipMemcpy(h.data(), stp, h.size() * 8, hipMemcpyDeviceToHost);
     double pro = 0, qkv = 0, att = 0, tl = 0, ep = 0, rt = 0, tot = 0;
-    const double rows_per_wg = (double)rows / grid;
     for (int b = 0; b < grid; b++) {
         const unsigned long long *s = &h[(size_t)b * 8];
         pro += (double)s[2]; qkv += (double)s[3]; att += (double)s[4]; tl += (double)s[5]; ep += (double)s[6]; rt += (double)(s[7] - s[1]);
     }
     tot = pro + qkv + att + tl + ep;
-    printf("stamps (wave 0, mean per row over %d workgroups x %.1f rows): %.0f cycles per row: prologue %.0f | q|k|v projection steps %.0f (%.0f per head) | "
+    printf("stamps (wave %d, mean per row over %d workgroups x %.1f rows): %.0f cycles per row: prologue %.0f | q|k|v projection steps %.0f (%.0f per head) | "
            "attention phases incl. k/v barrier %.0f (%.0f per head) | tail steps %.0f (%.0f per step) | tail epilogues %.0f | shader clock %.3f GHz\n",
-           grid, rows_per_wg, tot / grid / rows_per_wg, pro / grid / rows_per_wg, qkv / grid / rows_per_wg, qkv / grid / rows_per_wg / 8,
+           4 * which, grid, rows_per_wg, tot / grid / rows_per_wg, pro / grid / rows_per_wg, qkv / grid / rows_per_wg, qkv / grid / rows_per_wg / 8,
            att / grid / rows_per_wg, att / grid / rows_per_wg / 8, tl / grid / rows_per_wg, tl / grid / rows_per_wg / 16, ep / grid / rows_per_wg,
            tot / rt / 10.0);
+    }
     {   // STAMPS == 2: where a q|k-shaped step's cycles go (projection steps 0-3 of every head + the 16 tail steps = 48 per row), waves 0 and 4
         auto k2 = &attn256o_kernel<F16T, 2, 2>;
         hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

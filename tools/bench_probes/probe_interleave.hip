@@ -29,7 +29,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 #define DS "ds_read_b128 %4, %14\n"
 #define DS2 "ds_read_b128 %4, %14\n ds_read_b128 %5, %14 offset:4096\n"
 
-// MODE: 0 V, 1 T, 2 C, 3 D, 4 G ; K = fillers per MFMA
+// MODE: 0 V, 1 T, 2 C, 3 D, 4 G, 5 V with ONE accumulator chain (every MFMA depends on the one before), 6 V with TWO alternating chains ; K = fillers per MFMA
 template <int MODE, int K, int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k(float *out, long long *cyc, const unsigned char *src, int iters)
 {
@@ -55,7 +55,27 @@ __global__ __launch_bounds__(NT, NT / 256) void k(float *out, long long *cyc, co
     asm volatile(MFMA(0) F MFMA(1) F MFMA(2) F MFMA(3) F                                                                     \
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(d0), "+v"(d1), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)          \
                  : "v"(A), "v"(B), "v"(ca), "v"(cb), "v"(laddr))
-        if (MODE == 0) {
+#define BODY1(F)                                                                                                             \
+    asm volatile(MFMA(0) F MFMA(0) F MFMA(0) F MFMA(0) F                                                                     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(d0), "+v"(d1), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)          \
+                 : "v"(A), "v"(B), "v"(ca), "v"(cb), "v"(laddr))
+#define BODY2(F)                                                                                                             \
+    asm volatile(MFMA(0) F MFMA(1) F MFMA(0) F MFMA(1) F                                                                     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(d0), "+v"(d1), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)          \
+                 : "v"(A), "v"(B), "v"(ca), "v"(cb), "v"(laddr))
+        if (MODE == 5) {
+            if (K == 0) BODY1("");
+            else if (K == 4) BODY1(VF VF);
+            else if (K == 6) BODY1(VF VF VF);
+            else if (K == 8) BODY1(VF VF VF VF);
+            else if (K == 12) BODY1(VF VF VF VF VF VF);
+        } else if (MODE == 6) {
+            if (K == 0) BODY2("");
+            else if (K == 4) BODY2(VF VF);
+            else if (K == 6) BODY2(VF VF VF);
+            else if (K == 8) BODY2(VF VF VF VF);
+            else if (K == 12) BODY2(VF VF VF VF VF VF);
+        } else if (MODE == 0) {
             if (K == 0) BODY("");
             else if (K == 1) BODY(VF1);
             else if (K == 2) BODY(VF);
@@ -115,6 +135,15 @@ int main()
     float *d; hipMalloc(&d, 256 * 512 * 4);
     long long *dc; hipMalloc(&dc, 256 * 8 * 8);
     unsigned char *src; hipMalloc(&src, 256 * 64 * 1024); hipMemset(src, 1, 256 * 64 * 1024);
+    BOTH(5, 0, "1 chain: MFMA only");
+    BOTH(5, 4, "1 chain: MFMA + 4 v_fma");
+    BOTH(5, 6, "1 chain: MFMA + 6 v_fma");
+    BOTH(5, 8, "1 chain: MFMA + 8 v_fma");
+    BOTH(5, 12, "1 chain: MFMA + 12 v_fma");
+    BOTH(6, 0, "2 chains: MFMA only");
+    BOTH(6, 6, "2 chains: MFMA + 6 v_fma");
+    BOTH(6, 8, "2 chains: MFMA + 8 v_fma");
+    BOTH(6, 12, "2 chains: MFMA + 12 v_fma");
     BOTH(0, 0, "MFMA only");
     BOTH(0, 1, "MFMA + 1 v_fma");
     BOTH(0, 2, "MFMA + 2 v_fma");
