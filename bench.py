@@ -431,7 +431,7 @@ def tokenizer_cfg4_launch(local_rank, reps=20):
             "note": "cfg4 per-GPU shard: 512 instances x 128 agents on per-instance 50 x 50 padded maps"}
 
 
-def build_workload(name, precision, rank, world, local_rank, instances=0, use_graph=True, chunk_rows=0):
+def build_workload(name, precision, rank, world, local_rank, instances=0, use_graph=False, chunk_rows=0):
     """-> dict(run, pos, goal, grid, s_ok, g_ok, rows, n_total, ...) for this rank's shard of workload `name`."""
     from mapf_gpt_amd import maps
     from mapf_gpt_amd.model import build_model
@@ -457,16 +457,18 @@ def build_workload(name, precision, rank, world, local_rank, instances=0, use_gr
                 n_agents=n_agents, inst_per_gpu=inst_per_gpu, model=model, max_steps=max_steps, map_name=map_name)
 
 
-def timed_steps(w, steps, warmup, world, use_prof, coll_dev, sample_clock=None):
-    """W untimed warmup steps, then exactly `steps` steps between barrier + synchronize on both sides; max over ranks."""
+def timed_steps(w, steps, warmup, world, use_prof, coll_dev, sample_clock=None, collective=None):
+    """W untimed warmup steps, then exactly `steps` steps between barrier + synchronize on both sides; max over ranks.
+    collective: the process-group calls are made (default: world > 1; main() forces them at world = 1 under MGPT_BENCH_FORCE_COLLECTIVE)."""
     from mapf_gpt_amd import _lib
     run, pos, goal, max_steps = w["run"], w["pos"], w["goal"], w["max_steps"]
-    if world > 1:
+    collective = (world > 1) if collective is None else collective
+    if collective:
         import torch.distributed as dist
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -495,7 +497,7 @@ def timed_steps(w, steps, warmup, world, use_prof, coll_dev, sample_clock=None):
     if use_prof:
         _lib.prof_enable(False)
         prof = _lib.prof_read()
-    if world > 1:
+    if collective:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -596,8 +598,12 @@ def main():
     backend = os.environ.get("MGPT_BENCH_BACKEND", "nccl")
     if os.environ.get("MGPT_BENCH_SHARE_GPU"):
         local_rank = 0
-    if world > 1:
+    # MGPT_BENCH_FORCE_COLLECTIVE=1: take the process-group path (init, barriers, max-over-ranks all_reduce, the metrics all_gather)
+    # at world = 1 too -- a one-rank RCCL communicator on a one-GPU box runs exactly the calls of the N > 1 job
+    collective = world > 1 or bool(os.environ.get("MGPT_BENCH_FORCE_COLLECTIVE"))
+    if collective:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         try:
             if backend == "nccl":
@@ -624,9 +630,12 @@ def main():
     name = a.workload or ("cfg3" if world == 1 else "cfg4")
     w = build_workload(name, a.precision, rank, world, local_rank, a.instances, chunk_rows=a.chunk_rows)
     use_prof = not a.no_prof
-    dt, prof_raw = timed_steps(w, a.steps, a.warmup, world, use_prof, coll_dev, sample_clock=(local_rank if rank == 0 else None))
+    dt, prof_raw = timed_steps(w, a.steps, a.warmup, world, use_prof, coll_dev, sample_clock=(local_rank if rank == 0 else None),
+                               collective=collective)
     prof, prof_full, prof_last = fold_last(prof_raw)
-    metrics = gather_metrics(w["run"].metrics().to(coll_dev), w["n_total"], rank, world)       # the job's one collective
+    local_metrics = w["run"].metrics().to(coll_dev)
+    metrics = gather_metrics(local_metrics, w["n_total"], rank, world, force=collective)       # the job's one collective
+    gathered_on = str(metrics.device) if collective else None
     torch.cuda.synchronize()
 
     if rank == 0:
@@ -637,8 +646,9 @@ def main():
         out = {"metric": "agent-steps/s (env+obs+GPT fwd)", "value": value, "unit": "agent-steps/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-               "collective_backend": (backend if world > 1 else None), "rccl_ranks": (world if world > 1 and backend == "nccl" else None),
-               "rccl_version": (".".join(map(str, torch.cuda.nccl.version())) if world > 1 and backend == "nccl" else None),
+               "collective_backend": (backend if collective else None), "rccl_ranks": (world if collective and backend == "nccl" else None),
+               "rccl_version": (".".join(map(str, torch.cuda.nccl.version())) if collective and backend == "nccl" else None),
+               "metrics_gathered_on": gathered_on,
                "config": {"workload": f"{name}: {map_name}, {n_agents} agents, MAPF-GPT-{model} shape, "
                                       f"{w['inst_per_gpu']} instances/GPU ({n_total} total), {n_total * n_agents} rows/step",
                           "parallelism": f"instances sharded x{world}, no per-step collective",
@@ -694,17 +704,19 @@ def main():
                                          "steps": 8, "warmup": 2, "dtype": a.precision}}
             del w2
             torch.cuda.empty_cache()
-            # cfg1 (the reference's own CPU-runnable case: one 32-agent instance) is launch-bound: whole step replayed as a hipGraph
+            # cfg1 (the reference's own CPU-runnable case: one 32-agent instance): eager launches are the product path; the hipGraph replay of
+            # the whole step is an option of BatchedRunner that does not pay here (the step is GPU-latency bound) and is timed beside it
             c1 = {}
-            for tag, ug in (("graph", True), ("eager", False)):
+            for tag, ug in (("eager", False), ("graph", True)):
                 w1 = build_workload("cfg1", a.precision, 0, 1, local_rank, use_graph=ug)
                 dt1, _ = timed_steps(w1, 120, 8, 1, False, coll_dev)
                 c1[tag] = 1e3 * dt1 / 120
                 del w1
             out["secondary"]["cfg1"] = {"workload": "cfg1: validation-random-seed-000, 32 agents, MAPF-GPT-2M shape, 1 instance, 32 rows/step",
-                                        "value": 32 / (c1["graph"] * 1e-3), "unit": "agent-steps/s", "ms_per_step": c1["graph"],
-                                        "ms_per_step_eager_launches": c1["eager"], "graph_speedup": c1["eager"] / c1["graph"],
-                                        "steps": 120, "warmup": 8, "dtype": a.precision}
+                                        "value": 32 / (c1["eager"] * 1e-3), "unit": "agent-steps/s", "ms_per_step": c1["eager"],
+                                        "ms_per_step_graph_replay": c1["graph"], "graph_speedup": c1["eager"] / c1["graph"],
+                                        "steps": 120, "warmup": 8, "dtype": a.precision,
+                                        "note": "value = eager launches (the default); the hipGraph replay of the step is an option (use_graph=True), timed beside it"}
             torch.cuda.empty_cache()
             # BASELINE configs[3] and [4]: the per-GPU shards of the two 8-GPU configurations, under this run's clock
             if name != "cfg4":
@@ -719,7 +731,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and name != "cfg4":
             out["cpu_baseline"] = cpu_baseline(map_name, n_agents, model)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

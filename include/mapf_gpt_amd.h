@@ -205,6 +205,29 @@ int mgpt_gpt_debug_copy(mgpt_gpt *gpt, int which, float *d_out, int64_t n_elem, 
  * 5/6 = attention output planes hi/lo; 7/8 = MLP hidden planes hi/lo (lo only for MGPT_PREC_F16X3). */
 int mgpt_gpt_debug_copy_raw(mgpt_gpt *gpt, int precision, int which, void *d_out, int64_t nbytes, void *stream);
 
+/* Precision envelope of MGPT_PREC_F16X3 (split-fp16 MFMA passes, fp32 accumulate).  The 1e-5 logit bar of that mode is established
+ * on checkpoints whose block matrices stay within max|w| <= MGPT_ENVELOPE_MAX_W and rms(w) <= MGPT_ENVELOPE_MAX_RMS (N(0, 0.02)-family
+ * weights up to x4 in scale and x20 outliers on 1 % of the entries: tests/test_gpu_parity_r2.py, profiles/r0*_parity_records.jsonl);
+ * beyond that (x8 scale, x100 outliers) it is 2e-5 .. 1e-3.  So the envelope is a run-time property of the loaded checkpoint:
+ * mgpt_gpt_finalize measures max|w| and rms(w) of every 2-D block matrix, and the first MGPT_PREC_F16X3 forward runs
+ * MGPT_ENVELOPE_PROBE_ROWS fixed pseudo-random token rows through the exact-fp32 path and the split path and compares the logits
+ * (bar MGPT_ENVELOPE_PROBE_TOL).  A checkpoint outside either test is served according to the policy:
+ *   MGPT_ENVELOPE_FALLBACK (default)  MGPT_PREC_F16X3 requests run the MGPT_PREC_F32 kernels; one line on stderr says so
+ *   MGPT_ENVELOPE_REFUSE              MGPT_PREC_F16X3 requests fail with MGPT_ERR_UNSUPPORTED
+ *   MGPT_ENVELOPE_IGNORE              no test, the split path runs (parity experiments)
+ * Follows reference mapf_gpt/inference.py:72-85 (a loaded checkpoint is served as is, in fp32). */
+#define MGPT_ENVELOPE_FALLBACK 0
+#define MGPT_ENVELOPE_REFUSE 1
+#define MGPT_ENVELOPE_IGNORE 2
+#define MGPT_ENVELOPE_MAX_W 2.5f
+#define MGPT_ENVELOPE_MAX_RMS 0.1f
+#define MGPT_ENVELOPE_PROBE_ROWS 8
+#define MGPT_ENVELOPE_PROBE_TOL 1e-5f
+int mgpt_gpt_set_envelope_policy(mgpt_gpt *gpt, int policy);
+/* out[0] = max|w|, out[1] = max rms(w) over the block matrices (valid after finalize), out[2] = probe error (-1 before the first
+ * MGPT_PREC_F16X3 forward under a policy other than IGNORE); *state: 0 not decided yet, 1 inside, 2 outside */
+int mgpt_gpt_envelope(mgpt_gpt *gpt, float *out3, int *state);
+
 /* test/debug: event counters of the policy kernels since the last reset (synchronises the device).
  * which 0 = waves of the C = 256 / C = 160 attention kernels that threw a head of the pipelined key-tile loop (one softmax reference
  * per query and head) away and redid it with the exact running-maximum loop, because a half-row sum of exp2(s - ref) left the

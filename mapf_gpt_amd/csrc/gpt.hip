@@ -158,6 +158,50 @@ extern "C" int mgpt_gpt_set_param(mgpt_gpt *g, const char *name, const float *da
     return MGPT_OK;
 }
 
+// ----- precision envelope of the split-fp16 mode (include/mapf_gpt_amd.h: MGPT_ENVELOPE_*) -----
+// max |w| and sum of squares of one matrix: block-level reduction, then one atomic per block (max on the bit pattern of a non-negative float)
+__global__ __launch_bounds__(256) void wstats_kernel(const float *__restrict__ w, int64_t n, unsigned *__restrict__ max_bits, float *__restrict__ sumsq)
+{
+    float mx = 0.f, sq = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = w[i];
+        mx = fmaxf(mx, fabsf(v));
+        sq = fmaf(v, v, sq);
+    }
+    __shared__ float smx[256], ssq[256];
+    smx[threadIdx.x] = mx; ssq[threadIdx.x] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + o]); ssq[threadIdx.x] += ssq[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicMax(max_bits, __float_as_uint(smx[0])); atomicAdd(sumsq, ssq[0]); }
+}
+
+static int envelope_stats(mgpt_gpt *g)
+{
+    const size_t C = g->C;
+    float *d = nullptr;                                    // [0] max bits, [1] sum of squares
+    MGPT_HIP(hipMalloc(&d, 2 * sizeof(float)));
+    g->env_max_w = 0.f; g->env_max_rms = 0.f;
+    int rc = MGPT_OK;
+    for (int l = 0; l < g->L && rc == MGPT_OK; l++) {
+        const LayerOff &lo = g->layers[l];
+        const size_t offs[4] = {lo.attn_w, lo.proj_w, lo.fc_w, lo.proj2_w}, cnt[4] = {3 * C * C, C * C, 4 * C * C, 4 * C * C};
+        for (int k = 0; k < 4; k++) {
+            if (hipMemset(d, 0, 2 * sizeof(float)) != hipSuccess) { rc = MGPT_ERR_HIP; break; }
+            hipLaunchKernelGGL(wstats_kernel, dim3(64), dim3(256), 0, nullptr, g->params + offs[k], (int64_t)cnt[k], reinterpret_cast<unsigned *>(d), d + 1);
+            float h[2];
+            if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { rc = MGPT_ERR_HIP; break; }
+            g->env_max_w = std::max(g->env_max_w, h[0]);
+            g->env_max_rms = std::max(g->env_max_rms, sqrtf(h[1] / (float)cnt[k]));
+        }
+    }
+    (void)hipFree(d);
+    if (rc != MGPT_OK) set_error("envelope statistics failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
 extern "C" int mgpt_gpt_finalize(mgpt_gpt *g)
 {
     MGPT_REQUIRE(g, MGPT_ERR_ARG, "NULL argument");
@@ -165,7 +209,24 @@ extern "C" int mgpt_gpt_finalize(mgpt_gpt *g)
         MGPT_REQUIRE(g->is_set[i], MGPT_ERR_STATE, "parameter tensor #%zu was never set (see mgpt_gpt_set_param)", i);
     int rc = gpt_fast_finalize(g);
     if (rc != MGPT_OK) return rc;
+    if ((rc = envelope_stats(g)) != MGPT_OK) return rc;
+    g->env_state = 0; g->env_probe_err = -1.f; g->env_logged = false;
     g->finalized = true;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_gpt_set_envelope_policy(mgpt_gpt *g, int policy)
+{
+    MGPT_REQUIRE(g && policy >= MGPT_ENVELOPE_FALLBACK && policy <= MGPT_ENVELOPE_IGNORE, MGPT_ERR_ARG, "envelope policy %d", policy);
+    g->env_policy = policy;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_gpt_envelope(mgpt_gpt *g, float *out3, int *state)
+{
+    MGPT_REQUIRE(g && out3 && state, MGPT_ERR_ARG, "NULL argument");
+    out3[0] = g->env_max_w; out3[1] = g->env_max_rms; out3[2] = g->env_probe_err;
+    *state = g->env_state;
     return MGPT_OK;
 }
 
@@ -286,20 +347,80 @@ extern "C" int mgpt_gpt_debug_copy_raw(mgpt_gpt *g, int precision, int which, vo
     return gpt_fast_debug_copy(g, precision, which, d_out, nbytes, (hipStream_t)stream);
 }
 
-extern "C" int mgpt_gpt_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, void *stream)
+// Decides once per finalized checkpoint whether MGPT_PREC_F16X3 requests are served by the split path: the weight statistics of
+// mgpt_gpt_finalize against the validated range, then MGPT_ENVELOPE_PROBE_ROWS fixed pseudo-random rows through both paths.
+// (Synchronises the stream: the first split-mode forward of a checkpoint must not sit inside a stream capture -- mgpt_step_run's
+// first step is eager for this and other first-use work.)
+static int envelope_decide(mgpt_gpt *g, hipStream_t s)
+{
+    const int n = std::min(g->max_rows, MGPT_ENVELOPE_PROBE_ROWS);
+    bool inside = g->env_max_w <= MGPT_ENVELOPE_MAX_W && g->env_max_rms <= MGPT_ENVELOPE_MAX_RMS;
+    if (inside) {
+        std::vector<uint8_t> h_tok((size_t)n * kT);
+        uint64_t st = 0x9e3779b97f4a7c15ull;
+        for (auto &t : h_tok) { st = st * 6364136223846793005ull + 1442695040888963407ull; t = (uint8_t)((st >> 33) % (uint64_t)kV); }
+        uint8_t *d_tok = nullptr; float *d_lg = nullptr;
+        MGPT_HIP(hipMalloc(&d_tok, h_tok.size()));
+        if (hipMalloc(&d_lg, (size_t)2 * n * kV * sizeof(float)) != hipSuccess) { (void)hipFree(d_tok); set_error("hipMalloc failed in the envelope probe"); return MGPT_ERR_HIP; }
+        int rc = MGPT_OK;
+        std::vector<float> h_lg((size_t)2 * n * kV);
+        if (hipMemcpyAsync(d_tok, h_tok.data(), h_tok.size(), hipMemcpyHostToDevice, s) != hipSuccess) rc = MGPT_ERR_HIP;
+        if (rc == MGPT_OK) rc = forward_f32_chunk(g, d_tok, n, d_lg, s);
+        if (rc == MGPT_OK) rc = gpt_fast_forward(g, d_tok, n, d_lg + (size_t)n * kV, MGPT_PREC_F16X3, s, n);
+        if (rc == MGPT_OK && hipMemcpyAsync(h_lg.data(), d_lg, h_lg.size() * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) rc = MGPT_ERR_HIP;
+        if (rc == MGPT_OK && hipStreamSynchronize(s) != hipSuccess) rc = MGPT_ERR_HIP;
+        (void)hipFree(d_tok); (void)hipFree(d_lg);
+        if (rc != MGPT_OK) { if (rc == MGPT_ERR_HIP) set_error("envelope probe failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
+        float err = 0.f;
+        for (size_t i = 0; i < (size_t)n * kV; i++) {
+            const float d = fabsf(h_lg[i] - h_lg[(size_t)n * kV + i]);
+            err = (d == d) ? std::max(err, d) : INFINITY;  // NaN counts as outside
+        }
+        g->env_probe_err = err;
+        inside = err <= MGPT_ENVELOPE_PROBE_TOL;
+    }
+    g->env_state = inside ? 1 : 2;
+    return MGPT_OK;
+}
+
+// call_rows: rows of the C-ABI call these rows belong to (mgpt_gpt_act chunks its rows itself), see gpt_ctx.h
+static int gpt_forward_impl(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, void *stream, int call_rows)
 {
     MGPT_REQUIRE(g && d_tokens && d_logits, MGPT_ERR_ARG, "NULL argument");
     MGPT_REQUIRE(rows > 0, MGPT_ERR_ARG, "rows=%d", rows);
     MGPT_REQUIRE(g->finalized, MGPT_ERR_STATE, "mgpt_gpt_finalize must precede forward");
     hipStream_t s = (hipStream_t)stream;
+    if (precision == MGPT_PREC_F16X3 && g->env_policy != MGPT_ENVELOPE_IGNORE) {
+        if (g->env_state == 0) {
+            const int rc = envelope_decide(g, s);
+            if (rc != MGPT_OK) return rc;
+        }
+        if (g->env_state == 2) {
+            MGPT_REQUIRE(g->env_policy != MGPT_ENVELOPE_REFUSE, MGPT_ERR_UNSUPPORTED,
+                         "checkpoint outside the validated f16x3 envelope (max|w| %.3g, rms %.3g, probe |f16x3 - f32| %.3g)",
+                         g->env_max_w, g->env_max_rms, g->env_probe_err);
+            if (!g->env_logged) {
+                fprintf(stderr, "mapf_gpt_amd: checkpoint outside the validated f16x3 envelope (max|w| %.3g of %.3g, rms %.3g of %.3g, probe |f16x3 - f32| %.3g of %.3g): "
+                                "MGPT_PREC_F16X3 requests run the exact-fp32 kernels (mgpt_gpt_set_envelope_policy to refuse or to ignore)\n",
+                        g->env_max_w, MGPT_ENVELOPE_MAX_W, g->env_max_rms, MGPT_ENVELOPE_MAX_RMS, g->env_probe_err, MGPT_ENVELOPE_PROBE_TOL);
+                g->env_logged = true;
+            }
+            precision = MGPT_PREC_F32;
+        }
+    }
     for (int r0 = 0; r0 < rows; r0 += g->max_rows) {
         const int n = std::min(g->max_rows, rows - r0);
         int rc;
         if (precision == MGPT_PREC_F32) rc = forward_f32_chunk(g, d_tokens + (size_t)r0 * kT, n, d_logits + (size_t)r0 * kV, s);
-        else rc = gpt_fast_forward(g, d_tokens + (size_t)r0 * kT, n, d_logits + (size_t)r0 * kV, precision, s);
+        else rc = gpt_fast_forward(g, d_tokens + (size_t)r0 * kT, n, d_logits + (size_t)r0 * kV, precision, s, call_rows);
         if (rc != MGPT_OK) return rc;
     }
     return MGPT_OK;
+}
+
+extern "C" int mgpt_gpt_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, void *stream)
+{
+    return gpt_forward_impl(g, d_tokens, rows, d_logits, precision, stream, rows);
 }
 
 extern "C" int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_actions, int do_sample, uint64_t seed,
@@ -324,7 +445,7 @@ static int gpt_act_impl(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int32_t 
     for (int r0 = 0; r0 < rows; r0 += g->max_rows) {
         const int n = std::min(g->max_rows, rows - r0);
         float *lg = d_logits ? d_logits + (size_t)r0 * kV : g->logits_tmp;
-        int rc = mgpt_gpt_forward(g, d_tokens + (size_t)r0 * kT, n, lg, precision, stream);
+        int rc = gpt_forward_impl(g, d_tokens + (size_t)r0 * kT, n, lg, precision, stream, rows);
         if (rc != MGPT_OK) return rc;
         ProfScope ps(P_SAMPLE, s);
         hipLaunchKernelGGL(sample_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, lg, n, d_actions + r0, do_sample,

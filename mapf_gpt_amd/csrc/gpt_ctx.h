@@ -22,13 +22,21 @@ struct mgpt_gpt {
     // fast-path state (gpt_fast.hip)
     void *fast = nullptr;
     uint64_t generation = 1;          // bumped when weight planes / workspaces are freed or rebuilt (common.h: gpt_generation)
+    // precision envelope of the split-fp16 mode (gpt.hip: envelope_*; include/mapf_gpt_amd.h: mgpt_gpt_envelope)
+    float env_max_w = 0.f, env_max_rms = 0.f;   // over the 2-D matrices of the blocks, computed by mgpt_gpt_finalize
+    float env_probe_err = -1.f;                 // max |f16x3 - f32| over the probe rows' logits (-1: not probed yet)
+    int env_policy = 0;                         // MGPT_ENVELOPE_FALLBACK / _REFUSE / _IGNORE
+    int env_state = 0;                          // 0 not decided, 1 inside, 2 outside
+    bool env_logged = false;
 };
 
 
 // gpt_fast.hip: 16-bit-MFMA path (packed operand planes, own workspace)
 int gpt_fast_finalize(mgpt_gpt *g);
 void gpt_fast_destroy(mgpt_gpt *g);
-int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, hipStream_t s);
+// call_rows = rows of the whole C-ABI call this chunk belongs to: path choices that change the arithmetic (the head-parallel small-launch
+// kernels) are made from it, so that every chunk of one call -- a ragged remainder included -- runs the same kernels
+int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, hipStream_t s, int call_rows);
 int gpt_fast_debug_copy(mgpt_gpt *g, int precision, int which, void *d_out, int64_t nbytes, hipStream_t s);
 
 // gpt.hip: final LayerNorm + tied lm_head on the last position of g->x (shared by both paths)

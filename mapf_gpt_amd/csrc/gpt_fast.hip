@@ -596,7 +596,7 @@ int launch_row_stats(const float *x, float2 *stats, int64_t n_tok, int C, hipStr
 }
 
 template <class T, int NP>
-int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, float *d_logits, hipStream_t s)
+int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, float *d_logits, hipStream_t s, int call_rows)
 {
     const int C = g->C;
     const int64_t M = (int64_t)rows * kT;
@@ -605,7 +605,8 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     // register-resident path (C = 64, 160; head size 32): a layer is attn_block_kernel + mlp_fused_kernel
     const bool attn_block = m->qkv_fused && g->hs == 32 && m->mlp_fused;
     // small launch: the heads of a row run on different CUs (attn_block_kernel<HP>), their partial sums are folded by the next kernel
-    const bool head_par = attn_block && rows <= kSmallRows && m->head_parts != nullptr;
+    // (decided by the CALL's row count, not the chunk's: the remainder chunk of a large call stays on the large-launch kernels)
+    const bool head_par = attn_block && call_rows <= kSmallRows && rows <= kSmallRows && m->head_parts != nullptr;
     const int64_t part_stride = (int64_t)kSmallRows * kT * C;
     // the first attention block forms x = wte[token] + wpe[position] itself (no embedding kernel, no first read of x)
     const bool embed_fused = attn_block && g->L > 1 && !head_par;
@@ -927,7 +928,7 @@ void gpt_fast_destroy(mgpt_gpt *g)
     g->fast = nullptr;
 }
 
-int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, hipStream_t s)
+int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, hipStream_t s, int call_rows)
 {
     MGPT_REQUIRE(precision == MGPT_PREC_F16X3 || precision == MGPT_PREC_BF16, MGPT_ERR_ARG, "unknown precision %d", precision);
     FastState *f = static_cast<FastState *>(g->fast);
@@ -945,8 +946,8 @@ int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_lo
         }
         if (rc != MGPT_OK) { free_mode(g, m); return rc; }         // no half-built planes survive a failed build (e.g. out of memory)
     }
-    if (precision == MGPT_PREC_F16X3) return forward_chunk<fastk::F16T, 2>(g, m, d_tokens, rows, d_logits, s);
-    return forward_chunk<fastk::BF16T, 1>(g, m, d_tokens, rows, d_logits, s);
+    if (precision == MGPT_PREC_F16X3) return forward_chunk<fastk::F16T, 2>(g, m, d_tokens, rows, d_logits, s, call_rows);
+    return forward_chunk<fastk::BF16T, 1>(g, m, d_tokens, rows, d_logits, s, call_rows);
 }
 
 // test/debug: raw copy of a fast-path workspace buffer of the given precision

@@ -30,7 +30,9 @@ class GPTConfig:          # = model.py:107-115 (same field names and defaults)
 
 
 class GPT:
-    def __init__(self, config, max_rows=2048, precision="f32", device="cuda"):
+    ENVELOPE_POLICIES = {"fallback": 0, "refuse": 1, "ignore": 2}      # include/mapf_gpt_amd.h: MGPT_ENVELOPE_*
+
+    def __init__(self, config, max_rows=2048, precision="f32", device="cuda", envelope="fallback"):
         if config.vocab_size != 67:
             raise ValueError("vocab_size must be 67 (observation_generator.cpp:321-344)")
         if config.bias or config.dropout != 0.0:
@@ -38,6 +40,12 @@ class GPT:
         self.config = config
         self.max_rows = int(max_rows)
         self.precision = precision
+        if envelope not in self.ENVELOPE_POLICIES:
+            raise ValueError(f"envelope must be one of {sorted(self.ENVELOPE_POLICIES)}")
+        # what happens to precision="f16x3" requests when the loaded checkpoint lies outside the range on which that mode's 1e-5
+        # logit bar was established: "fallback" = serve them with the exact-fp32 kernels (one line on stderr), "refuse" = raise,
+        # "ignore" = run the split path regardless (parity experiments).  See include/mapf_gpt_amd.h, mgpt_gpt_envelope.
+        self.envelope_policy = envelope
         self.device = torch.device(device)
         self._h = None
         self._loaded = False
@@ -53,6 +61,7 @@ class GPT:
             with torch.cuda.device(self.device):
                 _lib.check(_lib.lib().mgpt_gpt_create(ctypes.byref(h), c.n_layer, c.n_head, c.n_embd, c.block_size, self.max_rows))
             self._h = h
+            _lib.check(_lib.lib().mgpt_gpt_set_envelope_policy(h, self.ENVELOPE_POLICIES[self.envelope_policy]))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -95,6 +104,18 @@ class GPT:
         _lib.check(_lib.lib().mgpt_gpt_finalize(self._h))
         self._loaded = True
         return unknown
+
+    def envelope(self):
+        """Precision envelope of the loaded checkpoint: {max_abs_w, max_rms_w (over the block matrices), probe_err (max |f16x3 - f32|
+        over the probe rows' logits, None before the first f16x3 forward), state: "undecided" | "inside" | "outside",
+        effective_precision: what a precision="f16x3" request runs}."""
+        assert self._loaded, "load_state_dict first"
+        out, st = (ctypes.c_float * 3)(), ctypes.c_int(0)
+        _lib.check(_lib.lib().mgpt_gpt_envelope(self._h, out, ctypes.byref(st)))
+        state = ("undecided", "inside", "outside")[st.value]
+        eff = "f32" if (state == "outside" and self.envelope_policy == "fallback") else "f16x3"
+        return {"max_abs_w": float(out[0]), "max_rms_w": float(out[1]), "probe_err": (None if out[2] < 0 else float(out[2])),
+                "state": state, "policy": self.envelope_policy, "effective_precision": eff}
 
     # ---- compute ---------------------------------------------------------------------------
     def _prec(self, precision):
@@ -155,8 +176,11 @@ class GPT:
             # must not pin seed 0) and drawn again -- call counter back to 0 -- whenever that RNG was touched since our draw:
             # torch.manual_seed(s), also with the SAME s as before (the usual reproducibility pattern: the second run then
             # replays the first one's draws, as the reference's multinomial would), or any other consumer of the global stream.
-            state = torch.get_rng_state()
-            if getattr(self, "_act_seed", None) is None or not torch.equal(state, self._act_rng_after):
+            # (A seed pinned with reset_sampler(seed) is kept until reset_sampler() is called again: no look at the global RNG --
+            #  another thread's act() or any torch.manual_seed silently dropped the pin, and the 5-KB state snapshot of
+            #  every call sat on the one-environment latency path.)
+            pinned = getattr(self, "_act_pinned", False)
+            if not pinned and (getattr(self, "_act_seed", None) is None or not torch.equal(torch.get_rng_state(), self._act_rng_after)):
                 self._act_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
                 self._act_rng_after = torch.get_rng_state()
                 self._act_calls = 0
@@ -170,14 +194,15 @@ class GPT:
         self._act_calls = 0
         if seed is None:
             self._act_seed = None
+            self._act_pinned = False
         else:
             self._act_seed = int(seed)
-            self._act_rng_after = torch.get_rng_state()
+            self._act_pinned = True
 
 
-def build_model(name_or_args, seed=0, scale=1.0, max_rows=2048, precision="f32", device="cuda", state_dict=None):
+def build_model(name_or_args, seed=0, scale=1.0, max_rows=2048, precision="f32", device="cuda", state_dict=None, envelope="fallback"):
     """Convenience: GPT with the named shape ("2M", "6M", "85M", "tiny") and synthetic or given weights."""
     args = weights.model_args(name_or_args)
-    net = GPT(GPTConfig(**args), max_rows=max_rows, precision=precision, device=device)
+    net = GPT(GPTConfig(**args), max_rows=max_rows, precision=precision, device=device, envelope=envelope)
     net.load_state_dict(state_dict if state_dict is not None else weights.synthetic_state_dict(args, seed=seed, scale=scale))
     return net.eval()

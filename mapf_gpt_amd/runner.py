@@ -29,11 +29,12 @@ def shard_range(n_total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_metrics(local, n_total, rank=0, world=1, group=None):
+def gather_metrics(local, n_total, rank=0, world=1, group=None, force=False):
     """all_gather of per-instance metric records float32 [n_local, 5] -> [n_total, 5] on every rank.
     The only collective of the job (RCCL over xGMI with backend "nccl"; gloo on CPU for tests);
-    ~20 B x instances, latency-bound -- one call, no ring tuning."""
-    if world == 1:
+    ~20 B x instances, latency-bound -- one call, no ring tuning.  force: take the collective at world = 1 too (a process
+    group of one rank: how the RCCL branch is exercised on a one-GPU box, tests/test_gpu_bench.py)."""
+    if world == 1 and not force:
         return local
     import torch.distributed as dist
     dev = local.device
@@ -61,7 +62,7 @@ def make_instances(grid, n_inst, n_agents, first_seed=0, start_ok=None, goal_ok=
 
 class BatchedRunner:
     def __init__(self, grids, n_inst, n_agents, net, max_episode_steps=128, seed=0, do_sample=True, precision=None,
-                 device="cuda", row_offset=0, use_graph=True):
+                 device="cuda", row_offset=0, use_graph=False):
         self.device = torch.device(device)
         self.env = BatchedEnv(grids, n_inst, n_agents, max_episode_steps, device=device)
         self.tok = BatchedTokenizer(grids, n_inst, n_agents, device=device)
@@ -74,7 +75,10 @@ class BatchedRunner:
         self.actions = torch.full((n_inst, n_agents), -1, dtype=torch.int32, device=self.device)
         self.t = 0
         self._pos_ptr, self._goal_ptr, _ = self.env.state_ptrs()
-        # the whole step behind one library call, replayed as a hipGraph after the first (eager) step
+        # the whole step behind one library call.  use_graph=True replays it as a hipGraph after the first (eager) step: an OPTION since
+        # round 5, not the default -- a cfg1 step is 19 dependent launches that keep the GPU 97 % busy, so the replay has no launch cost
+        # to remove (0.279 ms against 0.272 ms eager, BENCH_r04); it stays for callers that want the host out of the loop, and
+        # tests/test_gpu_step_graph.py keeps it bit-identical to the eager path
         self.use_graph = bool(use_graph)
         self._step = ctypes.c_void_p()
         with torch.cuda.device(self.device):

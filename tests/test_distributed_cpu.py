@@ -71,3 +71,21 @@ def test_two_rank_sharding_and_metrics_gather(tmp_path):
     single = np.stack([_episode_metrics(grid, pos[i].numpy(), goal[i].numpy(), 16, seed=i) for i in range(n_total)])
     assert np.array_equal(r0, single)          # sharded run == single-process run, instance by instance
     assert (r0[:, 4] <= 16).all() and (r0[:, 1] >= 0).all() and (r0[:, 1] <= 1).all()
+
+
+def _worker_one(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapf_gpt_amd.runner import gather_metrics
+    local = torch.arange(15, dtype=torch.float32).reshape(3, 5)
+    assert gather_metrics(local, 3, 0, 1) is local                                # world = 1: no collective unless forced
+    np.save(os.path.join(out_dir, "one.npy"), gather_metrics(local, 3, 0, 1, force=True).numpy())
+    dist.destroy_process_group()
+
+
+def test_forced_collective_with_one_rank(tmp_path):
+    """gather_metrics(force=True) at world = 1 goes through all_gather of a one-rank group (the path bench.py takes under
+    MGPT_BENCH_FORCE_COLLECTIVE to exercise the RCCL branch on a one-GPU box) and returns the records unchanged."""
+    mp.start_processes(_worker_one, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    assert np.array_equal(np.load(tmp_path / "one.npy"), np.arange(15, dtype=np.float32).reshape(3, 5))

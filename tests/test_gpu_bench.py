@@ -59,3 +59,22 @@ def test_bench_single_rank_line():
     assert j["n_gpus"] == 1 and j["config"]["workload"].startswith("cfg3: wfi_warehouse, 192 agents, MAPF-GPT-6M")
     assert j["unit"] == "agent-steps/s" and j["dtype"] == "f16x3" and j["vs_baseline"] is None
     assert j["roofline"]["bound"] == "mfma" and j["roofline_tokenizer"]["bound"] == "hbm"
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """the backend "nccl" (= RCCL) branch -- init_process_group(device_id=...), the barriers, the
+    max-over-ranks all_reduce and the metrics all_gather on DEVICE tensors -- executed for real on a one-GPU box: bench.py under
+    torch.distributed.run with one rank and MGPT_BENCH_FORCE_COLLECTIVE=1 takes the N > 1 code path with a one-rank communicator."""
+    env = dict(os.environ, MGPT_BENCH_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MGPT_BENCH_BACKEND", None)
+    env.pop("MGPT_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--workload", "cfg4", "--instances", "6", "--precision", "f16x3", "--no-cpu-baseline", "--no-secondary", "--no-tokenizer-leg"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 1 and j["collective_backend"] == "nccl" and j["rccl_ranks"] == 1
+    assert j["rccl_version"] and j["rccl_version"][0].isdigit()
+    assert j["metrics_gathered_on"].startswith("cuda")
+    assert 0.0 <= j["config"]["mean_ISR_after_run"] <= 1.0

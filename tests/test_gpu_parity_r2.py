@@ -136,7 +136,9 @@ def test_256_real_rows_within_1e5_of_reference(shape, scale, precision):
     gpurun_out/parity_records.jsonl; the round's copy is profiles/r03_parity_records.jsonl."""
     from mapf_gpt_amd.model import build_model
     g = _big(shape, scale)
-    net = build_model(shape, seed=0, scale=float(scale), max_rows=64 if shape == "85M" else 128, precision=precision)
+    # envelope="ignore": this test measures the split-fp16 ARITHMETIC; what a drop-in user gets on a checkpoint outside the
+    # validated range is test_precision_envelope_is_a_runtime_property's subject
+    net = build_model(shape, seed=0, scale=float(scale), max_rows=64 if shape == "85M" else 128, precision=precision, envelope="ignore")
     logits = net.logits_tokens(torch.from_numpy(g["tokens"]).cuda()).cpu().numpy().astype(np.float64)
     e_ref = np.abs(g["logits_f32"].astype(np.float64) - g["logits_f64"]).max()
     e32 = np.abs(logits - g["logits_f32"]).max()
@@ -146,6 +148,11 @@ def test_256_real_rows_within_1e5_of_reference(shape, scale, precision):
     msg = f"{shape} x{scale} {precision}: vs fp32 ref {e32:.3e}, vs fp64 ref {e64:.3e} (reference fp32 vs fp64 {e_ref:.3e})"
     if precision == "f32" and (shape, scale) == ("85M", 4):
         assert e64 <= 2 * e_ref and e32 <= 2 * e_ref, msg
+    elif (shape, scale) == ("85M", 4):
+        # the one set on which the absolute bar cannot hold (the reference's own fp32 run is 3.64e-5 from its
+        # fp64 run) is held to what is MEASURED (profiles/r04_parity_records.jsonl: e32 5.66e-5, e64 3.77e-5 = 1.037 e_ref), not to
+        # an open multiple of e_ref
+        assert e32 <= 6.5e-5 and e64 <= 1.1 * e_ref, msg
     else:
         # e32 stays bounded in every case (it may exceed 1e-5 only where the reference's own fp32 run is further
         # than that from fp64, and then by at most twice that distance), and the fp64 yardstick gets real headroom: the recorded
@@ -165,7 +172,7 @@ def test_x8_weights_break_point_of_the_absolute_bar(shape, precision):
     the reference's fp32 run, within a factor of two."""
     from mapf_gpt_amd.model import build_model
     g = _big(shape, 8)
-    net = build_model(shape, seed=0, scale=8.0, max_rows=128, precision=precision)
+    net = build_model(shape, seed=0, scale=8.0, max_rows=128, precision=precision, envelope="ignore")     # (x8 lies outside the envelope: rms 0.16)
     logits = net.logits_tokens(torch.from_numpy(g["tokens"]).cuda()).cpu().numpy().astype(np.float64)
     e_ref = np.abs(g["logits_f32"].astype(np.float64) - g["logits_f64"]).max()
     e32 = np.abs(logits - g["logits_f32"]).max()
@@ -189,7 +196,7 @@ def test_heavy_tailed_weights_x20(shape):
             v[rng.random(v.shape) < 0.01] *= 20.0
     tok = torch.from_numpy(rng.integers(0, 67, (256, 256)).astype(np.uint8)).cuda()
     a = build_model(shape, precision="f32", max_rows=256, state_dict=sd).logits_tokens(tok).cpu().numpy()
-    b = build_model(shape, precision="f16x3", max_rows=256, state_dict=sd).logits_tokens(tok).cpu().numpy()
+    b = build_model(shape, precision="f16x3", max_rows=256, state_dict=sd, envelope="ignore").logits_tokens(tok).cpu().numpy()
     err = float(np.abs(a - b).max())
     record_parity(test="heavy_tails_x20", shape=shape, precision="f16x3 vs f32", err=err, max_abs_logit=float(np.abs(a).max()))
     assert err <= TOL, f"{shape}: max |f16x3 - f32| = {err:.3e} at |logits| <= {np.abs(a).max():.2f}"
@@ -301,3 +308,43 @@ def test_generatorless_act_advances_between_calls():
     a = net.act(idx).cpu().numpy()
     net.reset_sampler(seed=5)
     assert np.array_equal(a, net.act(idx).cpu().numpy())
+
+
+def test_precision_envelope_is_a_runtime_property():
+    """the range on which precision="f16x3" meets the 1e-5 bar is checked at load time, per checkpoint
+    (include/mapf_gpt_amd.h: MGPT_ENVELOPE_*): weight statistics at finalize, a probe of 8 fixed rows through both paths at the first
+    f16x3 forward.  N(0, 0.02) weights: inside, the split path runs.  x100 outliers on 1 % of the entries (max|w| ~ 9: where the
+    split path is 1e-4 .. 1e-3 off): outside; "fallback" serves the request with the exact-fp32 kernels (bit-identical to
+    precision="f32", and as close to the fp64 port as torch's own fp32 forward), "refuse" raises, "ignore" runs the split path."""
+    from mapf_gpt_amd.model import build_model
+    from oracle import gpt_oracle
+    rng = np.random.Generator(np.random.PCG64(5))
+    rows = np.load(os.path.join(GOLDEN, "gptbig_6M_s1.npz"))["tokens"][:16]
+    tok = torch.from_numpy(rows).cuda()
+    ok = build_model("6M", seed=0, max_rows=16, precision="f16x3")
+    assert ok.envelope()["state"] == "undecided"
+    ok.logits_tokens(tok)
+    e = ok.envelope()
+    assert e["state"] == "inside" and e["effective_precision"] == "f16x3" and e["probe_err"] <= 1e-5 and e["max_abs_w"] < 0.2, e
+    sd = weights.synthetic_state_dict("6M", seed=3)
+    for k, v in sd.items():
+        if v.ndim == 2 and "wte" not in k and "wpe" not in k:
+            v[rng.random(v.shape) < 0.01] *= 100.0
+    guarded = build_model("6M", precision="f16x3", max_rows=16, state_dict=sd)
+    a = guarded.logits_tokens(tok).cpu().numpy()
+    e = guarded.envelope()
+    assert e["state"] == "outside" and e["effective_precision"] == "f32" and e["max_abs_w"] > 2.5, e
+    exact = build_model("6M", precision="f32", max_rows=16, state_dict=sd).logits_tokens(tok).cpu().numpy()
+    assert np.array_equal(a, exact), "the guard must hand the request to the exact-fp32 kernels"
+    raw = build_model("6M", precision="f16x3", max_rows=16, state_dict=sd, envelope="ignore").logits_tokens(tok).cpu().numpy()
+    ref64 = gpt_oracle.forward_logits(sd, weights.model_args("6M"), rows, dtype=torch.float64).numpy()
+    ref32 = gpt_oracle.forward_logits(sd, weights.model_args("6M"), rows).numpy().astype(np.float64)
+    e_ref, e_guard, e_raw = np.abs(ref32 - ref64).max(), np.abs(a - ref64).max(), np.abs(raw - ref64).max()
+    record_parity(test="envelope_x100", shape="6M", e_guarded_vs_fp64=e_guard, e_split_vs_fp64=e_raw, e_torch_fp32_vs_fp64=e_ref,
+                  max_abs_logit=float(np.abs(ref64).max()), max_abs_w=e["max_abs_w"], max_rms_w=e["max_rms_w"])
+    assert e_guard <= max(TOL, 2.0 * e_ref), f"guarded {e_guard:.3e}, torch fp32 {e_ref:.3e} (split path unguarded: {e_raw:.3e})"
+    with pytest.raises(RuntimeError, match="envelope"):
+        build_model("6M", precision="f16x3", max_rows=16, state_dict=sd, envelope="refuse").logits_tokens(tok)
+    x8 = build_model("6M", seed=0, scale=8.0, precision="f16x3", max_rows=16)
+    x8.logits_tokens(tok)
+    assert x8.envelope()["state"] == "outside" and x8.envelope()["max_rms_w"] > 0.1
