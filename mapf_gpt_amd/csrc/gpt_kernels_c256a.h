@@ -216,7 +216,18 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
     };
     auto other_half_max = [&](float v) { float a, b2; half_swap(v, a, b2); return fmaxf(a, b2); };
     auto other_half_sum = [&](float v) { float a, b2; half_swap(v, a, b2); return a + b2; };
+    // Units of q and k.  Round 4 (and the -DMGPT_AB_ATTN_CLUMPED / _RUNMAX builds): the planes carry the raw accumulators, i.e. q and k
+    // times the weight stream's power-of-two scale, and the softmax multiplies every score by sc2.  Default build: the accumulators are
+    // brought to q * log2(e) / sqrt(hs) and to k (true units) before they are split -- 32 multiplies per head -- so that a score IS
+    // the exponent and the per-score multiply-add of the key-tile loop goes (see "one reference per query" below): sc2 = 1.
+#if defined(MGPT_AB_ATTN_CLUMPED) || defined(MGPT_AB_ATTN_RUNMAX)
+    constexpr bool QK_UNITS = false;
     const float sc2 = scale_log2e * inv_scale * inv_scale; // softmax exponent scale for q.k in weight-scaled units
+#else
+    constexpr bool QK_UNITS = true;
+    const float sc2 = 1.0f;
+#endif
+    const float q_units = scale_log2e * inv_scale, k_units = inv_scale;
     // (the four K / V^T lane addresses are recomputed at the top of every head from lane16 through an opaque copy: as row-loop
     //  invariants they cost four registers that this kernel does not have -- one variant of it kept one in scratch, and the
     //  reload put a compiler vmcnt(0), which drains the ring, in front of every attention phase)
@@ -333,6 +344,10 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
             step_pair(I2{}, P4S{}, nothing, std::true_type{});
             step_pair(I3{}, P4{}, nothing, std::true_type{});
             u32x4 qf[2][2];                                // B operand of S^T = K Q^T: [k-step][plane]
+            if constexpr (QK_UNITS) {
+#pragma unroll
+                for (int g = 0; g < 16; g++) { qa[g] *= q_units; ka[g] *= k_units; }
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) pack_octet(qa, ks, qf[ks]);
             {   // k -> sK[pl][key = tok0 + r][octet ks][half h]   (all waves passed this head's step syncs: the head before -- or the
@@ -728,13 +743,18 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                 for (int ks = 0; ks < 2; ks++) sA = amma(kf[ks], qf[ks], sA);
                 __builtin_amdgcn_sched_barrier(0);
                 load_k(I1{});
-                // the reference of the head: the maximum of the query's first key tile.  sA[g] = S[query r][key tau(g, h)] (times 1 / inv_scale^2)
-                float nm;
+                // the reference of the head: the maximum of the query's first key tile.  sA[g] = S[query r][key tau(g, h)], in exponent
+                // units (QK_UNITS).  The scores of tiles 1-7 START from -reference: the first S MFMA of a tile takes the block nmb (the
+                // value in all 16 registers) as its C operand, so that exp2 applies to the accumulator as it is -- 16 multiply-adds per
+                // tile fewer; tile 0, whose scores exist before the reference does, pays 16 additions once per head.
+                f32x16 nmb;
                 {
                     float mx = sA[0];
 #pragma unroll
                     for (int g = 1; g < 16; g++) mx = fmaxf(mx, sA[g]);
-                    nm = -other_half_max(mx) * sc2;
+                    const float nm = -other_half_max(mx);
+#pragma unroll
+                    for (int g = 0; g < 16; g++) { nmb[g] = nm; sA[g] += nm; }
                 }
                 float l_part = 0.f;                        // this lane's half of the row sum (all eight tiles)
                 auto tile = [&](auto kt_c, f32x16 &cur, f32x16 &nxt) {
@@ -748,7 +768,7 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                         o = amma(vf[1], pf[1], o);
 #pragma unroll
                         for (int g = 0; g < 4; g++) {
-                            cur[g] = __builtin_amdgcn_exp2f(fmaf(cur[g], sc2, nm));
+                            cur[g] = __builtin_amdgcn_exp2f(cur[g]);
                             l_part += cur[g];
                         }
                         place(std::integral_constant<int, NM>{}, std::integral_constant<int, 4>{});
@@ -764,20 +784,18 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
                     // (read issued after K of tile kt + 1: V^T k-step 0 of tile kt)
                     if constexpr (!LASTT) {
                         lgkm(LV{});
-#pragma unroll
-                        for (int g = 0; g < 16; g++) nxt[g] = 0.f;
-#pragma unroll
-                        for (int ks = 0; ks < 2; ks++) nxt = amma(kf[ks], qf[ks], nxt);
+                        nxt = amma(kf[0], qf[0], nmb);
+                        nxt = amma(kf[1], qf[1], nxt);
                     }
 #if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
 #pragma unroll
                     for (int g = FIRSTT ? 0 : 4; g < 16; g++) {
-                        cur[g] = __builtin_amdgcn_exp2f(fmaf(cur[g], sc2, nm));
+                        cur[g] = __builtin_amdgcn_exp2f(cur[g]);
                         l_part += cur[g];
                     }
                     pack_octet(cur, 0, pf[0]);
 #else
-                    l_part += cur[3] + nm;
+                    l_part += cur[3];
 #pragma unroll
                     for (int e = 0; e < 4; e++) { pf[0][0][e] = __builtin_bit_cast(unsigned, cur[e]); pf[0][1][e] = __builtin_bit_cast(unsigned, cur[4 + e]); }
 #endif
