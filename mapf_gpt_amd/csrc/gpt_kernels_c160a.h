@@ -193,7 +193,14 @@ __global__ __launch_bounds__(512, 2) void attn160o_kernel(float *__restrict__ x,
     };
     auto other_half_max = [&](float v) { float a, b2; half_swap(v, a, b2); return fmaxf(a, b2); };
     auto other_half_sum = [&](float v) { float a, b2; half_swap(v, a, b2); return a + b2; };
+    // units of q and k: see attn256o_kernel (default build: exponent units, 32 multiplies per head before the split)
+#if defined(MGPT_AB_ATTN_CLUMPED)
+    constexpr bool QK_UNITS = false;
     const float sc2 = scale_log2e * inv_scale * inv_scale; // softmax exponent scale for q.k in weight-scaled units
+#else
+    constexpr bool QK_UNITS = true;
+#endif
+    const float q_units = scale_log2e * inv_scale, k_units = inv_scale;
 
     u32x4 xn[KS][2];                                       // operand planes: LayerNorm(x) during the heads, y during the tail
 
@@ -308,6 +315,10 @@ __global__ __launch_bounds__(512, 2) void attn160o_kernel(float *__restrict__ x,
             step(I0{}, I0{}, P4S{}, nothing, std::true_type{});
             step(I0{}, I1{}, P4S{}, nothing, std::true_type{});
             u32x4 qf[2][2];                                // B operand of S^T = K Q^T: [k-step][plane]
+            if constexpr (QK_UNITS) {
+#pragma unroll
+                for (int g = 0; g < 16; g++) { qa[g] *= q_units; ka[g] *= k_units; }
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) pack_octet(qa, ks, qf[ks]);
             {   // k -> sK[pl][key = tok0 + r][octet ks][half h]   (all waves passed this head's step syncs: the head before -- or the
@@ -350,75 +361,15 @@ __global__ __launch_bounds__(512, 2) void attn160o_kernel(float *__restrict__ x,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                  // k, v^T of the head complete
 
-            // ---- attention of this wave's 32 queries against the 256 keys of the head (model.py:58-60: no mask) ----
+            // ---- attention of this wave's 32 queries against the 256 keys of the head (model.py:58-60: no mask): the pipelined
+            //      key-tile loop of attn256o_kernel (round 5, gpt_kernels_attn_tiles.h; exact running-maximum loop as its fallback) ----
             f32x16 o;
-#pragma unroll
-            for (int g = 0; g < 16; g++) o[g] = 0.f;
-            float m_run = -INFINITY, l_run = 0.f;
-            {
-                u32x4 kf[2][2], vf[2][2];
-                auto load_k = [&](int kt) {                // K fragments of key tile kt: [k-step][plane]
-                    const unsigned a = kr_addr + (unsigned)kt * (32 * KROW);
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][0]) : "v"(a) : "memory");
-                    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(kf[1][0]) : "v"(a) : "memory");
-                    if (NP == 2) {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][1]) : "v"(a), "n"(kT * KROW) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][1]) : "v"(a), "n"(kT * KROW + 32) : "memory");
-                    } else { kf[0][1] = kf[0][0]; kf[1][1] = kf[1][0]; }
-                };
-                load_k(0);
-#pragma unroll 1
-                for (int kt = 0; kt < kT / 32; kt++) {
-                    f32x16 sc;
-#pragma unroll
-                    for (int g = 0; g < 16; g++) sc[g] = 0.f;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int ks = 0; ks < 2; ks++) sc = mma<T, NP>(kf[ks], qf[ks], sc);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // V^T fragments of this tile, then K of the next one (both land during the softmax arithmetic)
-                    {
-                        const unsigned a = vr_addr + (unsigned)kt * 64;
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[0][0]) : "v"(a) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(vf[1][0]) : "v"(a) : "memory");
-                        if (NP == 2) {
-                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[0][1]) : "v"(a), "n"(HS * VROW) : "memory");
-                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[1][1]) : "v"(a), "n"(HS * VROW + 32) : "memory");
-                        } else { vf[0][1] = vf[0][0]; vf[1][1] = vf[1][0]; }
-                    }
-                    if (kt + 1 < kT / 32) load_k(kt + 1);
-                    // sc[g] = S[query r][key 32 kt + tau(g, h)]  (times 1/inv_scale^2)
-                    float mx = sc[0];
-#pragma unroll
-                    for (int g = 1; g < 16; g++) mx = fmaxf(mx, sc[g]);
-                    mx = other_half_max(mx);
-                    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {        // some query's running max moved: rescale (wave-uniform branch)
-                        const float m_new = fmaxf(m_run, mx);
-                        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
-                        l_run *= alpha;
-#pragma unroll
-                        for (int g = 0; g < 16; g++) o[g] *= alpha;
-                        m_run = m_new;
-                    }
-                    const float nm = -m_run * sc2;
-                    float psum = 0.f;
-#pragma unroll
-                    for (int g = 0; g < 16; g++) {
-                        sc[g] = __builtin_amdgcn_exp2f(fmaf(sc[g], sc2, nm));
-                        psum += sc[g];
-                    }
-                    l_run += other_half_sum(psum);
-                    u32x4 pf[2][2];
-#pragma unroll
-                    for (int mm = 0; mm < 2; mm++) pack_octet(sc, mm, pf[mm]);
-                    if (kt + 1 < kT / 32) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NP) : "memory");   // v^T fragments landed, K of the next tile may fly
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mm = 0; mm < 2; mm++) o = mma<T, NP>(vf[mm], pf[mm], o);
-                }
-            }
+            float l_run = 0.f;
+#if defined(MGPT_AB_ATTN_CLUMPED)
+            attention_exact_tiles<T, NP, KROW, VROW, HS>(kr_addr, vr_addr, qf, sc2, o, l_run);
+#else
+            attention_tiles<T, NP, KROW, VROW, HS>(kr_addr, vr_addr, qf, lane, o, l_run);
+#endif
             // ---- y planes of the head: o[g] = O[query r][d = tau(g, h)] / l, times the v projection's weight scale: register
             //      octet kk = k-step 2 hd + kk of the out-projection's B operand ----
             {

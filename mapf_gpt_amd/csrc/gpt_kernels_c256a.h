@@ -25,24 +25,10 @@
 // c_proj pre-scaled by a power of two, fp32 accumulation over k = head-major d); results per token do not depend on the grid.
 #pragma once
 #include "gpt_kernels_c256p.h"
-
-// VALU instructions placed behind each MFMA of the attention phase's sub-blocks A / B1 / B2 (see the key-tile loop below)
-#ifndef MGPT_ATT_NVA
-#define MGPT_ATT_NVA 6
-#endif
-#ifndef MGPT_ATT_NVB1
-#define MGPT_ATT_NVB1 10
-#endif
-#ifndef MGPT_ATT_NVB2
-#define MGPT_ATT_NVB2 6
-#endif
+#include "gpt_kernels_attn_tiles.h"
 
 namespace mgpt {
 namespace fastk {
-
-// waves that threw a head of the pipelined attention loop away and redid it with the exact loop (attn256o_kernel below); read by
-// mgpt_debug_counter (tests: zero on the synthetic N(0, 0.02) checkpoints, non-zero when the scores are made to spread)
-__device__ unsigned long long g_attn_fallbacks = 0;
 
 constexpr int kA256oProjSteps = 16;
 constexpr int kA256oPeriod = 8 * kA256StepsPerHead + kA256oProjSteps;     // stream steps per row
@@ -216,11 +202,11 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
     };
     auto other_half_max = [&](float v) { float a, b2; half_swap(v, a, b2); return fmaxf(a, b2); };
     auto other_half_sum = [&](float v) { float a, b2; half_swap(v, a, b2); return a + b2; };
-    // Units of q and k.  Round 4 (and the -DMGPT_AB_ATTN_CLUMPED / _RUNMAX builds): the planes carry the raw accumulators, i.e. q and k
+    // Units of q and k.  Round 4 (and the -DMGPT_AB_ATTN_CLUMPED build): the planes carry the raw accumulators, i.e. q and k
     // times the weight stream's power-of-two scale, and the softmax multiplies every score by sc2.  Default build: the accumulators are
     // brought to q * log2(e) / sqrt(hs) and to k (true units) before they are split -- 32 multiplies per head -- so that a score IS
     // the exponent and the per-score multiply-add of the key-tile loop goes (see "one reference per query" below): sc2 = 1.
-#if defined(MGPT_AB_ATTN_CLUMPED) || defined(MGPT_AB_ATTN_RUNMAX)
+#if defined(MGPT_AB_ATTN_CLUMPED)
     constexpr bool QK_UNITS = false;
     const float sc2 = scale_log2e * inv_scale * inv_scale; // softmax exponent scale for q.k in weight-scaled units
 #else
@@ -419,427 +405,17 @@ __global__ __launch_bounds__(512, 2) void attn256o_kernel(float *__restrict__ x,
             phase(3);
             __builtin_amdgcn_s_barrier();                  // k, v^T of the head complete
 
-            // ---- attention of this wave's 32 queries against the 256 keys of the head ----
+            // ---- attention of this wave's 32 queries against the 256 keys of the head (gpt_kernels_attn_tiles.h) ----
             f32x16 o;
             float l_run = 0.f;
-            // The EXACT loop (round 4): online softmax with a running maximum per query, one key tile after the other (6 S MFMAs, the
-            // softmax arithmetic, 6 PV MFMAs).  Since round 5 it is the FALLBACK of the pipelined loop below (and the whole phase under
-            // -DMGPT_AB_ATTN_CLUMPED): a wave whose scores outgrow the fp16 range of the P planes redoes its head here.
-            auto attention_exact = [&]() {
-                // (the start values come out of an opaque asm: as plain constants hipcc hoisted a zero block and -inf out of the ROW loop
-                //  -- this path being cold -- and paid for their 17 registers with spills in the LayerNorm prologue)
-                float m_run, zero;
-                asm volatile("v_mov_b32 %0, 0xff800000\n\tv_mov_b32 %1, 0" : "=v"(m_run), "=v"(zero));
-                l_run = zero;
-#pragma unroll
-                for (int g = 0; g < 16; g++) o[g] = zero;
-            {
-                u32x4 kf[2][2], vf[2][2];
-                auto load_k = [&](int kt) {                // K fragments of key tile kt: [k-step][plane]
-                    const unsigned a = kr_addr + (unsigned)kt * (32 * KROW);
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][0]) : "v"(a) : "memory");
-                    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(kf[1][0]) : "v"(a) : "memory");
-                    if (NP == 2) {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][1]) : "v"(a), "n"(kT * KROW) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][1]) : "v"(a), "n"(kT * KROW + 32) : "memory");
-                    } else { kf[0][1] = kf[0][0]; kf[1][1] = kf[1][0]; }
-                };
-                load_k(0);
-#pragma unroll 1
-                for (int kt = 0; kt < kT / 32; kt++) {
-                    f32x16 sc;
-#pragma unroll
-                    for (int g = 0; g < 16; g++) sc[g] = 0.f;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int ks = 0; ks < 2; ks++) sc = mma<T, NP>(kf[ks], qf[ks], sc);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // V^T fragments of this tile, then K of the next one (both land during the softmax arithmetic)
-                    {
-                        const unsigned a = vr_addr + (unsigned)kt * 64;
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[0][0]) : "v"(a) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(vf[1][0]) : "v"(a) : "memory");
-                        if (NP == 2) {
-                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[0][1]) : "v"(a), "n"(HS * VROW) : "memory");
-                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[1][1]) : "v"(a), "n"(HS * VROW + 32) : "memory");
-                        } else { vf[0][1] = vf[0][0]; vf[1][1] = vf[1][0]; }
-                    }
-                    if (kt + 1 < kT / 32) load_k(kt + 1);
-                    // sc[g] = S[query r][key 32 kt + tau(g, h)]  (times 1/inv_scale^2)
-                    float mx = sc[0];
-#pragma unroll
-                    for (int g = 1; g < 16; g++) mx = fmaxf(mx, sc[g]);
-                    mx = other_half_max(mx);
-                    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {        // some query's running max moved: rescale (wave-uniform branch)
-                        const float m_new = fmaxf(m_run, mx);
-                        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
-                        l_run *= alpha;
-#pragma unroll
-                        for (int g = 0; g < 16; g++) o[g] *= alpha;
-                        m_run = m_new;
-                    }
-                    const float nm = -m_run * sc2;
-                    // (Two variants of this loop were built and measured in round 4, A/B in one box, cfg3 attention ms per step:
-                    //  v_pk_fma_f32 / v_pk_add_f32 on score pairs, 15 instructions fewer per key tile: 54.5 against 53.9;
-                    //  software pipelining -- the S MFMAs of tile kt + 1 issued before the softmax arithmetic of tile kt, the second
-                    //  score block in the 16 registers of the next step's prefetched weight fragments, bit-identical results: 54.2
-                    //  against 54.0.  Neither the count of full-rate VALU instructions nor the MFMA / VALU order inside a wave
-                    //  bounds this phase: the second wave of the SIMD already fills the gaps, and what is saved in cycles comes
-                    //  back as a lower clock (HISTORY.md section 12, round 3).)
-                    float psum = 0.f;
-#pragma unroll
-                    for (int g = 0; g < 16; g++) {
-                        sc[g] = __builtin_amdgcn_exp2f(fmaf(sc[g], sc2, nm));
-                        psum += sc[g];
-                    }
-                    l_run += other_half_sum(psum);
-                    u32x4 pf[2][2];
-#pragma unroll
-                    for (int mm = 0; mm < 2; mm++) pack_octet(sc, mm, pf[mm]);
-                    if (kt + 1 < kT / 32) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NP) : "memory");   // v^T fragments landed, K of the next tile may fly
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mm = 0; mm < 2; mm++) o = mma<T, NP>(vf[mm], pf[mm], o);
-                }
-            }
-            };
 #if defined(MGPT_AB_ATTN_CLUMPED)
-            attention_exact();
-#elif defined(MGPT_AB_ATTN_RUNMAX)
-            float m_run = -INFINITY;
-            {
-                // Round 5: the key-tile loop as a MODULO-SCHEDULED pipeline, placed one MFMA at a time.  Round 4's loop ran a tile as
-                // three clumps -- 6 S MFMAs, ~95 VALU of softmax, 6 PV MFMAs -- and on this chip clumped issue times ADD, also across
-                // the two waves of a SIMD (stamps: 1 700 - 1 940 cycles per tile pair = 768 of matrix pipe + ~900 of VALU issue), while
-                // ~6 VALU instructions per MFMA are free when they sit BETWEEN MFMAs (profiles/r02_probe_interleave.txt).  So tile kt's
-                // softmax arithmetic now rides under the MFMAs of its neighbours:
-                //     A   max of S(kt)                                   under   PV, second k-step, of tile kt - 1   (3 MFMAs)
-                //     R   rescale when some query's running max moved (rare, wave-uniform branch)
-                //     B1  exp2 / row sum of S(kt), split of octet 0      under   S(kt + 1) -> the other score block  (6 MFMAs)
-                //     B2  split of octet 1, running sum                  under   PV, first k-step, of tile kt        (3 MFMAs)
-                // Same products, same order of every accumulation as before (o: PV(kt - 1) completes before tile kt's rescale and
-                // PV(kt) follows; l: tile by tile), so the results are bit-identical to round 4's loop (-DMGPT_AB_ATTN_CLUMPED).
-                // Registers: two score blocks instead of one; the 16 registers come from NOT holding the next step's first weight
-                // fragments across the phase (they are requested under the last tile instead, see below).
-                // LDS reads of the phase return in issue order; per tile: V^T k-step 1 of tile kt (2 NP / 2... NP reads), K of tile
-                // kt + 2 (2 NP), V^T k-step 0 of tile kt + 1 (NP).  lgkmcnt(N): N = reads issued after the one needed.
-                u32x4 kf[2][2], vf[2][2], pf[2][2];
-                f32x16 sA, sB;                             // score blocks of the even / odd key tiles
-                constexpr int NM = NP == 2 ? 3 : 1;        // MFMAs per k-step
-#ifdef MGPT_ABL_ATT                                        // tools/bench_probes/check_attn256o.hip only (results are wrong): 1 = no MFMAs, 2 = no softmax arithmetic in the phase
-                auto amma = [&](const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16 c) {
-                    if constexpr ((MGPT_ABL_ATT & 1) != 0) { asm volatile("" : "+v"(c)); return c; }
-                    else return mma<T, NP>(a, b, c);
-                };
+            attention_exact_tiles<T, NP, KROW, VROW, HS>(kr_addr, vr_addr, qf, sc2, o, l_run);
 #else
-                auto amma = [&](const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16 c) { return mma<T, NP>(a, b, c); };
-#endif
-                auto load_k = [&](auto kt_c) {             // K fragments of key tile kt: [k-step][plane]
-                    constexpr int off = decltype(kt_c)::value * (32 * KROW);
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][0]) : "v"(kr_addr), "n"(off) : "memory");
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][0]) : "v"(kr_addr), "n"(off + 32) : "memory");
-                    if (NP == 2) {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][1]) : "v"(kr_addr), "n"(off + kT * KROW) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][1]) : "v"(kr_addr), "n"(off + kT * KROW + 32) : "memory");
-                    } else { kf[0][1] = kf[0][0]; kf[1][1] = kf[1][0]; }
-                };
-                auto load_v = [&](auto kt_c, auto mm_c) {  // V^T fragments of key tile kt, k-step mm: [plane]
-                    constexpr int off = decltype(kt_c)::value * 64 + decltype(mm_c)::value * 32, mm = decltype(mm_c)::value;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[mm][0]) : "v"(vr_addr), "n"(off) : "memory");
-                    if (NP == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[mm][1]) : "v"(vr_addr), "n"(off + HS * VROW) : "memory");
-                    else vf[mm][1] = vf[mm][0];
-                };
-                auto lgkm = [&](auto n_c) {
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(n_c)::value) : "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                // NMF MFMAs, each followed by NV VALU instructions; what is left of the VALU work goes behind the last one
-                auto place = [&](auto nmf_c, auto nv_c) {
-#pragma unroll
-                    for (int n = 0; n < decltype(nmf_c)::value; n++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, decltype(nv_c)::value, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                using LK = std::integral_constant<int, 2 * NP>;       // reads of one K tile
-                using LV = std::integral_constant<int, NP>;           // reads of one V^T k-step
-                load_k(I0{});
-                lgkm(I0{});
-#pragma unroll
-                for (int g = 0; g < 16; g++) sA[g] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 2; ks++) sA = amma(kf[ks], qf[ks], sA);
-                __builtin_amdgcn_sched_barrier(0);
-                load_k(I1{});
-                load_v(I0{}, I0{});
-                auto tile = [&](auto kt_c, f32x16 &cur, f32x16 &nxt) {
-                    constexpr int kt = decltype(kt_c)::value;
-                    constexpr bool FIRSTT = kt == 0, LASTT = kt == kT / 32 - 1, HAS2 = kt + 2 < kT / 32;
-                    // ---- A: max of this tile's scores under the second k-step of the previous tile's PV ----
-                    // (reads issued after V^T k-step 1 of tile kt - 1: K of tile kt + 1, V^T k-step 0 of tile kt)
-                    if constexpr (!FIRSTT) lgkm(std::integral_constant<int, (LASTT ? 0 : LK::value) + LV::value>{});
-                    if constexpr (!FIRSTT) o = amma(vf[1], pf[1], o);
-                    // cur[g] = S[query r][key 32 kt + tau(g, h)]  (times 1 / inv_scale^2)
-                    float mx = cur[0];
-#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
-#pragma unroll
-                    for (int g = 1; g < 16; g++) mx = fmaxf(mx, cur[g]);
-                    mx = other_half_max(mx);
-#endif
-                    place(std::integral_constant<int, FIRSTT ? 0 : NM>{}, std::integral_constant<int, MGPT_ATT_NVA>{});
-                    asm volatile("" : "+v"(o));
-                    load_v(kt_c, I1{});
-                    // ---- R ----
-                    if constexpr (FIRSTT) {
-                        m_run = mx;                        // (round 4's loop scaled o = 0 and l = 0 by exp2(-inf) = 0 here: the same values)
-                    } else if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {     // some query's running max moved: rescale (wave-uniform branch)
-                        const float m_new = fmaxf(m_run, mx);
-                        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
-                        l_run *= alpha;
-#pragma unroll
-                        for (int g = 0; g < 16; g++) o[g] *= alpha;
-                        m_run = m_new;
-                    }
-                    const float nm = -m_run * sc2;
-                    __builtin_amdgcn_sched_barrier(0);
-                    // ---- B1: exponentials, row sum, split of octet 0 under S(kt + 1) ----
-                    // (reads issued after K of tile kt + 1: V^T k-step 0 and k-step 1 of tile kt)
-                    if constexpr (!LASTT) {
-                        lgkm(std::integral_constant<int, 2 * LV::value>{});
-#pragma unroll
-                        for (int g = 0; g < 16; g++) nxt[g] = 0.f;
-#pragma unroll
-                        for (int ks = 0; ks < 2; ks++) nxt = amma(kf[ks], qf[ks], nxt);
-                    }
-                    float psum = 0.f;
-#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
-#pragma unroll
-                    for (int g = 0; g < 16; g++) {
-                        cur[g] = __builtin_amdgcn_exp2f(fmaf(cur[g], sc2, nm));
-                        psum += cur[g];
-                    }
-                    pack_octet(cur, 0, pf[0]);
-#else
-                    psum = cur[3] + nm;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { pf[0][0][e] = __builtin_bit_cast(unsigned, cur[e]); pf[0][1][e] = __builtin_bit_cast(unsigned, cur[4 + e]); }
-#endif
-                    place(std::integral_constant<int, LASTT ? 0 : 2 * NM>{}, std::integral_constant<int, MGPT_ATT_NVB1>{});
-                    if constexpr (!LASTT) asm volatile("" : "+v"(nxt));
-                    if constexpr (HAS2) load_k(std::integral_constant<int, HAS2 ? kt + 2 : 0>{});
-                    // ---- B2: split of octet 1, running sum under the first k-step of this tile's PV ----
-                    // (reads issued after V^T k-step 0 of tile kt: V^T k-step 1 of tile kt, K of tile kt + 2)
-                    lgkm(std::integral_constant<int, LV::value + (HAS2 ? LK::value : 0)>{});
-                    if constexpr (FIRSTT) {                // (o starts here: a zero block held across the first tile cost 16 registers -- hipcc spilled it)
-#pragma unroll
-                        for (int g = 0; g < 16; g++) o[g] = 0.f;
-                    }
-                    o = amma(vf[0], pf[0], o);
-#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
-                    pack_octet(cur, 1, pf[1]);
-                    l_run += other_half_sum(psum);
-#else
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { pf[1][0][e] = __builtin_bit_cast(unsigned, cur[8 + e]); pf[1][1][e] = __builtin_bit_cast(unsigned, cur[12 + e]); }
-                    l_run += psum;
-#endif
-                    place(std::integral_constant<int, NM>{}, std::integral_constant<int, MGPT_ATT_NVB2>{});
-                    asm volatile("" : "+v"(o));
-                    if constexpr (!LASTT) load_v(std::integral_constant<int, LASTT ? 0 : kt + 1>{}, I0{});
-                };
-                using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
-                using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>; using K6 = std::integral_constant<int, 6>; using K7 = std::integral_constant<int, 7>;
-                static_assert(kT / 32 == 8, "eight key tiles");
-                tile(K0{}, sA, sB); tile(K1{}, sB, sA); tile(K2{}, sA, sB); tile(K3{}, sB, sA);
-                tile(K4{}, sA, sB); tile(K5{}, sB, sA); tile(K6{}, sA, sB); tile(K7{}, sB, sA);
-                // the second k-step of the last tile's PV; under it, the first pairs of the next stream step (the step after this
-                // phase; its slot landed for every wave before the last v step's barrier) -- round 4 requested them in that step's
-                // chunk 3 and held their 16 registers across the whole phase
-                lgkm(I0{});
-                o = amma(vf[1], pf[1], o);
-                __builtin_amdgcn_sched_barrier(0);
-                lds_pair(nxt_addr, I0{}, wb[0][0]);
-                lds_pair(nxt_addr, I1{}, wb[0][1]);
-            }
-#else
-            {
-                // Round 5: the key-tile loop as a MODULO-SCHEDULED pipeline placed one MFMA at a time, with ONE reference per query.
-                // What the hardware does (tools/bench_probes/probe_interleave.hip, profiles/r05_probe_interleave.txt): the two waves of a
-                // SIMD TIME-SLICE -- a second wave adds 5-10 % of throughput, an MFMA of one wave never covers the VALU work of the other
-                // -- and inside ONE wave about six VALU instructions ride free behind every MFMA when they are placed BETWEEN MFMAs;
-                // beyond that every VALU instruction costs its 4 cycles and every MFMA ~15.  Round 4's loop ran a tile as three clumps
-                // (6 S MFMAs, ~95 VALU, 6 PV MFMAs: 1 700 - 1 940 cycles per tile pair of a SIMD, the sum of everything).  Two changes:
-                // (1) PIPELINE.  Tile kt's softmax arithmetic rides under the MFMAs of its neighbours:
-                //         B1  exp2, row sum, split of octet 0     under   PV k-step 1 of tile kt - 1 (3 MFMAs) and S(kt + 1) -> the other
-                //                                                         score block (6 MFMAs), two chains alternating
-                //         B2  split of octet 1, sums              under   PV k-step 0 of tile kt (3 MFMAs)
-                //     (-DMGPT_AB_ATTN_RUNMAX: the same with round 4's running maximum, bit-identical to round 4: 53.5 -> 51.2 ms of
-                //      attention per cfg3 step, profiles/r05_ab.txt).
-                // (2) FEWER VALU INSTRUCTIONS: the phase is VALU-issue bound (~95 per tile against 12 MFMAs), so the running maximum
-                //     goes (8 v_max3 + half swap + compare + branch per tile): every query takes the maximum of its FIRST key tile as
-                //     the reference of the whole head, p = exp2(s - ref) may exceed 1, and the cross-half sums of l are taken once per
-                //     head.  Softmax is shift-invariant, fp32 carries p, l and o up to 2^127; the one thing that is not free is the
-                //     fp16 range of the P planes (hi = fp16(p) <= 65504): a wave in which a lane's half-row sum reaches 60 000 (some
-                //     score more than ~11 nats above its query's first-tile maximum), or is not finite, throws its head away and
-                //     redoes it with attention_exact() (wave-uniform branch; K and V^T stay in LDS until the next head's writes, which
-                //     wait for every wave).  Deterministic per row: the decision depends on the wave's own 32 queries only.
-                // LDS reads of the phase return in issue order; per tile: [after B1a] V^T k-step 0 of tile kt (NP reads); [B1 end] V^T k-step
-                // 1 of tile kt (NP); [B2 end] K of tile kt + 2 (2 NP).  lgkmcnt(N): N = reads issued after the one needed.
-                u32x4 kf[2][2], vf[2][2], pf[2][2];
-                f32x16 sA, sB;                             // score blocks of the even / odd key tiles
-                constexpr int NM = NP == 2 ? 3 : 1;        // MFMAs per k-step
-#ifdef MGPT_ABL_ATT                                        // tools/bench_probes/check_attn256o.hip only (results are wrong): 1 = no MFMAs, 2 = no softmax arithmetic in the phase
-                auto amfma = [&](u32x4 a, u32x4 b2, f32x16 c) {
-                    if constexpr ((MGPT_ABL_ATT & 1) != 0) { asm volatile("" : "+v"(c)); return c; }
-                    else return T::mfma(a, b2, c);
-                };
-#else
-                auto amfma = [&](u32x4 a, u32x4 b2, f32x16 c) { return T::mfma(a, b2, c); };
-#endif
-                auto amma = [&](const u32x4 (&a)[2], const u32x4 (&b2)[2], f32x16 c) {     // = mma<T, NP>: small terms first
-                    if (NP == 2) { c = amfma(a[1], b2[0], c); c = amfma(a[0], b2[1], c); }
-                    return amfma(a[0], b2[0], c);
-                };
-                auto load_k = [&](auto kt_c) {             // K fragments of key tile kt: [k-step][plane]
-                    constexpr int off = decltype(kt_c)::value * (32 * KROW);
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][0]) : "v"(kr_addr), "n"(off) : "memory");
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][0]) : "v"(kr_addr), "n"(off + 32) : "memory");
-                    if (NP == 2) {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][1]) : "v"(kr_addr), "n"(off + kT * KROW) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][1]) : "v"(kr_addr), "n"(off + kT * KROW + 32) : "memory");
-                    } else { kf[0][1] = kf[0][0]; kf[1][1] = kf[1][0]; }
-                };
-                auto load_v = [&](auto kt_c, auto mm_c) {  // V^T fragments of key tile kt, k-step mm: [plane]
-                    constexpr int off = decltype(kt_c)::value * 64 + decltype(mm_c)::value * 32, mm = decltype(mm_c)::value;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[mm][0]) : "v"(vr_addr), "n"(off) : "memory");
-                    if (NP == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[mm][1]) : "v"(vr_addr), "n"(off + HS * VROW) : "memory");
-                    else vf[mm][1] = vf[mm][0];
-                };
-                auto lgkm = [&](auto n_c) {
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(n_c)::value) : "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                // NMF MFMAs, each followed by NV VALU instructions; what is left of the VALU work goes behind the last one
-                auto place = [&](auto nmf_c, auto nv_c) {
-#pragma unroll
-                    for (int n = 0; n < decltype(nmf_c)::value; n++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, decltype(nv_c)::value, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                using LK = std::integral_constant<int, 2 * NP>;       // reads of one K tile
-                using LV = std::integral_constant<int, NP>;           // reads of one V^T k-step
-                load_k(I0{});
-                lgkm(I0{});
-#pragma unroll
-                for (int g = 0; g < 16; g++) sA[g] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 2; ks++) sA = amma(kf[ks], qf[ks], sA);
-                __builtin_amdgcn_sched_barrier(0);
-                load_k(I1{});
-                // the reference of the head: the maximum of the query's first key tile.  sA[g] = S[query r][key tau(g, h)], in exponent
-                // units (QK_UNITS).  The scores of tiles 1-7 START from -reference: the first S MFMA of a tile takes the block nmb (the
-                // value in all 16 registers) as its C operand, so that exp2 applies to the accumulator as it is -- 16 multiply-adds per
-                // tile fewer; tile 0, whose scores exist before the reference does, pays 16 additions once per head.
-                f32x16 nmb;
-                {
-                    float mx = sA[0];
-#pragma unroll
-                    for (int g = 1; g < 16; g++) mx = fmaxf(mx, sA[g]);
-                    const float nm = -other_half_max(mx);
-#pragma unroll
-                    for (int g = 0; g < 16; g++) { nmb[g] = nm; sA[g] += nm; }
-                }
-                float l_part = 0.f;                        // this lane's half of the row sum (all eight tiles)
-                auto tile = [&](auto kt_c, f32x16 &cur, f32x16 &nxt) {
-                    constexpr int kt = decltype(kt_c)::value;
-                    constexpr bool FIRSTT = kt == 0, LASTT = kt == kT / 32 - 1, HAS2 = kt + 2 < kT / 32;
-                    // ---- B1a: the second k-step of the previous tile's PV; the first exponentials ----
-                    // (read issued after V^T k-step 1 of tile kt - 1: K of tile kt + 1)
-#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
-                    if constexpr (!FIRSTT) {
-                        lgkm(std::integral_constant<int, LASTT ? 0 : LK::value>{});
-                        o = amma(vf[1], pf[1], o);
-#pragma unroll
-                        for (int g = 0; g < 4; g++) {
-                            cur[g] = __builtin_amdgcn_exp2f(cur[g]);
-                            l_part += cur[g];
-                        }
-                        place(std::integral_constant<int, NM>{}, std::integral_constant<int, 4>{});
-                        asm volatile("" : "+v"(o));
-                    }
-#else
-                    if constexpr (!FIRSTT) { lgkm(std::integral_constant<int, LASTT ? 0 : LK::value>{}); o = amma(vf[1], pf[1], o); __builtin_amdgcn_sched_barrier(0); }
-#endif
-                    // (V^T k-step 0 of THIS tile is requested only here, and K of tile kt + 2 only after B2: requested earlier their registers
-                    //  were live next to pf[1] / vf[1] above resp. next to the three P planes of B2, and xn paid for them with scratch)
-                    load_v(kt_c, I0{});
-                    // ---- B1b: the rest of the exponentials, row sum, split of octet 0 under S(kt + 1) ----
-                    // (read issued after K of tile kt + 1: V^T k-step 0 of tile kt)
-                    if constexpr (!LASTT) {
-                        lgkm(LV{});
-                        nxt = amma(kf[0], qf[0], nmb);
-                        nxt = amma(kf[1], qf[1], nxt);
-                    }
-#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
-#pragma unroll
-                    for (int g = FIRSTT ? 0 : 4; g < 16; g++) {
-                        cur[g] = __builtin_amdgcn_exp2f(cur[g]);
-                        l_part += cur[g];
-                    }
-                    pack_octet(cur, 0, pf[0]);
-#else
-                    l_part += cur[3];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { pf[0][0][e] = __builtin_bit_cast(unsigned, cur[e]); pf[0][1][e] = __builtin_bit_cast(unsigned, cur[4 + e]); }
-#endif
-                    place(std::integral_constant<int, LASTT ? 0 : 2 * NM>{}, std::integral_constant<int, MGPT_ATT_NVB1>{});
-                    if constexpr (!LASTT) asm volatile("" : "+v"(nxt));
-                    load_v(kt_c, I1{});
-                    // ---- B2: split of octet 1 under the first k-step of this tile's PV ----
-                    // (read issued after V^T k-step 0 of tile kt: V^T k-step 1 of tile kt)
-                    lgkm(LV{});
-                    if constexpr (FIRSTT) {                // (o starts here: a zero block held across the first tile cost 16 registers -- hipcc spilled it)
-#pragma unroll
-                        for (int g = 0; g < 16; g++) o[g] = 0.f;
-                    }
-                    o = amma(vf[0], pf[0], o);
-#if !defined(MGPT_ABL_ATT) || (MGPT_ABL_ATT & 2) == 0
-                    pack_octet(cur, 1, pf[1]);
-#else
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { pf[1][0][e] = __builtin_bit_cast(unsigned, cur[8 + e]); pf[1][1][e] = __builtin_bit_cast(unsigned, cur[12 + e]); }
-#endif
-                    place(std::integral_constant<int, NM>{}, std::integral_constant<int, MGPT_ATT_NVB2>{});
-                    asm volatile("" : "+v"(o));
-                    if constexpr (HAS2) load_k(std::integral_constant<int, HAS2 ? kt + 2 : 0>{});
-                };
-                using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
-                using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>; using K6 = std::integral_constant<int, 6>; using K7 = std::integral_constant<int, 7>;
-                static_assert(kT / 32 == 8, "eight key tiles");
-                tile(K0{}, sA, sB); tile(K1{}, sB, sA); tile(K2{}, sA, sB); tile(K3{}, sB, sA);
-                tile(K4{}, sA, sB); tile(K5{}, sB, sA); tile(K6{}, sA, sB); tile(K7{}, sB, sA);
-                // the second k-step of the last tile's PV
-                lgkm(I0{});
-                o = amma(vf[1], pf[1], o);
-                __builtin_amdgcn_sched_barrier(0);
-                l_run = other_half_sum(l_part);
-                // every p is positive, so a half-row sum below 60 000 bounds every p of the lane; !(a < b) is also true for NaN
-                if (__builtin_amdgcn_ballot_w64(!(l_part < 60000.0f)) != 0) {
-                    if (lane == 0) atomicAdd(&g_attn_fallbacks, 1ull);
-                    attention_exact();
-                }
-                // the first pairs of the next stream step (the step after this phase; its slot landed for every wave before the last
-                // v step's barrier) -- round 4 requested them in that step's chunk 3 and held their 16 registers across the whole phase
-                lds_pair(nxt_addr, I0{}, wb[0][0]);
-                lds_pair(nxt_addr, I1{}, wb[0][1]);
-            }
+            attention_tiles<T, NP, KROW, VROW, HS>(kr_addr, vr_addr, qf, lane, o, l_run);
+            // the first pairs of the next stream step (the step after this phase; its slot landed for every wave before the last
+            // v step's barrier) -- round 4 requested them in that step's chunk 3 and held their 16 registers across the whole phase
+            lds_pair(nxt_addr, I0{}, wb[0][0]);
+            lds_pair(nxt_addr, I1{}, wb[0][1]);
 #endif
             // ---- y planes of the head: o[g] = O[query r][d = tau(g, h)] / l, times the v projection's weight scale: register
             //      octet kk = k-step 2 hd + kk of the out-projection's B operand ----
