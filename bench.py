@@ -33,6 +33,9 @@ import torch  # noqa: E402
 WORKLOADS = {
     # name: (map, agents, instances per GPU, model, max_episode_steps)   -- BASELINE.json configs
     "cfg1": ("validation-random-seed-000", 32, 1, "2M", 128),
+    # env6M: ONE environment on the 6M model -- how the reference evaluates it (eval_configs/01-random/01-random.yaml:145-148, one
+    # environment per worker; inference.py:148-172): 64 agents = 64 rows per step, the small-launch kernels of the 6M shape
+    "env6M": ("validation-mazes-seed-000", 64, 1, "6M", 128),
     "cfg2": ("validation-mazes-seed-000", 64, 256, "2M", 128),
     "cfg3": ("wfi_warehouse", 192, 64, "6M", 128),
     # cfg4 = BASELINE configs[3]: 4096 instances over 8 GPUs = 512 per GPU; every instance has its own synthetic map, half
@@ -556,11 +559,11 @@ def secondary_shard(name, precision, steps, warmup, local_rank, coll_dev, instan
     return out
 
 
-TRAFFIC_FILE = "r04_hbm_traffic.json"
+TRAFFIC_FILE = "r05_hbm_traffic.json"
 
 
 def traffic_for(kernel_key, rows_per_launch=None):
-    """HBM bytes per launch from THIS round's committed PMC passes (profiles/r04_hbm_traffic.json; no fallback to earlier
+    """HBM bytes per launch from THIS round's committed PMC passes (profiles/r05_hbm_traffic.json; no fallback to earlier
     rounds' files -- VERDICT r03: a stale entry is worse than null): a replay of a rocprofv3 run of this command, NOT a
     measurement of this run.  An entry that records the launch size it was measured at is only used for launches of that size."""
     tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
@@ -717,6 +720,16 @@ def main():
                                         "ms_per_step_graph_replay": c1["graph"], "graph_speedup": c1["eager"] / c1["graph"],
                                         "steps": 120, "warmup": 8, "dtype": a.precision,
                                         "note": "value = eager launches (the default); the hipGraph replay of the step is an option (use_graph=True), timed beside it"}
+            torch.cuda.empty_cache()
+            # one 64-agent environment on the 6M model: launch-latency bound, eager launches
+            w6 = build_workload("env6M", a.precision, 0, 1, local_rank)
+            dt6, _ = timed_steps(w6, 60, 6, 1, False, coll_dev)
+            out["secondary"]["env6M"] = {"workload": "one environment: validation-mazes-seed-000, 64 agents, MAPF-GPT-6M shape, 1 instance, 64 rows/step",
+                                         "value": 64 * 60 / dt6, "unit": "agent-steps/s", "ms_per_step": 1e3 * dt6 / 60, "steps": 60, "warmup": 6,
+                                         "dtype": a.precision,
+                                         "note": "calls of <= 128 rows take the small-launch kernels of the 6M shape (head-parallel attention + packed out-projection, "
+                                                 "64-token MLP blocks, one-launch last layer + head): DESIGN section 3.2"}
+            del w6
             torch.cuda.empty_cache()
             # BASELINE configs[3] and [4]: the per-GPU shards of the two 8-GPU configurations, under this run's clock
             if name != "cfg4":

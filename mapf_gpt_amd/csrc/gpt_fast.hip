@@ -55,6 +55,12 @@ constexpr bool kMlp160Half = false;
 #else
 constexpr bool kMlp160Half = true;
 #endif
+// -DMGPT_AB_NO_SMALL256 keeps small launches of the 6M shape on the row-per-workgroup kernels
+#ifdef MGPT_AB_NO_SMALL256
+constexpr bool kSmall256 = false;
+#else
+constexpr bool kSmall256 = true;
+#endif
 #ifdef MGPT_AB_NO_LAST1_TAIL
 constexpr bool kLast1Tail = false;
 #else
@@ -235,6 +241,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         }
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256p_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      fastk::kMPLds<NP>));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256p_kernel<T, NP, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     fastk::kMPLds<NP>));
         m->attn256 = (g->hs == 32 && g->nh == 8);
         if (m->attn256) {
             const size_t n16 = (size_t)8 * fastk::kA256StepsPerHead * 8 * NP * 512;
@@ -270,6 +278,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             }
             MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256_kernel<T, NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
             MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256_kernel<T, NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
+            MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256_kernel<T, NP, false, 0, fastk::kA256Stagger, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
         }
     } else if (m->mlp_fused) {
         const size_t frags = C / 16 + 2 * (C / 32), nt = 4 * C / 32;
@@ -374,8 +384,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
     if (g->hs == 32 && (C == 256 || C == 160 || C == 64) && m->mlp_fused) {
         // the last layer's attention block for token 255 alone (attn_last1_kernel): fp32 transposes of W_q, W_v and c_proj.weight
         const LayerOff &lo = g->layers[g->L - 1];
-        // (C = 160 / 64 also: c_fc.weight and mlp.c_proj.weight transposed, for the one-launch last layer + head of small launches)
-        const bool tail = C != 256;
+        // (also c_fc.weight and mlp.c_proj.weight transposed, for the one-launch last layer + head of small launches; C = 256 since round 5)
+        const bool tail = true;
         MGPT_HIP(hipMalloc(&m->last1_wt, (size_t)(tail ? 11 : 3) * C * C * sizeof(float)));
         struct { size_t off; int rows, cols; size_t dst; } mats[5] = {
             {lo.attn_w, (int)C, (int)C, 0}, {lo.attn_w + (size_t)2 * C * C, (int)C, (int)C, (size_t)C * C}, {lo.proj_w, (int)C, (int)C, (size_t)2 * C * C},
@@ -389,7 +399,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
 #define MGPT_LAST1_LDS(C_, R_, TAIL_)                                                                                                          \
     MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn_last1_kernel<C_, 32, R_, TAIL_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  fastk::kLast1Lds<C_, R_, TAIL_>))
-        if (C == 256) { MGPT_LAST1_LDS(256, fastk::kLast1R, false); MGPT_LAST1_LDS(256, 1, false); }
+        if (C == 256) { MGPT_LAST1_LDS(256, fastk::kLast1R, false); MGPT_LAST1_LDS(256, 1, false); MGPT_LAST1_LDS(256, 1, true); }
         else if (C == 160) { MGPT_LAST1_LDS(160, fastk::kLast1R, false); MGPT_LAST1_LDS(160, 1, true); }
         else { MGPT_LAST1_LDS(64, fastk::kLast1R, false); MGPT_LAST1_LDS(64, 1, true); }
 #undef MGPT_LAST1_LDS
@@ -418,6 +428,8 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_VT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     fastk::gemm_pk_lds(NP, 4, fastk::EPI_RESID)));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      lds + fastk::kGeluLutN * 8));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 8, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds + 3072));
@@ -547,7 +559,7 @@ int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
 }
 
 template <class T, int NP, int EPI>
-int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
+int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s, bool half_tiles = false)
 {
     constexpr int NST = fastk::gemm_pk_nst(NP, 8, EPI), KPS = fastk::gemm_pk_kps(NP);
     MGPT_REQUIRE(a.M % 256 == 0 && a.N % 256 == 0 && a.K % 32 == 0 && a.K >= 16 * KPS * NST, MGPT_ERR_UNSUPPORTED,
@@ -559,6 +571,10 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s)
         MGPT_REQUIRE(EPI != fastk::EPI_GELU || lut, MGPT_ERR_STATE, "%s", "folded LayerNorm: the GELU epilogue needs the Phi table");
         hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8, 0, true>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
                            (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0) + 3072, s, a, (unsigned long long *)nullptr);
+    } else if (EPI == fastk::EPI_RESID && half_tiles) {
+        // small launches (one environment's out-projection: 32 tiles of 256 rows would leave 7 of 8 CUs idle): 128-row tiles, 4 waves
+        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 4>), dim3((unsigned)((a.M / 128) * a.n_tiles_n)), dim3(256),
+                           (size_t)fastk::gemm_pk_lds(NP, 4, EPI), s, a, (unsigned long long *)nullptr);
     } else {
         hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
                            (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0), s, a, (unsigned long long *)nullptr);
@@ -655,12 +671,16 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         const bool last_short = (attn_block || m->pk_gemm) && l == g->L - 1;
         const int rows_pad = ((rows + 255) / 256) * 256;
         // 6M shape, every layer but the last: attn256o_kernel does the out-projection and the residual add itself
-        const bool proj_fused = m->attn256 && !last_short && kAttn256Fused;
+        // ... unless the CALL is small (one environment, rows <= kSmallRows): then a row's eight heads run on eight CUs at once
+        // (attn256_kernel<.., HP>, one workgroup per (row, head), y planes) and the packed GEMM projects them (round 5)
+        const bool small256 = m->attn256 && !last_short && call_rows <= kSmallRows && rows <= kSmallRows && kSmall256;
+        const bool proj_fused = m->attn256 && !last_short && kAttn256Fused && !small256;
         // last layer of a launch that fills the chip: the attention block of token 255 alone, without K and V (attn_last1_kernel)
         const bool last1 = last_short && m->last1_wt != nullptr && m->x_tiled && !head_par && kLast1;
         // small launch (one environment): the last layer's attention block, its MLP block, ln_f and the head are ONE launch, one
         // workgroup per row (attn_last1_kernel<.., 1, TAIL>), fp32 throughout; logits come straight out of it
-        const bool last_tail = last_short && head_par && m->last1_wt != nullptr && C != 256 && kLast1 && kLast1Tail;
+        const bool small_call = head_par || (m->attn256 && call_rows <= kSmallRows && rows <= kSmallRows && kSmall256);
+        const bool last_tail = last_short && small_call && m->last1_wt != nullptr && kLast1 && kLast1Tail;
         if (last_tail) {
             ProfScope ps(P_ATTN_LAST, s);
             const float *wk = P + lo.attn_w + (size_t)C * C;
@@ -668,7 +688,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     hipLaunchKernelGGL((fastk::attn_last1_kernel<C_, 32, 1, true>), dim3((unsigned)rows), dim3(256 * fastk::last1_split(C_)),              \
                        (size_t)(fastk::kLast1Lds<C_, 1, true>), s, g->x, P + lo.ln1, wk, m->last1_wt, (float *)nullptr, rows, scale_log2e,    \
                        P + lo.ln2, P + g->off_lnf, P + g->off_wte, d_logits, kV)
-            if (C == 160) MGPT_LAST1T(160); else MGPT_LAST1T(64);
+            if (C == 256) MGPT_LAST1T(256); else if (C == 160) MGPT_LAST1T(160); else MGPT_LAST1T(64);
 #undef MGPT_LAST1T
             MGPT_LAUNCH_CHECK();
             return MGPT_OK;
@@ -727,6 +747,9 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if (last_short)
                 hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, true>), dim3((unsigned)rows), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
                                    m->attn256_pk[l], m->attn256_inv[l], scale_log2e, m->y_last, (unsigned long long *)nullptr);
+            else if (small256)
+                hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, false, 0, fastk::kA256Stagger, true>), dim3((unsigned)rows * 8), dim3(512), (size_t)kA256Lds<NP>, s,
+                                   g->x, m->attn256_pk[l], m->attn256_inv[l], scale_log2e, m->y[0], (unsigned long long *)nullptr);
             else
                 hipLaunchKernelGGL((fastk::attn256_kernel<T, NP, false>), dim3((unsigned)rows), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
                                    m->attn256_pk[l], m->attn256_inv[l], scale_log2e, m->y[0], (unsigned long long *)nullptr);
@@ -784,7 +807,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                     a.raw_out = m->apk; a.rsum_out = m->ln_parts;
                     a.shift = m->ln_mean; a.shift_stride = ls ? kT : 1; a.shift_offset = ls ? kT - 1 : 0;
                 }
-                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
+                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s, small256)) != MGPT_OK) return rc;
                 a.raw_out = nullptr; a.rsum_out = nullptr; a.shift = nullptr;
             } else if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
@@ -797,6 +820,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if (C == 256) {
                 // persistent: one workgroup per CU walks the 128-token blocks round-robin (results do not depend on the grid)
                 const int n_blocks = (int)(mlp_M / 128);
+                if (small256 && 2 * n_blocks <= m->n_cu)
+                    // small launch: 64-token blocks, four waves with a SIMD each (mlp256p_kernel<.., NPAIR = 2>): twice the workgroups
+                    hipLaunchKernelGGL((fastk::mlp256p_kernel<T, NP, 0, 2>), dim3((unsigned)std::min(2 * n_blocks, m->n_cu)), dim3(256), (size_t)fastk::kMPLds<NP>, s,
+                                       mlp_x, m->mlp256_pk[l], m->mlp256_inv1[l], m->proj2[l].inv_scale, m->mlp256_lut[l], 2 * n_blocks, (unsigned long long *)nullptr);
+                else
                 hipLaunchKernelGGL((fastk::mlp256p_kernel<T, NP>), dim3((unsigned)std::min(n_blocks, m->n_cu)), dim3(512), (size_t)fastk::kMPLds<NP>, s,
                                    mlp_x, m->mlp256_pk[l], m->mlp256_inv1[l], m->proj2[l].inv_scale, m->mlp256_lut[l], n_blocks, (unsigned long long *)nullptr);
                 if (!m->pk_gemm && l + 1 < g->L) {                       // this kernel leaves no LayerNorm statistics behind

@@ -486,7 +486,12 @@ __global__ __launch_bounds__(256) void pack_attn256_kernel(const float *__restri
 // 4 no attention phase, 8 no projection MFMAs, 16 no ring barriers -- results are wrong unless ABL == 0.  32: wave 0 of every
 // block leaves stamps[block][8] = {entry cycles, entry 100-MHz ticks, cycles after LayerNorm, exit cycles, exit ticks,
 // cycles in the q|k|v projection steps, cycles waiting at the head's k / v barrier, cycles in the attention phase}.
-template <class T, int NP, bool LAST, int ABL = 0, int STG = kA256Stagger>
+// HP (head-parallel, round 5: small launches -- one environment's rows on the 6M shape): one workgroup per (row, head), grid = rows * 8.
+// The workgroup forms the row's LayerNorm itself and runs ONE head (its six steps of the c_attn stream); the heads' y planes meet in
+// the y matrix, and the packed-GEMM out-projection that follows adds the residual.  A row's eight heads then run on eight CUs at
+// once instead of one after the other on one (117 -> ~30 us per attention block of a 32-row launch).  Same arithmetic per token as
+// the row-per-workgroup form (bit-identical y planes).
+template <class T, int NP, bool LAST, int ABL = 0, int STG = kA256Stagger, bool HP = false>
 __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict__ x,
                                                          const uint16_t *__restrict__ wstream, float inv_scale, float scale_log2e,
                                                          uint16_t *__restrict__ y, unsigned long long *stamps = nullptr)
@@ -510,12 +515,19 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int64_t b = blockIdx.x;
+    static_assert(!HP || !LAST, "the head-parallel form serves the full layers");
+    const int64_t b = HP ? blockIdx.x / NH : blockIdx.x;
+    const int hd_lo = HP ? (int)(blockIdx.x - b * NH) : 0;                                // heads of this workgroup: [hd_lo, hd_hi)
+    int hd_hi = HP ? hd_lo + 1 : NH;
+    // (opaque: with a trip count of one known at compile time hipcc drops the head loop, schedules the body as straight-line code and
+    //  spills 63 dwords -- and scratch traffic counts in vmcnt, which breaks every hand-counted wait of the ring protocol: NaN)
+    if constexpr (HP) asm volatile("" : "+s"(hd_hi));
+    const int nstep = HP ? SPH : NH * SPH;                 // stream steps of this workgroup, starting at step hd_lo * SPH
     const int tok0 = wave * 32;
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned lds0 = (unsigned)(size_t)smem + lane16;
     const unsigned sK = (unsigned)(size_t)smem + NSLOT * STEP, sV = sK + NP * kT * KROW;
-    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(wave * PW) * 1024;   // wave-uniform
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(wave * PW) * 1024 + (size_t)(hd_lo * SPH) * STEP;   // wave-uniform
     const bool full = !LAST || wave == NW - 1;             // wave-uniform: does this wave run the attention?
     int gstep = 0;
 
@@ -578,11 +590,24 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
     //      and the slot of step G-1 is free; it is refilled with step G+NSLOT-1.  STORES = y stores of this wave that are
     //      younger than the pieces waited for (they retire in issue order behind them). ----
     auto sync = [&](bool stores_younger) {                 // (wave-uniform flag)
-        if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3) + NST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSLOT - 3)) : "memory");
+        // pieces younger than those of step G + 1: the steps G + 2, G + 3 -- as far as the stream goes.  (Rounds 3-4 allowed two steps'
+        // worth of pieces at the end of the stream too, where fewer are in flight: the wait then covered nothing and the last steps'
+        // pieces had landed only because they were issued three steps earlier.  Found in round 5, when the head-parallel form made
+        // the stream six steps long.)
+        const int beyond = nstep - 2 - gstep;              // >= 2: both issued, 1: only G + 2, <= 0: none
+        if (beyond >= 2) {
+            if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * 2 + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * 2) : "memory");
+        } else if (beyond == 1) {
+            if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        } else {
+            if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         if constexpr (STG >= 100) { if (wave >= NW / 2) __builtin_amdgcn_s_sleep(STG - 100); }   // probe: phase offset in the projection steps
-        if (!(ABL & 1) && gstep + NSLOT - 1 < NSTEP) issue(gstep + NSLOT - 1, slot_prev);   // (gstep + NSLOT - 1) % NSLOT
+        if (!(ABL & 1) && gstep + NSLOT - 1 < nstep) issue(gstep + NSLOT - 1, slot_prev);   // (gstep + NSLOT - 1) % NSLOT
         gstep++;
     };
     // (all asm destinations are arch VGPRs here: with no "a" constraint in the kernel hipcc gives the whole 256-register
@@ -660,16 +685,16 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
     if constexpr ((ABL & 32) != 0) { ts[2] = __builtin_readcyclecounter(); t_mark = ts[2]; }
 
 #pragma unroll 1
-    for (int hd = 0; hd < NH; hd++) {
+    for (int hd = hd_lo; hd < hd_hi; hd++) {
         // ---- steps 0-3: q and k tiles (swapped: lane = token, registers = d) ----
         f32x16 qa, ka;
 #pragma unroll
         for (int g = 0; g < 16; g++) { qa[g] = 0.f; ka[g] = 0.f; }
         // y stores of the previous head's attention are younger than the pieces that steps 0-2 wait for (see sync)
-        const bool st_young = hd > 0 && full;
+        const bool st_young = hd > hd_lo && full;
         auto step_qk = [&](auto j_c) {
             constexpr int j = decltype(j_c)::value;
-            if (j > 0 || hd > 0) step_begin(j < 3 && st_young);
+            if (j > 0 || hd > hd_lo) step_begin(j < 3 && st_young);
             auto chunk = [&](auto c_c) {
                 constexpr int c = decltype(c_c)::value;
                 chunk_begin(c_c, true);
@@ -723,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void attn256_kernel(const float *__restrict
             chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
         };
         step_v(I0{}, true);
-        step_v(I1{}, hd + 1 < NH);
+        step_v(I1{}, hd + 1 < hd_hi);
         {   // v^T -> sV[pl][d = r][(wave, octet mm)][half h]
 #pragma unroll
             for (int g = 0; g < 16; g++) va[g] += vb[g];

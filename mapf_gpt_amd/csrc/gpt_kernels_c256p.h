@@ -99,8 +99,13 @@ __device__ __forceinline__ void vm_wait()
 // STAMPS (tools/bench_probes/check_mlp256p.hip only): 1 = wave 0 and wave 4 of every workgroup leave s_memtime / s_memrealtime at entry and
 // exit; 2 = cycles spent in wait + barrier instead of the exit wall clock; 3 = cycles per phase of a step: {wait + barrier,
 // DMA issue + slot bookkeeping, chunks 0-2, chunk 3 (up to the next step's top)}.
-template <class T, int NP, int STAMPS = 0>
-__global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv1,
+// NPAIR (round 5): producer / consumer pairs per workgroup = 32-token tiles per block.  4 = the throughput form above (128-token blocks,
+// two waves per SIMD, the producers fill the ring).  2 = small launches (one environment's 8 192 tokens are 64 blocks of 128 -- a
+// quarter of the chip): 64-token blocks, four waves with a SIMD each, and ALL four issue ring pieces (8 per wave and step, as the
+// producers of the 4-pair form) -- with only the two producers issuing, 16 pieces per wave and step would cost more than the block
+// gains.  Same arithmetic per token (the block a token falls in never enters it).
+template <class T, int NP, int STAMPS = 0, int NPAIR = 4>
+__global__ __launch_bounds__(NPAIR * 128, 2) void mlp256p_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv1,
                                                          float inv2, const float2 *__restrict__ gelu_lut, int n_blocks,
                                                          unsigned long long *stamps = nullptr)
 {
@@ -108,7 +113,10 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     constexpr int MS = 16;                                 // fragment pairs per step
     constexpr int STEP = MS * NP * 1024;                   // bytes per stream step
     constexpr int NSLOT = kMPSlots;
-    constexpr int PWP = MS * NP / 4;                       // direct-to-LDS pieces per PRODUCER wave per step; the consumers issue none: measured
+    static_assert(NPAIR == 4 || NPAIR == 2, "four or two pairs");
+    constexpr int NW = 2 * NPAIR;
+    constexpr bool ISSUE_ALL = NPAIR < 4;                  // every wave issues ring pieces (small-launch form)
+    constexpr int PWP = MS * NP / (ISSUE_ALL ? NW : NPAIR);   // direct-to-LDS pieces per ISSUING wave per step.  NPAIR = 4: the producers only; the consumers issue none: measured
                                                            // (STAMPS = 3), the consumer is the longer chain of a step (4 x 416 cycles of MFMA
                                                            // chunks + 290 of piece issue vs 4 x 309 + 79 with 650 cycles of barrier wait)
     constexpr int LUT_BYTES = kGeluLutN * 8;
@@ -117,16 +125,17 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave < 4;                        // wave-uniform
+    const bool producer = wave < NPAIR;                    // wave-uniform
     // (round 4: s_setprio for the consumers -- the longer chain of a step -- makes the kernel 3.6 % SLOWER, 57.6 -> 59.7 ms per cfg3
     //  step at priority 1 or 3; for the producers it changes nothing: oldest-first issue, i.e. the producers ahead, is what works)
-    const int pair = wave & 3;
+    const int pair = wave % NPAIR;
+    const int issuer = ISSUE_ALL ? wave : pair;            // which PWP-piece share of a step this wave moves
     const int r = lane & 31, h = lane >> 5;
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned lds0 = (unsigned)(size_t)smem + lane16;
     const unsigned lut_addr = (unsigned)(size_t)smem + NSLOT * STEP;
     const unsigned hand0 = lut_addr + LUT_BYTES + (unsigned)pair * (2 * 2 * NP * 1024) + lane16;    // this pair's hand-off, this lane
-    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(pair * PWP) * 1024 + lane16;
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wstream) + (size_t)(issuer * PWP) * 1024 + lane16;
     const int n_mine = n_blocks > (int)blockIdx.x ? (n_blocks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     unsigned long long t_in[2] = {0, 0}, t_sync = 0, t_ph[6] = {0, 0, 0, 0, 0, 0}, t_last = 0;
     auto mark = [&](int ph) {                              // STAMPS == 3: cycles since the previous mark go to phase ph
@@ -146,19 +155,20 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     int slot_cur = 0, slot_prev = NSLOT - 1;
     unsigned cur_addr = 0, nxt_addr = 0;
     auto issue = [&](int slot) {
-        if (producer) {                                    // wave-uniform
+        if (producer || ISSUE_ALL) {                       // wave-uniform
             const unsigned char *src = wbase + (size_t)r_issue * STEP;
-            unsigned char *dst = smem + (size_t)slot * STEP + (size_t)(pair * PWP) * 1024;
+            unsigned char *dst = smem + (size_t)slot * STEP + (size_t)(issuer * PWP) * 1024;
 #pragma unroll
             for (int i = 0; i < PWP; i++) dma_piece(src + (i >> 2) * 4096, dst + (i >> 2) * 4096, std::integral_constant<int, 0>{}, i & 3);
         }
         r_issue = r_issue + 1 == kMPPeriod ? 0 : r_issue + 1;
     };
-    {   // Phi table -> LDS (24 pieces of 1 KiB, 3 per wave); older than every ring piece
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(gelu_lut) + (size_t)wave * (LUT_BYTES / 8) + lane16;
+    {   // Phi table -> LDS (24 pieces of 1 KiB, 24 / NW per wave); older than every ring piece
+        static_assert(LUT_BYTES % (NW * 1024) == 0, "whole pieces per wave");
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(gelu_lut) + (size_t)wave * (LUT_BYTES / NW) + lane16;
 #pragma unroll
-        for (int i = 0; i < LUT_BYTES / 8192; i++)
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024), (lds_void_t *)(smem + NSLOT * STEP + wave * (LUT_BYTES / 8) + i * 1024), 16, 0, 0);
+        for (int i = 0; i < LUT_BYTES / (NW * 1024); i++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + i * 1024), (lds_void_t *)(smem + NSLOT * STEP + wave * (LUT_BYTES / NW) + i * 1024), 16, 0, 0);
     }
     issue(0);
     issue(1);
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
             const int64_t blk = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
             // x is chunk-major (xt_off): [32-token tile][C / 8 chunks][32 tokens][8 floats]; lane (r, h) owns the 16 bytes at
             // r * 32 + h * 16 of every 1-KiB chunk, so that a wave's load or store is 1 KiB contiguous
-            const float *xrow = x + (blk * 128 + pair * 32) * C + r * 8 + 4 * h;
+            const float *xrow = x + (blk * (32 * NPAIR) + pair * 32) * C + r * 8 + 4 * h;
             f32x4 xr[32];                                  // raw row pieces: xr[4 j + gq] = features 32 j + 8 gq + 4 h .. + 3 (chunk 4 j + gq)
             // ---- step 0: GELU(tile 31), first k-step; row loads ----
             sync(E0{});
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
         // steps 0 .. 7 of a period for the consumer: the block blk_prev is finished (c_proj of its tiles 30, 31, then the
         // residual add + store, acc = 0)
         auto finish_block = [&](int64_t blk_prev) {
-            float *xrow = x + (blk_prev * 128 + pair * 32) * C + r * 8 + 4 * h;    // chunk-major, as in the producer
+            float *xrow = x + (blk_prev * (32 * NPAIR) + pair * 32) * C + r * 8 + 4 * h;    // chunk-major, as in the producer
             auto ld = [&](auto j_c) {                      // residual pieces of output tile j -> xs[j % 4]
                 constexpr int j = decltype(j_c)::value;
                 f32x4 (&xj)[4] = xs[j % 4];
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
             ld(J0{}); ld(J1{});
             // ---- steps 4 .. 7: residual add + store, two output tiles per step, loads one step ahead ----
             // vector-memory operations of a consumer per step: 8 loads (two tiles) | 8 stores (two tiles)   (no ring pieces)
-            constexpr int PW = 0;
+            constexpr int PW = ISSUE_ALL ? PWP : 0;        // ring pieces this consumer issues at the top of a step
             sync(std::integral_constant<int, 8>{});                                       // step 4 (pending: L0 L1)
             ld(J2{}); ld(J3{});
             st(J0{}, std::integral_constant<int, PW + 8>{}); st(J1{}, std::integral_constant<int, PW + 8 + 4>{});
@@ -529,8 +539,8 @@ __global__ __launch_bounds__(512, 2) void mlp256p_kernel(float *__restrict__ x, 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no direct-to-LDS load may outlive the workgroup
     if constexpr (STAMPS != 0) {
-        if ((wave == 0 || wave == 4) && lane == 0) {
-            unsigned long long *o = stamps + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 4;
+        if ((wave == 0 || wave == NPAIR) && lane == 0) {
+            unsigned long long *o = stamps + ((size_t)blockIdx.x * 2 + (wave >= NPAIR ? 1 : 0)) * 4;
             if constexpr (STAMPS == 3) { o[0] = t_ph[0]; o[1] = t_ph[1]; o[2] = t_ph[2] + t_ph[3] + t_ph[4]; o[3] = t_ph[5]; }
             else { o[0] = t_in[0]; o[1] = t_in[1]; o[2] = __builtin_readcyclecounter(); o[3] = STAMPS == 2 ? t_sync : wall_clock64(); }
         }

@@ -176,13 +176,14 @@ def test_other_shapes_take_the_generic_chain(n_head, n_embd, precision, tol):
     assert np.isfinite(logits).all() and err <= tol, f"C={n_embd} heads={n_head} {precision}: max |dlogit| = {err:.3e}"
 
 
-@pytest.mark.parametrize("name,precision", [("2M", "f16x3"), ("2M", "bf16"), ("tiny", "f16x3")])
+@pytest.mark.parametrize("name,precision", [("2M", "f16x3"), ("2M", "bf16"), ("tiny", "f16x3"), ("6M", "f16x3"), ("6M", "bf16")])
 def test_head_parallel_small_launch_vs_row_per_workgroup_path(name, precision):
     """Round 4: launches of <= 128 rows of the C = 64 / 160 shapes run the attention block head-parallel (one workgroup per
     (row, head), the heads' c_proj contributions folded in head order by the next kernel) -- the way one environment (BASELINE
     cfg1) is served.  The same rows inside a 160-row launch take the row-per-workgroup kernels.  Same products, another
     summation order of the residual stream: the two must agree to fp32 rounding and both must sit within 1e-5 of the fp32 port
-    (the f16x3 mode; bf16: its own class)."""
+    (the f16x3 mode; bf16: its own class).  Round 5: the 6M shape too -- calls of <= 128 rows run attn256_kernel<HP> (one workgroup per
+    (row, head), y planes) + the packed-GEMM out-projection instead of the persistent attn256o_kernel."""
     from mapf_gpt_amd.model import build_model
     rows = np.load(os.path.join(GOLDEN, "gptbig_2M_s1.npz"))["tokens"][:160]
     net = build_model(name, seed=0, max_rows=160, precision=precision)
@@ -228,21 +229,21 @@ def test_spread_scores_take_the_exact_attention_loop():
     Both paths together must stay in the f16x3 class against our exact-fp32-MFMA path (whose attention is a different kernel)."""
     from mapf_gpt_amd.model import build_model
     rng = np.random.Generator(np.random.PCG64(23))
-    tok = torch.from_numpy(np.load(os.path.join(GOLDEN, "gptbig_6M_s1.npz"))["tokens"][:64]).cuda()
+    tok = torch.from_numpy(np.load(os.path.join(GOLDEN, "gptbig_6M_s1.npz"))["tokens"][:160]).cuda()   # (> 128 rows: the persistent kernels)
     _lib.debug_counter(0, reset=True)
-    net = build_model("6M", seed=0, max_rows=64, precision="f16x3")
+    net = build_model("6M", seed=0, max_rows=160, precision="f16x3")
     plain = net.logits_tokens(tok).cpu().numpy()
     assert _lib.debug_counter(0, reset=True) == 0, "synthetic N(0, 0.02) weights must stay on the pipelined loop"
     sd = weights.synthetic_state_dict("6M", seed=0)
     for layer in (1, 2, 4):
         w = sd[f"transformer.h.{layer}.attn.c_attn.weight"]
         w[:512] *= 7.0                                     # q and k rows: scores x 49
-    a = build_model("6M", precision="f32", max_rows=64, state_dict=sd).logits_tokens(tok).cpu().numpy()
+    a = build_model("6M", precision="f32", max_rows=160, state_dict=sd).logits_tokens(tok).cpu().numpy()
     _lib.debug_counter(0, reset=True)
-    b = build_model("6M", precision="f16x3", max_rows=64, state_dict=sd, envelope="ignore").logits_tokens(tok).cpu().numpy()   # (rms 0.115: outside the envelope)
+    b = build_model("6M", precision="f16x3", max_rows=160, state_dict=sd, envelope="ignore").logits_tokens(tok).cpu().numpy()   # (rms 0.115: outside the envelope)
     n_fallback = _lib.debug_counter(0, reset=True)
     err = float(np.abs(a - b).max())
-    print(f"spread scores: {n_fallback} (wave, head) fallbacks of {64 * 8 * 8 * 7}, max |f16x3 - f32| = {err:.3e}, |logits| <= {np.abs(a).max():.2f}")
+    print(f"spread scores: {n_fallback} (wave, head) fallbacks of {160 * 8 * 8 * 7}, max |f16x3 - f32| = {err:.3e}, |logits| <= {np.abs(a).max():.2f}")
     assert n_fallback > 0, "the scaled checkpoint was meant to leave the fp16 range of the P planes somewhere"
     assert np.isfinite(b).all() and err <= 3e-5, f"max |f16x3 - f32| = {err:.3e}"
     assert np.abs(plain - a).max() > 1e-3                  # (the scaling really changed the function)

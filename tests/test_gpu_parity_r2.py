@@ -310,6 +310,7 @@ def test_generatorless_act_advances_between_calls():
     assert np.array_equal(a, net.act(idx).cpu().numpy())
 
 
+@pytest.mark.envelope_fallback_ok
 def test_precision_envelope_is_a_runtime_property():
     """the range on which precision="f16x3" meets the 1e-5 bar is checked at load time, per checkpoint
     (include/mapf_gpt_amd.h: MGPT_ENVELOPE_*): weight statistics at finalize, a probe of 8 fixed rows through both paths at the first
