@@ -690,7 +690,7 @@ def main():
             out["kernel_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
             out["kernel_ms_per_step_last_layer_launches"] = {k: v[0] / a.steps for k, v in prof_last.items()}
         if w.get("clock_power"):
-            out["clock_power"] = dict(w["clock_power"], note="sampled on this GPU between the two barriers of the timed region (DESIGN section 10: the forward runs at the package power limit)")
+            out["clock_power"] = dict(w["clock_power"], note="sampled on this GPU between the two barriers of the timed region by a host thread reading hwmon every 20 ms -- the sampler runs DURING the timing (DESIGN section 10: the forward runs at the package power limit)")
         if world == 1 and not a.no_tokenizer_leg:
             # SURVEY 8d asks for the tokenizer's HBM roofline on >= 1e5-row launches: cfg4's own per-GPU launch (65 536 rows on
             # per-instance maps, 128 agents: the KP = 2 path) is the headline tokenizer figure; the 524 288-row leg is secondary

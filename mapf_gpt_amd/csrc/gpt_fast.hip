@@ -333,7 +333,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             else { MGPT_ATTN_LDS(2, false, false, false); MGPT_ATTN_LDS(2, true, false, false); MGPT_ATTN_LDS(2, false, true, false);
                    MGPT_ATTN_LDS(2, false, false, true); MGPT_ATTN_LDS(2, true, false, true); }
 #undef MGPT_ATTN_LDS
-            if (m->mlp_fused) MGPT_HIP(hipMalloc(&m->head_parts, (size_t)g->nh * kSmallRows * kT * C * sizeof(float)));
+            // (head_parts -- the heads' partial sums of small launches -- is allocated by the first small launch: forward_chunk)
             if (m->mlp_fused && C == 160) {
                 const size_t n16 = (size_t)fastk::kM5Period * 20 * NP * 512;
                 m->mlp160_pk.assign(g->L, nullptr);
@@ -622,8 +622,15 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     const bool attn_block = m->qkv_fused && g->hs == 32 && m->mlp_fused;
     // small launch: the heads of a row run on different CUs (attn_block_kernel<HP>), their partial sums are folded by the next kernel
     // (decided by the CALL's row count, not the chunk's: the remainder chunk of a large call stays on the large-launch kernels)
-    const bool head_par = attn_block && call_rows <= kSmallRows && rows <= kSmallRows && m->head_parts != nullptr;
-    const int64_t part_stride = (int64_t)kSmallRows * kT * C;
+    const bool head_par = attn_block && call_rows <= kSmallRows && rows <= kSmallRows;
+    const int small_cap = std::min(g->max_rows, kSmallRows);                 // rows a small launch of this context can have
+    const int64_t part_stride = (int64_t)small_cap * kT * C;
+    if (head_par && m->head_parts == nullptr) {
+        // first small launch of this context (105 MB for the 2M shape were allocated per precision mode and per adapter whether
+        // or not the context ever served one environment).  New device memory: captured step graphs of this context are stale
+        MGPT_HIP(hipMalloc(&m->head_parts, (size_t)g->nh * (size_t)part_stride * sizeof(float)));
+        g->generation++;
+    }
     // the first attention block forms x = wte[token] + wpe[position] itself (no embedding kernel, no first read of x)
     const bool embed_fused = attn_block && g->L > 1 && !head_par;
     if (m->x_tiled && !embed_fused) {

@@ -524,11 +524,15 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, f32x16 (&acc)
                             for (int e = 0; e < 4; e++) { c[e] += acc[i][j][4 * gq + e] * os; acc[i][j][4 * gq + e] = c[e]; }   // keep the new row for the stats
                             *reinterpret_cast<f32x4 *>(p.x_out + (p.x_tiled ? xt_off(m, n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h, p.N)
                                                                              : m * p.N + n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h)) = c;
-                            rsum[i] += (c[0] + c[1]) + (c[2] + c[3]);
+                            if (p.raw_out == nullptr) rsum[i] += (c[0] + c[1]) + (c[2] + c[3]);
                             if (p.raw_out != nullptr) {                        // the next GEMM's A operand: the raw row in operand planes
-                                rsq[i] += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
                                 const int n = n0 + (wn * TN + j) * 32 + 8 * gq + 4 * h;
                                 const float v[4] = {c[0] - sh, c[1] - sh, c[2] - sh, c[3] - sh};
+                                // (sum, sum of squares) of the SHIFTED row: the shift is the row's mean at the LayerNorm before, so
+                                // E[v^2] - E[v]^2 in ln_finalize_kernel is a variance about a nearly centred value -- on the raw row its
+                                // relative error grew with (mean / std)^2
+                                rsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                                rsq[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                                 u32x2 hi, lo;
                                 split4<T, NP>(v, hi, lo);
                                 *reinterpret_cast<u32x2 *>(p.raw_out + pk_off(m, n, 0, p.N >> 4, NP)) = hi;
@@ -842,11 +846,12 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2 *__restri
     if (m >= M) return;
     float s1 = 0.f, s2 = 0.f;
     for (int q = 0; q < n_parts; q++) { const float2 v = parts[(size_t)q * M + m]; s1 += v.x; s2 += v.y; }
-    const float mean = s1 / (float)C;
-    const float var = fmaxf(s2 / (float)C - mean * mean, 0.f);
+    // the partial sums are those of x - shift (shift = the row's mean at the LayerNorm before): mean and variance about the shift
+    const float dm = s1 / (float)C;                        // mean - shift
+    const float var = fmaxf(s2 / (float)C - dm * dm, 0.f);
     const float sh = mean_buf[m * stride + offset];
-    stats[m] = make_float2(mean - sh, rsqrtf(var + 1e-5f));
-    if (keep) mean_buf[m * stride + offset] = mean;
+    stats[m] = make_float2(dm, rsqrtf(var + 1e-5f));
+    if (keep) mean_buf[m * stride + offset] = sh + dm;
 }
 
 // LayerNorm + split into PK operand planes, statistics computed here: a workgroup owns one 32-token tile, every lane

@@ -349,3 +349,33 @@ def test_precision_envelope_is_a_runtime_property():
     x8 = build_model("6M", seed=0, scale=8.0, precision="f16x3", max_rows=16)
     x8.logits_tokens(tok)
     assert x8.envelope()["state"] == "outside" and x8.envelope()["max_rms_w"] > 0.1
+
+
+@pytest.mark.parametrize("offset", [0.5, 2.0])
+def test_folded_layernorm_with_a_large_per_token_mean(offset, monkeypatch):
+    """the 85M shape's bf16 chain folds LayerNorm into the GEMMs (DESIGN, HISTORY 11.9): the residual epilogues leave (sum, sum of
+    squares) partials and ln_finalize_kernel turns them into (mean, rstd).  Since round 5 the partials are those of the SHIFTED row (x minus
+    its mean at the LayerNorm before), so the one-pass variance is taken about a nearly centred value.  A constant added to wte gives the
+    residual stream a per-token mean of 9 / 36 standard deviations (C = 768, 12 heads, 2 layers: the 85M chain); the folded path must stay in
+    the class of ln_pack_kernel (MGPT_LN_FOLD=0, two-pass LayerNorm) against the fp64 port: measured 0.036 vs 0.026 at 9 and 0.103 vs 0.059 at 36
+    standard deviations (|logits| up to 4.2 / 9.5) -- the difference is the bf16 rounding of x minus a shift that is one residual update old, not
+    the variance formula (0.106 before the partials were shifted)."""
+    from mapf_gpt_amd.model import GPT, GPTConfig
+    from tests.helpers import load_tok
+    rows = load_tok("mazes000")["tokens"][7, :3]
+    args = weights.model_args(dict(n_layer=2, n_head=12, n_embd=768))
+    sd = {k: np.array(v, copy=True) for k, v in weights.synthetic_state_dict(args, seed=11, scale=2.0).items()}
+    sd["transformer.wte.weight"] = sd["transformer.wte.weight"] + np.float32(offset)
+    sd["lm_head.weight"] = sd["transformer.wte.weight"]                      # tied
+    ref = gpt_oracle.forward_logits(sd, args, rows, dtype=torch.float64).numpy()
+    err = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("MGPT_LN_FOLD", fold)
+        net = GPT(GPTConfig(**args), max_rows=4, precision="bf16")
+        net.load_state_dict(sd)
+        err[fold] = float(np.abs(net.logits_tokens(torch.from_numpy(rows).cuda()).cpu().numpy() - ref).max())
+        del net
+    x0 = np.asarray(sd["transformer.wte.weight"][0] + sd["transformer.wpe.weight"][0])
+    record_parity(test="ln_fold_large_mean", offset=offset, mean_over_std=float(abs(x0.mean()) / x0.std()), e_fold=err["1"], e_ln_pack=err["0"],
+                  max_abs_logit=float(np.abs(ref).max()))
+    assert err["1"] <= 2.0 * err["0"] + 5e-3, f"fold {err['1']:.3e} vs ln_pack {err['0']:.3e} at |mean|/std = {abs(x0.mean()) / x0.std():.1f}"
