@@ -1,4 +1,6 @@
 """Host-side logic that needs no GPU: config surface, maps, placement, sampler restatement, sharding."""
+import os
+
 import numpy as np
 import pytest
 
@@ -102,4 +104,19 @@ def test_bench_flop_accounting_matches_survey():
         fused = per_layer["gpt_gemm_qkv"] + per_layer["gpt_attention"] + per_layer["gpt_gemm_attn_proj"] + per_layer["gpt_mlp_fused"]
         assert a["n_layer"] * fused + 2 * a["n_embd"] * 67 == total
         assert per_layer["gpt_gemm_mlp_fc"] + per_layer["gpt_gemm_mlp_proj"] == per_layer["gpt_mlp_fused"]
-    assert set(bench.WORKLOADS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5"} and bench.TOKENIZER_BYTES_PER_ROW == 694
+    assert set(bench.WORKLOADS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "env6M"} and bench.TOKENIZER_BYTES_PER_ROW == 694
+
+
+def test_gpt_envelope_policy_names():
+    """GPT(..., envelope=...) accepts the three policies of include/mapf_gpt_amd.h (MGPT_ENVELOPE_*) and nothing else; the context is
+    only created on first use, so this needs no device."""
+    from mapf_gpt_amd.model import GPT, GPTConfig
+    cfg = GPTConfig(block_size=256)
+    assert GPT.ENVELOPE_POLICIES == {"fallback": 0, "refuse": 1, "ignore": 2}
+    for name in GPT.ENVELOPE_POLICIES:
+        assert GPT(cfg, envelope=name).envelope_policy == name
+    with pytest.raises(ValueError):
+        GPT(cfg, envelope="sometimes")
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mapf_gpt_amd.h")).read()
+    for name, value in (("FALLBACK", 0), ("REFUSE", 1), ("IGNORE", 2)):
+        assert f"#define MGPT_ENVELOPE_{name} {value}" in header
