@@ -318,6 +318,10 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
     const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane < 32 ? 0u : 1u << (lane - 32);
     const uint32_t lt_lo = lane < 32 ? bit_lo - 1u : 0xffffffffu, lt_hi = lane < 32 ? 0u : bit_hi - 1u;
 
+    // the candidates' packed positions (lane + 64 k: the same agents for every row of the instance): read once per wave, not per row and pass
+    uint32_t cpos[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++) cpos[k] = spos[lane + 64 * k];
     // Issue the window gathers of ALL rows this wave owns before touching any of them (bytes in flight).
     // (Round 4: reading each row's record straight from global memory (scalar loads) so that the gathers start BEFORE the workgroup stages the
     //  records into LDS -- one dependent round trip less -- is 7-13 % SLOWER at every launch size: the kernel issues, it does not wait.)
@@ -380,8 +384,13 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
             int x1 = min(max(v1 - midp, 0), 2 * kLimit + 2);
             x0 = (v0 == UNR) ? 2 * kLimit + 3 : x0;                     // cpp:308-309 (-80)
             x1 = (v1 == UNR) ? 2 * kLimit + 3 : x1;
-            tok0_at[u * kRowBytes] = lut[x0];
-            tok1_at[u * kRowBytes] = lut[x1];
+            // token of x: 0 -> -40 (42), 1..41 -> x - 1, 42 -> +40 (43), 43 -> -80 (41).  Arithmetic instead of the LDS table of rounds 1-4: a
+            // table read cannot move in front of the byte stores of the row before (the same LDS array), so every row paid two dependent
+            // LDS round trips here (-3.6 % on the 524 160-row launch, profiles/r05_tokenizer_ablation.txt)
+            const int t0 = x0 == 0 ? TOK_NEG : x0 >= 2 * kLimit + 2 ? 127 - 2 * x0 : x0 - 1;
+            const int t1 = x1 == 0 ? TOK_NEG : x1 >= 2 * kLimit + 2 ? 127 - 2 * x1 : x1 - 1;
+            tok0_at[u * kRowBytes] = (uint8_t)t0;
+            tok1_at[u * kRowBytes] = (uint8_t)t1;
 
             // --- neighbours: the 11x11 scan of cpp:492-495 on the LDS-resident positions ---
             const uint32_t myb = my0 ^ 0x80008000u;
@@ -389,7 +398,7 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
             ncand[u] = 0;
 #pragma unroll
             for (int k = 0; k < KP; k++) {
-                const uint32_t bp = spos[lane + 64 * k];
+                const uint32_t bp = cpos[k];
                 const us2 t = __builtin_bit_cast(us2, bp) - lo;                              // (dr + 5, dc + 5) mod 2^16
                 const us2 mx = __builtin_elementwise_max(t, (us2){2 * kR, 2 * kR});
                 const bool in = __builtin_bit_cast(uint32_t, mx) == (uint32_t)(2 * kR) * 0x00010001u;
