@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/make_hbm_traffic.py fetch_summary.txt write_summary.txt out.json -- HBM bytes per launch of the kernels bench.py's
+"""tools/make_hbm_traffic.py fetch_summary.txt write_summary.txt out.json [fetch_cfg5.txt write_cfg5.txt] -- HBM bytes per launch of the kernels bench.py's
 `roofline.traffic` looks up, from two tools/pmc.sh passes (FETCH_SIZE, WRITE_SIZE; counters in KiB; FETCH_SIZE doubled per the
 gfx950 note of MI355X_MICROARCH.md: 64 B counted per 128-B request)."""
 import json
@@ -31,6 +31,13 @@ KEYS = [  # (json key, kernel substring, grid, note)
     ("tok_generate_observations_524160_rows", "tokens_kernel<4, 16>", 2096640, "2730 instances x 192 agents on the warehouse map"),
 ]
 
+KEYS5 = [  # from the cfg5 passes (bench.py --workload cfg5 --precision bf16, launches of 1024 rows = 262 144 tokens)
+    ("cfg5_bf16_gpt_gemm_mlp_fc", "gemm_pk_kernel<mgpt::fastk::BF16T, 1, 3, 8, 0, true>", 6291456,
+     "c_fc of the 85M bf16 chain (LayerNorm folded): raw operand planes of 262 144 tokens x 768 in, hidden planes x 3072 out, weight tiles from L2"),
+    ("cfg5_bf16_gpt_gemm_mlp_proj", "gemm_pk_kernel<mgpt::fastk::BF16T, 1, 2, 8, 0, false>", 1572864,
+     "residual GEMMs of the 85M bf16 chain (attention out-projection K = 768 and mlp.c_proj K = 3072 share this instantiation: the average mixes both)"),
+]
+
 f, w = table(sys.argv[1]), table(sys.argv[2])
 out = {"source": f"{sys.argv[1]} + {sys.argv[2]}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (counters + kernel trace only) of "
                  "`python bench.py --no-cpu-baseline --no-secondary --steps 4 --warmup 1` (cfg3, f16x3, plus the two tokenizer roofline legs); counters in KiB; "
@@ -46,5 +53,16 @@ for key, sub, grid, note in KEYS:
     out[key] = {"kernel": sub, "grid_threads": grid, "dispatches": f[fk[0]][0], "fetch_raw": fr, "fetch_corrected_x2": 2 * fr, "write": wr, "note": note}
     if key.startswith("cfg3_f16x3_gpt"):
         out[key]["rows_per_launch"] = 12288
+if len(sys.argv) >= 6:
+    f5, w5 = table(sys.argv[4]), table(sys.argv[5])
+    for key, sub, grid, note in KEYS5:
+        fk = [k for k in f5 if sub in k and k.endswith(f"grid={grid}")]
+        wk = [k for k in w5 if sub in k and k.endswith(f"grid={grid}")]
+        if not fk:
+            continue
+        fr = f5[fk[0]][1]
+        wr = w5[wk[0]][1] if wk else 0.0
+        out[key] = {"kernel": sub, "grid_threads": grid, "dispatches": f5[fk[0]][0], "fetch_raw": fr, "fetch_corrected_x2": 2 * fr, "write": wr, "note": note,
+                    "rows_per_launch": 1024}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: (round(v["fetch_corrected_x2"] / 1e6, 1), round(v["write"] / 1e6, 1)) for k, v in out.items() if isinstance(v, dict)}, indent=1))
