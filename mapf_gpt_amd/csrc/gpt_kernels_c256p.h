@@ -35,6 +35,11 @@ namespace fastk {
 constexpr int kMPPause = 4;                     // steps per block in which a role has no MFMAs (see the table above)
 constexpr int kMPPeriod = 64 + kMPPause;        // stream steps per block
 constexpr int kMPSlots = 3;                     // LDS ring depth (steps)
+#ifdef MGPT_ABL_MLPP                            // timing experiments (tools/bench_probes/check_mlp256p.hip; results are wrong): 1 = each chunk reads ONE
+constexpr int kMPAbl = MGPT_ABL_MLPP;           // fragment pair and uses it twice (the LDS traffic of a 64-token wave), 2 = no Phi-table gathers, 4 = every fragment read issued twice (results stay right)
+#else
+constexpr int kMPAbl = 0;
+#endif
 
 template <int NP>
 constexpr int kMPLds = kMPSlots * 16 * NP * 1024 + kGeluLutN * 8 + 4 * 2 * 2 * NP * 1024;   // ring | Phi table | hidden hand-off
@@ -200,11 +205,16 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256p_kernel(float *__restri
     using I3 = std::integral_constant<int, 3>;
 
     u32x4 wb[2][2][2];                                     // weight fragments [set = chunk & 1][pair of the chunk][plane]
+    constexpr int kS1 = (kMPAbl & 1) ? 0 : 1;              // (ablation 1: the second pair of a chunk IS the first)
     auto lds_pair = [&](unsigned slot_addr, auto ms_c, u32x4 (&dst)[2]) {
         constexpr int ms = decltype(ms_c)::value;
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(slot_addr), "n"(ms * NP * 1024) : "memory");
         if (NP == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(slot_addr), "n"((ms * NP + 1) * 1024) : "memory");
         else dst[1] = dst[0];
+        if (kMPAbl & 4) {                                  // every fragment read issued twice (same bytes to the same registers)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst[0]) : "v"(slot_addr), "n"(ms * NP * 1024) : "memory");
+            if (NP == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst[1]) : "v"(slot_addr), "n"((ms * NP + 1) * 1024) : "memory");
+        }
     };
     // chunk c (0 .. 3) of a step works on pairs MB + 2c, MB + 2c + 1 (set c & 1), requested one chunk earlier; it requests the
     // pairs of the next chunk (chunk 3: the first pairs of the next step, whose slot has landed) in front of its MFMAs
@@ -212,8 +222,8 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256p_kernel(float *__restri
         constexpr int MB = decltype(mb_c)::value, c = decltype(c_c)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (c < 3) { lds_pair(cur_addr, std::integral_constant<int, MB + 2 * c + 2>{}, wb[(c + 1) & 1][0]); lds_pair(cur_addr, std::integral_constant<int, MB + 2 * c + 3>{}, wb[(c + 1) & 1][1]); }
-        else if (next_step_has_work) { lds_pair(nxt_addr, std::integral_constant<int, MB>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, MB + 1>{}, wb[0][1]); }
+        if (c < 3) { lds_pair(cur_addr, std::integral_constant<int, MB + 2 * c + 2>{}, wb[(c + 1) & 1][0]); if (!(kMPAbl & 1)) lds_pair(cur_addr, std::integral_constant<int, MB + 2 * c + 3>{}, wb[(c + 1) & 1][1]); }
+        else if (next_step_has_work) { lds_pair(nxt_addr, std::integral_constant<int, MB>{}, wb[0][0]); if (!(kMPAbl & 1)) lds_pair(nxt_addr, std::integral_constant<int, MB + 1>{}, wb[0][1]); }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto pin = [&](auto n_valu_c) {
@@ -256,7 +266,8 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256p_kernel(float *__restri
                 const float t = __builtin_amdgcn_fmed3f(fmaf(hv, lut_scale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.002f);
                 gfr[e] = __builtin_amdgcn_fractf(t);
                 const unsigned idx = (unsigned)t;
-                asm volatile("ds_read_b64 %0, %1" : "=v"(gt[e]) : "v"(la + idx * 8u) : "memory");
+                if (kMPAbl & 2) { gt[e][0] = __builtin_bit_cast(float, idx); gt[e][1] = hv; (void)la; }
+                else asm volatile("ds_read_b64 %0, %1" : "=v"(gt[e]) : "v"(la + idx * 8u) : "memory");
             }
         };
         auto gelu1 = [&](auto q_c, int par) {
@@ -289,22 +300,22 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256p_kernel(float *__restri
             mark(1);
             chunk_begin(MB{}, I0{}, true);
             if (with_gelu) gelu0(std::integral_constant<int, 2 * half>{}, hsrc);
-            fc_mma(wb[0][0], xn[8 * half], wb[0][1], xn[8 * half + 1], hdst);
+            fc_mma(wb[0][0], xn[8 * half], wb[0][kS1], xn[8 * half + 1], hdst);
             pin(VN{});
             mark(2);
             chunk_begin(MB{}, I1{}, true);
             if (with_gelu) gelu1(std::integral_constant<int, 2 * half>{}, par);
-            fc_mma(wb[1][0], xn[8 * half + 2], wb[1][1], xn[8 * half + 3], hdst);
+            fc_mma(wb[1][0], xn[8 * half + 2], wb[1][kS1], xn[8 * half + 3], hdst);
             pin(VN{});
             mark(3);
             chunk_begin(MB{}, I2{}, true);
             if (with_gelu) gelu0(std::integral_constant<int, 2 * half + 1>{}, hsrc);
-            fc_mma(wb[0][0], xn[8 * half + 4], wb[0][1], xn[8 * half + 5], hdst);
+            fc_mma(wb[0][0], xn[8 * half + 4], wb[0][kS1], xn[8 * half + 5], hdst);
             pin(VN{});
             mark(4);
             chunk_begin(MB{}, I3{}, next_step_has_fc);
             if (with_gelu) gelu1(std::integral_constant<int, 2 * half + 1>{}, par);
-            fc_mma(wb[1][0], xn[8 * half + 6], wb[1][1], xn[8 * half + 7], hdst);
+            fc_mma(wb[1][0], xn[8 * half + 6], wb[1][kS1], xn[8 * half + 7], hdst);
             pin(VN{});
         };
         auto tile_fc = [&](f32x16 &hdst, const f32x16 &hsrc, int par, bool with_gelu, bool last_of_block) {
@@ -444,19 +455,19 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256p_kernel(float *__restri
             chunk_begin(MB{}, I0{}, true);
             if (kk == 0) load_hidden(I1{}, par);
             if (kk == 1 && prefetch_next_tile) load_hidden(I0{}, par ^ 1);
-            pj_mma(wb[0][0], wb[0][1], hf[kk], acc[0], acc[1]);
+            pj_mma(wb[0][0], wb[0][kS1], hf[kk], acc[0], acc[1]);
             pin(E0{});
             mark(2);
             chunk_begin(MB{}, I1{}, true);
-            pj_mma(wb[1][0], wb[1][1], hf[kk], acc[2], acc[3]);
+            pj_mma(wb[1][0], wb[1][kS1], hf[kk], acc[2], acc[3]);
             pin(E0{});
             mark(3);
             chunk_begin(MB{}, I2{}, true);
-            pj_mma(wb[0][0], wb[0][1], hf[kk], acc[4], acc[5]);
+            pj_mma(wb[0][0], wb[0][kS1], hf[kk], acc[4], acc[5]);
             pin(E0{});
             mark(4);
             chunk_begin(MB{}, I3{}, next_step_has_pj);
-            pj_mma(wb[1][0], wb[1][1], hf[kk], acc[6], acc[7]);
+            pj_mma(wb[1][0], wb[1][kS1], hf[kk], acc[6], acc[7]);
             pin(E0{});
         };
 

@@ -936,6 +936,11 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
 // end of the main loop, at exit, exit ticks}.
 // NWV = 8: one 256 x 256 block per CU.  NWV = 4: 128 x 256 blocks, two per CU, each with its own ring and barrier, started
 // half a tile apart (cu_arrivals) so that the epilogue of one runs under the main loop of the other.
+#ifdef MGPT_AB_GEMM_CLUMPED
+constexpr bool kGemmPkPlace = false;
+#else
+constexpr bool kGemmPkPlace = true;
+#endif
 constexpr int gemm_pk_kps(int NP) { return 1; }
 constexpr int gemm_pk_nst(int NP, int NWV = 8, int EPI = 0) { return NWV == 8 ? (NP == 2 ? 4 : 6) : (NP == 2 ? 3 : (EPI == EPI_GELU ? 4 : 6)); }
 constexpr int gemm_pk_lds(int NP, int NWV = 8, int EPI = 0) { return gemm_pk_nst(NP, NWV, EPI) * (NWV + 8) * gemm_pk_kps(NP) * NP * 1024; }   // + the Phi table when used
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
 #pragma unroll
             for (int j = 0; j < TN; j++)
                 acc[i][j] = SWAP ? T::mfma(fb[buf][j][pb], fa[buf][i][pa], acc[i][j]) : T::mfma(fa[buf][i][pa], fb[buf][j][pb], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
+        if (!kGemmPkPlace) __builtin_amdgcn_sched_barrier(0);
     };
     auto mfmas = [&](int buf) {
         if (NP == 2) {
@@ -1074,9 +1079,20 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
         for (int kk = 0; kk < KPS; kk++) {
             const int buf = (buf0 + kk) & 1;
             if (kk + 1 < KPS) fetch(S, kk + 1, buf ^ 1);
-            else if (S + 1 < NSTG) fetch(S + 1, 0, buf ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
+            else if (kGemmPkPlace || S + 1 < NSTG) fetch(S + 1, 0, buf ^ 1);   // (placed form: unconditional, so that reads and MFMAs share a basic block; after the last
+                                                                               //  stage the fragments read are stale ring contents that nothing uses)
+            if (!kGemmPkPlace) __builtin_amdgcn_sched_barrier(0);
             mfmas(buf);
+            if (kGemmPkPlace) {
+                // round 5: the (TM + TN) NP fragment reads of the NEXT k-step go out one at a time BEHIND the MFMAs of this one --
+                // clumped in front of them (rounds 1-4) their issue time added to the MFMAs' on both waves of the SIMD
+#pragma unroll
+                for (int n = 0; n < TM * TN * (NP == 2 ? 3 : 1); n++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (n < (TM + TN) * NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
