@@ -941,6 +941,11 @@ constexpr bool kGemmPkPlace = false;
 #else
 constexpr bool kGemmPkPlace = true;
 #endif
+#ifdef MGPT_AB_GEMM_DMA_TOP
+constexpr bool kGemmPkDmaPlace = false;
+#else
+constexpr bool kGemmPkDmaPlace = true;
+#endif
 constexpr int gemm_pk_kps(int NP) { return 1; }
 constexpr int gemm_pk_nst(int NP, int NWV = 8, int EPI = 0) { return NWV == 8 ? (NP == 2 ? 4 : 6) : (NP == 2 ? 3 : (EPI == EPI_GELU ? 4 : 6)); }
 constexpr int gemm_pk_lds(int NP, int NWV = 8, int EPI = 0) { return gemm_pk_nst(NP, NWV, EPI) * (NWV + 8) * gemm_pk_kps(NP) * NP * 1024; }   // + the Phi table when used
@@ -1096,6 +1101,30 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
         }
     };
 
+    // a stage of the main part of the loop (S + NST - 1 < NSTG): the refill of the slot freed by stage S - 1 is unconditional, so that its direct-to-LDS
+    // loads share the basic block of the MFMAs and go out BEHIND the first of them -- issued between the barrier and the first MFMA (rounds 1-4)
+    // they held the matrix pipe idle at the top of every stage, on both waves of the SIMD
+    auto stage_main = [&](int S, int buf) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * PER_WAVE) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(S + 1, 0, buf ^ 1);
+        issue(S + NST - 1);
+        mfmas(buf);
+        // (the refill is a store to LDS as far as hipcc knows: the fragment reads, earlier in program order, stay in front of it -- so the reads go
+        //  behind the first MFMAs and the refill pieces behind the ones that follow)
+        constexpr int NMF = TM * TN * (NP == 2 ? 3 : 1), NRD = (TM + TN) * NP, GAP = (NMF - NRD) / PER_WAVE > 0 ? (NMF - NRD) / PER_WAVE : 1;
+#pragma unroll
+        for (int n = 0; n < NMF; n++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (n < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if ((n - NRD) % GAP == 0 && (n - NRD) / GAP < PER_WAVE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x010, PER_WAVE, 0);      // (pieces that found no MFMA to stand behind: NWV = 4)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER_WAVE) : "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (DBG != 0) ts[2] = __builtin_readcyclecounter();
@@ -1104,8 +1133,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
 #pragma unroll 1
         for (int S = 0; S < NSTG; S++) stage(S, 0);
     } else {
+        int S = 0;
+        if (kGemmPkPlace && kGemmPkDmaPlace) {
 #pragma unroll 1
-        for (int S = 0; S < NSTG; S += 2) {
+            for (; S + NST < NSTG; S += 2) {
+                stage_main(S, 0);
+                stage_main(S + 1, 1);
+            }
+        }
+#pragma unroll 1
+        for (; S < NSTG; S += 2) {
             stage(S, 0);
             stage(S + 1, 1);
         }

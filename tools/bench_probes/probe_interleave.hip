@@ -4,6 +4,7 @@
 //   V<k>: k x v_fma_f32 after every MFMA          T<k>: k x v_exp_f32          C<k>: k x v_cvt_f16_f32
 //   D<k>: k x ds_read_b128 after every MFMA (lgkmcnt(0) once per 4 MFMAs, data unused)
 //   G   : one 1-KiB global_load_lds_dwordx4 per 4 MFMAs (+ 3 VALU and 1 ds_read per MFMA): the mix a fused MLP needs
+//   L<k>: k 1-KiB global_load_lds_dwordx4 per 4 MFMAs and nothing else     R<k>: k 1-KiB global_load_dwordx4 (to registers) per 4 MFMAs
 // 4 independent accumulators; 1 or 2 waves per SIMD; 256 blocks (one per CU).  Output: cycles (s_memtime) per MFMA.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -43,10 +44,19 @@ __global__ __launch_bounds__(NT, NT / 256) void k(float *out, long long *cyc, co
     for (int g = 0; g < 16; g++) { a0[g] = 0.f; a1[g] = 0.f; a2[g] = 0.f; a3[g] = 0.f; }
     float v0 = threadIdx.x, v1 = v0 + 1.f, v2 = v0 + 2.f, v3 = v0 + 3.f;
     const float ca = 1.0001f, cb = 0.5f;
-    f32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+    f32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
     const unsigned laddr = (unsigned)(lane * 16 + wave * 8192);
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
+        if (MODE == 7 || MODE == 8) {
+            const unsigned char *gp = src + ((size_t)((blockIdx.x * 8 + wave) % 256) * 64 + (it & 63)) * 1024 + lane * 16;
+#pragma unroll
+            for (int q = 0; q < K; q++) {
+                if (MODE == 7) __builtin_amdgcn_global_load_lds((gbl_void_t *)(gp + q * 65536), (lds_void_t *)(smem + 32768 + wave * 1024 + ((it + q) & 1) * 8192), 16, 0, 0);
+                else if (q == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(g0) : "v"(gp) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "+v"(g1) : "v"(gp) : "memory");
+            }
+        }
         if (MODE == 4) {
             __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + ((size_t)((blockIdx.x * 8 + wave) % 256) * 64 + (it & 63)) * 1024 + lane * 16),
                                              (lds_void_t *)(smem + 32768 + wave * 1024 + (it & 1) * 8192), 16, 0, 0);
@@ -96,6 +106,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k(float *out, long long *cyc, co
             else if (K == 2) BODY(DS2);
             else if (K == 3) BODY(DS2 VF VF1);         // 2 ds_read + 3 VALU
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (MODE == 7 || MODE == 8) {
+            BODY("");
+            if ((it & 1) == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");      // the loads of the last iteration may stay in flight
         } else if (MODE == 4) {
             BODY(DS VF VF1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -104,7 +117,8 @@ __global__ __launch_bounds__(NT, NT / 256) void k(float *out, long long *cyc, co
     }
     const long long t1 = __builtin_readcyclecounter();
     asm volatile("s_nop 15\n s_nop 15" ::: "memory");             // MFMA results settle before compiler code reads them
-    float s = v0 + v1 + v2 + v3 + d0[0] + d1[0];
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0), "+v"(g1)::"memory");
+    float s = v0 + v1 + v2 + v3 + d0[0] + d1[0] + g0[0] + g1[0];
     for (int g = 0; g < 16; g++) s += a0[g] + a1[g] + a2[g] + a3[g];
     out[blockIdx.x * NT + threadIdx.x] = s;
     if (lane == 0) cyc[blockIdx.x * (NT / 64) + wave] = t1 - t0;
@@ -130,11 +144,14 @@ void run(const char *tag, float *d, long long *dc, const unsigned char *src)
 }
 
 #define BOTH(M, K_, tag) run<M, K_, 256>(tag, d, dc, src); run<M, K_, 512>(tag, d, dc, src);
-int main()
+int main(int argc, char **argv)
 {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const bool only_new = argc > 1;
     float *d; hipMalloc(&d, 256 * 512 * 4);
     long long *dc; hipMalloc(&dc, 256 * 8 * 8);
-    unsigned char *src; hipMalloc(&src, 256 * 64 * 1024); hipMemset(src, 1, 256 * 64 * 1024);
+    unsigned char *src; hipMalloc(&src, 256 * 64 * 1024 + (1 << 20)); hipMemset(src, 1, 256 * 64 * 1024 + (1 << 20));
+    if (!only_new) {
     BOTH(5, 0, "1 chain: MFMA only");
     BOTH(5, 4, "1 chain: MFMA + 4 v_fma");
     BOTH(5, 6, "1 chain: MFMA + 6 v_fma");
@@ -161,5 +178,11 @@ int main()
     BOTH(3, 2, "MFMA + 2 ds_read_b128");
     BOTH(3, 3, "MFMA + 2 ds_read_b128 + 3 v_fma");
     BOTH(4, 0, "MFMA + 1 ds_read + 3 v_fma + DMA/4");
+    }
+    BOTH(0, 0, "MFMA only");
+    BOTH(7, 1, "MFMA + 1 DMA per 4 MFMAs");
+    BOTH(7, 2, "MFMA + 2 DMA per 4 MFMAs");
+    BOTH(8, 1, "MFMA + 1 global_load_dwordx4 per 4");
+    BOTH(8, 2, "MFMA + 2 global_load_dwordx4 per 4");
     return 0;
 }
