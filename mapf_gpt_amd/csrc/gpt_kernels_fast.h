@@ -1118,6 +1118,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
 #pragma unroll
         for (int n = 0; n < NMF; n++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#ifndef MGPT_AB_GEMM_SALU_FRONT
+            // slot / address arithmetic behind the first MFMA instead of between the barrier and it (one-plane mode: 731 -> 690 cycles per k-step; in the
+            // split mode the group size does not fit the second stage of the unrolled pair and the placement falls apart -- left to hipcc there)
+            if (n == 0 && NP == 1) __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
+#endif
             if (n < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             else if ((n - NRD) % GAP == 0 && (n - NRD) / GAP < PER_WAVE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
