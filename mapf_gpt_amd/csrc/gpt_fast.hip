@@ -558,6 +558,18 @@ int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
     return MGPT_OK;
 }
 
+// compute units of the current device (grid of the persistent packed GEMM); asked once
+int gemm_pk_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
 template <class T, int NP, int EPI>
 int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s, bool half_tiles = false)
 {
@@ -567,16 +579,21 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s, bool half_tiles = false)
     a.n_tiles_n = a.N / 256;
     if (EPI == fastk::EPI_RESID) a.stats_out = nullptr;               // rows span two waves: stats come from row_stats_kernel
     const bool lut = EPI == fastk::EPI_GELU && a.gelu_lut != nullptr;
-    if (EPI != fastk::EPI_RESID && a.ln_stats != nullptr) {          // folded LayerNorm (GemmArgs): the Phi table slot is always reserved
+    const int n_cu = gemm_pk_cus();
+    const bool lnf = EPI != fastk::EPI_RESID && a.ln_stats != nullptr;
+    const bool persist = fastk::gemm_pk_persistent(NP, EPI, lnf);    // one workgroup per CU walking the tiles (gpt_kernels_fast.h: gemm_pk_kernel)
+    const unsigned grid8 = (unsigned)(persist ? std::min((a.M / 256) * a.n_tiles_n, n_cu) : (a.M / 256) * a.n_tiles_n);
+    const unsigned grid4 = (unsigned)(persist ? std::min((a.M / 128) * a.n_tiles_n, 2 * n_cu) : (a.M / 128) * a.n_tiles_n);
+    if (lnf) {                                                       // folded LayerNorm (GemmArgs): the Phi table slot is always reserved
         MGPT_REQUIRE(EPI != fastk::EPI_GELU || lut, MGPT_ERR_STATE, "%s", "folded LayerNorm: the GELU epilogue needs the Phi table");
-        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8, 0, true>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
+        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8, 0, true>), dim3(grid8), dim3(512),
                            (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0) + 3072, s, a, (unsigned long long *)nullptr);
     } else if (EPI == fastk::EPI_RESID && half_tiles) {
         // small launches (one environment's out-projection: 32 tiles of 256 rows would leave 7 of 8 CUs idle): 128-row tiles, 4 waves
-        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 4>), dim3((unsigned)((a.M / 128) * a.n_tiles_n)), dim3(256),
+        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 4>), dim3(grid4), dim3(256),
                            (size_t)fastk::gemm_pk_lds(NP, 4, EPI), s, a, (unsigned long long *)nullptr);
     } else {
-        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3((unsigned)((a.M / 256) * a.n_tiles_n)), dim3(512),
+        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3(grid8), dim3(512),
                            (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0), s, a, (unsigned long long *)nullptr);
     }
     MGPT_LAUNCH_CHECK();

@@ -292,9 +292,7 @@ struct GemmArgs {
     int o_pk;                                                        // EPI_GELU: write the hidden planes in PK layout (o_hi = base)
     int chunk_major;                                                 // EPI_QK / EPI_VT: chunk-major q|k and v^T planes (below)
     const float2 *gelu_lut;                                          // EPI_GELU in gemm_pk_kernel: the Phi table (kGeluLutN pairs) or NULL
-    int stagger;                                                     // gemm_pk_kernel: start-up spread of the CUs, x 64 cycles (see there)
     int x_tiled;                                                     // EPI_RESID: x_out is chunk-major (xt_off) instead of row-major
-    unsigned *cu_arrivals;                                           // gemm_pk_kernel<.., NWV = 4>: per-CU arrival counters (see there) or NULL
     // LayerNorm folded into the GEMM chain (one-plane mode, C > 256; gpt_fast.hip `ln_fold`): the A operand is the RAW residual row
     // in operand planes and W carries ln.weight, so acc[m][n] = sum_k x[m][k] W'[n][k]; the consumer's epilogue forms
     // rstd[m] * (acc - mean[m] * colsum[n]) = sum_k LayerNorm(x)[m][k] W[n][k].  No kernel reads x to normalise it.
@@ -932,10 +930,9 @@ __global__ __launch_bounds__(256) void ln_pack_kernel(const float *__restrict__ 
 // global->LDS loads NST - 1 stages ahead), one s_barrier per stage.  KPS = 2 in the one-plane (bf16) mode (16 MFMAs per
 // wave between barriers) was measured and changes nothing (860 vs 888 cycles per k-step, tools/bench_probes/probe_gemm_pk.hip);
 // the library runs KPS = 1.
-// DBG (probe only): 1 = wave 0 leaves stamps[block][6] = {entry cycles, entry 100-MHz ticks, cycles at the first stage, at the
-// end of the main loop, at exit, exit ticks}.
-// NWV = 8: one 256 x 256 block per CU.  NWV = 4: 128 x 256 blocks, two per CU, each with its own ring and barrier, started
-// half a tile apart (cu_arrivals) so that the epilogue of one runs under the main loop of the other.
+// DBG (probe only): 1 = wave 0 leaves stamps[workgroup][8] = {cycles waiting at the tops of its tiles, in their k loops, in their epilogues, tiles, total cycles, total 100-MHz ticks}.
+// NWV = 8: one 256 x 256 block per CU.  NWV = 4: 128 x 256 blocks, two per CU, each with its own ring and barrier (small launches: more
+// tiles than the 256-row form; at full size it is no faster, profiles/r03_probe_gemm_pk.txt).
 #ifdef MGPT_AB_GEMM_CLUMPED
 constexpr bool kGemmPkPlace = false;
 #else
@@ -947,16 +944,25 @@ constexpr bool kGemmPkDmaPlace = false;
 constexpr bool kGemmPkDmaPlace = true;
 #endif
 constexpr int gemm_pk_kps(int NP) { return 1; }
+// instances compiled WITH the tile loop (see gemm_pk_kernel): the one-plane GELU epilogue, where it measured faster; the split-mode and the
+// natural-orientation (v^T) instances would spill with the loop's state carried through their epilogues, and the residual epilogue at K = 3072
+// got 4 % SLOWER merely by being compiled with the loop (launched one workgroup per tile in both builds: profiles/r05_ab.txt, visit H)
+constexpr bool gemm_pk_persistent(int NP, int EPI, bool LNF) { return NP == 1 && EPI == EPI_GELU; }
 constexpr int gemm_pk_nst(int NP, int NWV = 8, int EPI = 0) { return NWV == 8 ? (NP == 2 ? 4 : 6) : (NP == 2 ? 3 : (EPI == EPI_GELU ? 4 : 6)); }
 constexpr int gemm_pk_lds(int NP, int NWV = 8, int EPI = 0) { return gemm_pk_nst(NP, NWV, EPI) * (NWV + 8) * gemm_pk_kps(NP) * NP * 1024; }   // + the Phi table when used
 
 // LNF (folded LayerNorm, GemmArgs): the block's 256 column sums and the (mean, rstd) of its 256 rows are three more 1-KiB pieces in LDS,
 // behind the ring and the Phi table.
+// PERSISTENT form (round 5, gemm_pk_persistent instances): a grid SMALLER than the number of tiles makes workgroup v walk tiles v, v + gridDim.x,
+// ...; the first NST - 1 stages of the NEXT tile are requested before the epilogue of this one (the ring is idle by then) and land under it.
+// A/B in one box on the 85M chain (profiles/r05_ab.txt, visits G and H): c_fc (GELU epilogue) -3 to -4 %; attention out-projection -2.6 %, q|k
+// unchanged, c_proj (K = 3072) +4 % -- only the GELU instance keeps the loop.
 template <class T, int NP, int EPI, int NWV, int DBG = 0, bool LNF = false>
 __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsigned long long *stamps = nullptr)
 {
     static_assert(NWV == 8 || NWV == 4, "8 or 4 waves of 64 x 128");
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};         // DBG: {entry cycles, entry ticks, cycles waiting for stage 0, main loops, epilogues, tiles}
+    unsigned long long t_mark = 0;
     if constexpr (DBG != 0) { ts[0] = __builtin_readcyclecounter(); ts[1] = wall_clock64(); }
     constexpr int TM = 2, TN = 4;                          // MFMA tiles per wave; waves are (NWV / 2) x 2
     constexpr int AF = NWV;                                // A fragments per k-step = block rows / 32
@@ -971,21 +977,25 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    // Block -> tile map, XCD-aware: hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own
-    // 4 MiB L2), so logical ids are made contiguous per XCD, and inside an XCD the ~32 concurrently running blocks form
-    // bands of 4 token tiles x all column tiles (token tile fastest): every A tile is fetched once into that L2 and hit
-    // by the other column tiles, every weight tile by the 4 token tiles.
-    const int nb = gridDim.x, ntn = p.n_tiles_n, mtn = nb / ntn;
-    int id = blockIdx.x;
-    if ((nb & 7) == 0) id = (id & 7) * (nb >> 3) + (id >> 3);
-    constexpr int GM = 32 / AF;                            // 1024 token rows per band
-    const int band = id / (GM * ntn);
-    const int gm = min(GM, mtn - band * GM);
-    const int rem = id - band * GM * ntn;
-    const int nt = rem / gm, mt = band * GM + (rem - nt * gm);
+    // Tile map, XCD-aware: hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own 4 MiB L2) and tile
+    // v + k * gridDim.x stays on workgroup v's XCD (the grid is a multiple of 8), so logical ids are made contiguous per XCD, and inside an
+    // XCD the ~32 tiles in flight form bands of 4 token tiles x all column tiles (token tile fastest): every A tile is fetched once
+    // into that L2 and hit by the other column tiles, every weight tile by the 4 token tiles.
+    const int ntn = p.n_tiles_n, mtn = p.M / (AF * 32), nb = mtn * ntn;
     const int KS = p.K >> 4, NSTG = KS / KPS;
-    const unsigned char *abase = reinterpret_cast<const unsigned char *>(p.a_hi) + (size_t)mt * AF * KS * NP * 1024 + lane * 16;
-    const unsigned char *bbase = reinterpret_cast<const unsigned char *>(p.w_hi) + (size_t)nt * 8 * KS * NP * 1024 + lane * 16;
+    int mt = 0, nt = 0;
+    const unsigned char *abase = nullptr, *bbase = nullptr;
+    auto set_tile = [&](int v) {
+        int id = v;
+        if ((nb & 7) == 0 && (gridDim.x & 7) == 0) id = (id & 7) * (nb >> 3) + (id >> 3);
+        constexpr int GM = 32 / AF;                        // 1024 token rows per band
+        const int band = id / (GM * ntn);
+        const int gm = min(GM, mtn - band * GM);
+        const int rem = id - band * GM * ntn;
+        nt = rem / gm; mt = band * GM + (rem - nt * gm);
+        abase = reinterpret_cast<const unsigned char *>(p.a_hi) + (size_t)mt * AF * KS * NP * 1024 + lane * 16;
+        bbase = reinterpret_cast<const unsigned char *>(p.w_hi) + (size_t)nt * 8 * KS * NP * 1024 + lane * 16;
+    };
 
     // stage S -> LDS [fragment f][k-step kk of the stage][plane]: the KPS * NP pieces of a fragment are contiguous on both sides
     auto issue = [&](int S) {
@@ -1010,39 +1020,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
         lut_addr = (unsigned)(size_t)dst;
     }
     unsigned cs_addr = 0u;
-    if constexpr (LNF) {                                   // (older than every ring piece too; wave 0 only: a wave's counted waits stay exact)
-        unsigned char *dst = smem + (size_t)NST * STAGE + (EPI == EPI_GELU ? kGeluLutN * 8 : 0);
-        if (wave == 0)
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.colsum + nt * 256) + lane * 16), (lds_void_t *)dst, 16, 0, 0);
-        if (wave == 1 || wave == 2)                        // (mean, rstd) of the block's 256 rows: 2 KiB
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.ln_stats + (size_t)mt * (AF * 32)) + (wave - 1) * 1024 + lane * 16),
-                                             (lds_void_t *)(dst + wave * 1024), 16, 0, 0);
-        cs_addr = (unsigned)(size_t)dst;
-    }
+    if constexpr (LNF) cs_addr = (unsigned)(size_t)(smem + (size_t)NST * STAGE + (EPI == EPI_GELU ? kGeluLutN * 8 : 0));
+    int vt = blockIdx.x;                                   // the launcher keeps gridDim.x <= number of tiles
+    set_tile(vt);
 #pragma unroll
     for (int S = 0; S < NST - 1; S++) issue(S);            // K >= 16 * KPS * NST is checked by the launcher
-    if (NWV == 4 && p.stagger > 0 && p.cu_arrivals != nullptr && blockIdx.x < 512 && wave == 0) {
-        // The two blocks of a CU start together and, with equal work, stay in phase: both in the main loop, then both in
-        // the epilogue.  Of the first two blocks that arrive on a CU (a counter per CU, identified by its hardware id), the
-        // second starts p.stagger x 64 cycles late -- half a tile; the blocks that follow on the CU inherit the phase.
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned old = 0;
-        if (lane == 0) old = atomicAdd(p.cu_arrivals + (((xcc & 15u) << 8) | ((hw >> 8) & 255u)), 1u);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old & 1u)
-            for (int i = 0; i < p.stagger; i++) __builtin_amdgcn_s_sleep(1);
-    }
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
-
     u32x4 fa[2][TM][NP], fb[2][TN][NP];                    // [buffer][tile][plane]
     auto fetch = [&](int S, int kk, int buf) {             // fragments of k-step kk of stage S
         const unsigned char *st = smem + (size_t)(S % NST) * STAGE + (size_t)kk * NP * 1024 + lane * 16;
@@ -1100,10 +1084,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
             }
         }
     };
-
     // a stage of the main part of the loop (S + NST - 1 < NSTG): the refill of the slot freed by stage S - 1 is unconditional, so that its direct-to-LDS
     // loads share the basic block of the MFMAs and go out BEHIND the first of them -- issued between the barrier and the first MFMA (rounds 1-4)
     // they held the matrix pipe idle at the top of every stage, on both waves of the SIMD
+    constexpr bool PERSIST = gemm_pk_persistent(NP, EPI, LNF);
     auto stage_main = [&](int S, int buf) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * PER_WAVE) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1130,36 +1114,80 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER_WAVE) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if constexpr (DBG != 0) ts[2] = __builtin_readcyclecounter();
-    fetch(0, 0, 0);
-    if (KPS == 2) {
 #pragma unroll 1
-        for (int S = 0; S < NSTG; S++) stage(S, 0);
-    } else {
-        int S = 0;
-        if (kGemmPkPlace && kGemmPkDmaPlace) {
+    for (;;) {
+        if constexpr (DBG != 0) t_mark = __builtin_readcyclecounter();
+        // ---- top of a tile: its stage 0 has landed for everyone (requested by the prologue above, or before the previous tile's epilogue: then the
+        //      (NST - 2) PER_WAVE operations a wave may leave in flight are that epilogue's last stores and every piece is older.  Counting on more of
+        //      the epilogue's operations -- measured with 24 -- changes nothing: what the top of a tile waits for is the barrier, i.e. the slower wave
+        //      of each SIMD finishing its epilogue, 4 k cycles behind the faster one) ----
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER_WAVE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (LNF) {                               // this tile's column sums and row statistics (read by its epilogue; the barrier above
+            unsigned char *dst = smem + (size_t)NST * STAGE + (EPI == EPI_GELU ? kGeluLutN * 8 : 0);   // is behind the previous epilogue's reads)
+            if (wave == 0)
+                __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.colsum + nt * 256) + lane * 16), (lds_void_t *)dst, 16, 0, 0);
+            if (wave == 1 || wave == 2)                    // (mean, rstd) of the block's 256 rows: 2 KiB
+                __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.ln_stats + (size_t)mt * (AF * 32)) + (wave - 1) * 1024 + lane * 16),
+                                                 (lds_void_t *)(dst + wave * 1024), 16, 0, 0);
+            // (extra operations YOUNGER than a piece only make a counted wait for that piece stricter; the tail of the k loop waits for everything)
+        }
+        if constexpr (DBG != 0) { const unsigned long long t = __builtin_readcyclecounter(); ts[2] += t - t_mark; t_mark = t; }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
+        fetch(0, 0, 0);
+        if (KPS == 2) {
 #pragma unroll 1
-            for (; S + NST < NSTG; S += 2) {
-                stage_main(S, 0);
-                stage_main(S + 1, 1);
+            for (int S = 0; S < NSTG; S++) stage(S, 0);
+        } else {
+            int S = 0;
+            if (kGemmPkPlace && kGemmPkDmaPlace) {
+#pragma unroll 1
+                for (; S + NST < NSTG; S += 2) {
+                    stage_main(S, 0);
+                    stage_main(S + 1, 1);
+                }
+            }
+#pragma unroll 1
+            for (; S < NSTG; S += 2) {
+                stage(S, 0);
+                stage(S + 1, 1);
             }
         }
-#pragma unroll 1
-        for (; S < NSTG; S += 2) {
-            stage(S, 0);
-            stage(S + 1, 1);
+        if constexpr (DBG != 0) { asm volatile("s_nop 0" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); ts[3] += t - t_mark; t_mark = t; }
+        // ---- the next tile's first stages go out before this tile's epilogue: every wave has read its last fragments (barrier), nothing of the
+        //      ring is in flight (the loop's tail waited for everything) ----
+        const int64_t m0e = (int64_t)mt * (AF * 32);
+        const int n0e = nt * 256;
+        const int vnext = vt + (int)gridDim.x;
+        const bool more = PERSIST && vnext < nb;           // uniform
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            set_tile(vnext);
+#pragma unroll
+            for (int S = 0; S < NST - 1; S++) issue(S);
         }
+        gemm16_epilogue<T, NP, EPI, TM, TN, 2, LNF>(p, acc, m0e, n0e, wm, wn, r, h, lut_addr, cs_addr);
+        if constexpr (DBG != 0) { const unsigned long long t = __builtin_readcyclecounter(); ts[4] += t - t_mark; ts[5] += 1; }
+        if (!PERSIST || !more) break;
+        // (the tile's coordinates and operand addresses are formed again from an opaque copy of the index: carried through the epilogue they
+        //  cost it registers it does not have in the natural-orientation and split instances -- and scratch traffic counts in vmcnt)
+        vt = vnext;
+        asm volatile("" : "+s"(vt));
+        set_tile(vt);
     }
-    if constexpr (DBG != 0) { asm volatile("s_nop 0" ::: "memory"); ts[3] = __builtin_readcyclecounter(); }
-    gemm16_epilogue<T, NP, EPI, TM, TN, 2, LNF>(p, acc, (int64_t)mt * (AF * 32), nt * 256, wm, wn, r, h, lut_addr, cs_addr);
     if constexpr (DBG != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ts[4] = __builtin_readcyclecounter(); ts[5] = wall_clock64();
-        if (tid == 0)
-#pragma unroll
-            for (int i = 0; i < 6; i++) stamps[(size_t)blockIdx.x * 6 + i] = ts[i];
+        if (tid == 0) {
+            unsigned long long *o = stamps + (size_t)blockIdx.x * 8;
+            o[0] = ts[2]; o[1] = ts[3]; o[2] = ts[4]; o[3] = ts[5];
+            o[4] = __builtin_readcyclecounter() - ts[0]; o[5] = wall_clock64() - ts[1];
+        }
     }
 }
 

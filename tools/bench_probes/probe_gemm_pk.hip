@@ -14,14 +14,14 @@ void run(const char *tag, uint16_t *a, uint16_t *w, uint16_t *o, float *x, const
 {
     GemmArgs p{};
     p.a_hi = a; p.w_hi = w; p.out_scale = 1.0f; p.M = M; p.N = N; p.K = K; p.n_tiles_n = N / 256; p.x_out = x; p.o_hi = o; p.o_pk = 1; p.gelu_lut = lut;
-    p.C = 768; p.n_head = 12; p.hs = 64; p.stagger = stagger < 0 ? 0 : stagger; p.x_tiled = stagger < 0;
+    p.C = 768; p.n_head = 12; p.hs = 64; p.x_tiled = stagger < 0;
     const size_t lds = (size_t)gemm_pk_lds(NP, NWV, EPI) + (EPI == EPI_GELU ? kGeluLutN * 8 : 0);
-    static unsigned *arr = nullptr; if (!arr) { hipMalloc(&arr, 4096 * 4); hipMemset(arr, 0, 4096 * 4); }
-    p.cu_arrivals = arr;
     auto kern = &gemm_pk_kernel<T, NP, EPI, NWV>;
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const dim3 grid((unsigned)((M / (NWV * 32)) * (N / 256)));
+    const unsigned n_tiles = (unsigned)((M / (NWV * 32)) * (N / 256));
+    int dev = 0, ncu = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const dim3 grid(gemm_pk_persistent(NP, EPI, false) ? std::min(n_tiles, (unsigned)(ncu * (NWV == 8 ? 1 : 2))) : n_tiles);      // persistent workgroups
     for (int i = 0; i < 2; i++) kern<<<grid, NWV * 64, lds>>>(p, nullptr);
     float best = 1e9f;
     for (int rep = 0; rep < 3; rep++) {
@@ -34,22 +34,23 @@ void run(const char *tag, uint16_t *a, uint16_t *w, uint16_t *o, float *x, const
     {   // stamps
         auto dk = &gemm_pk_kernel<T, NP, EPI, NWV, 1>;
         hipFuncSetAttribute(reinterpret_cast<const void *>(dk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        unsigned long long *st; hipMalloc(&st, (size_t)grid.x * 48);
+        unsigned long long *st; hipMalloc(&st, (size_t)grid.x * 64);
         for (int i = 0; i < 3; i++) dk<<<grid, NWV * 64, lds>>>(p, st);
         hipDeviceSynchronize();
-        std::vector<unsigned long long> h((size_t)grid.x * 6);
+        std::vector<unsigned long long> h((size_t)grid.x * 8);
         hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
-        double fill = 0, loop = 0, epi = 0, tot = 0, rt = 0;
+        double fill = 0, loop = 0, epi = 0, tot = 0, rt = 0, tiles = 0;
         for (unsigned b = 0; b < grid.x; b++) {
-            const unsigned long long *q = &h[(size_t)b * 6];
-            fill += (double)(q[2] - q[0]); loop += (double)(q[3] - q[2]); epi += (double)(q[4] - q[3]); tot += (double)(q[4] - q[0]); rt += (double)(q[5] - q[1]);
+            const unsigned long long *q = &h[(size_t)b * 8];
+            fill += (double)q[0]; loop += (double)q[1]; epi += (double)q[2]; tiles += (double)q[3]; tot += (double)q[4]; rt += (double)q[5];
         }
-        printf("    stamps (wave 0, mean over %u blocks): ring fill %.0f | main loop %.0f (%.0f per k-step) | epilogue %.0f | total %.0f cycles, shader clock %.3f GHz\n",
-               grid.x, fill / grid.x, loop / grid.x, loop / grid.x / (K / 16), epi / grid.x, tot / grid.x, tot / rt / 10.0);
+        printf("    stamps (wave 0, per tile, mean over %.0f tiles of %u workgroups): wait for stage 0 %.0f | main loop %.0f (%.0f per k-step) | epilogue %.0f | "
+               "total %.0f cycles, shader clock %.3f GHz\n",
+               tiles, grid.x, fill / tiles, loop / tiles, loop / tiles / (K / 16), epi / tiles, tot / tiles, tot / rt / 10.0);
         hipFree(st);
     }
     const double flops = 2.0 * M * (double)N * K;
-    const double tiles_per_cu = (double)grid.x / 256.0;
+    const double tiles_per_cu = (double)n_tiles / 256.0;
     printf("%-18s M=%d N=%4d K=%4d  %8.3f ms  %7.1f TFLOP/s (%4.2f of 2500; x%d MFMA passes)  %7.2f us per tile  [%s]\n", tag, M, N, K, best,
            flops / (best * 1e-3) / 1e12, flops / (best * 1e-3) / 2.5e15, NP == 2 ? 3 : 1, best * 1e3 / tiles_per_cu, hipGetErrorString(hipGetLastError()));
 }
@@ -78,10 +79,10 @@ int main()
     }
     for (int K : {768, 1536, 3072}) run<BF16T, 1, EPI_GELU>("bf16 gelu->pk", a, w, o, x, lut, M, 3072, K);
     for (int K : {768, 1536, 3072}) run<BF16T, 1, EPI_RESID>("bf16 resid", a, w, o, x, lut, M, 768, K);
-    printf("two 128 x 256 blocks per CU, second arrival on a CU delayed by n x 64 cycles:\n");
-    for (int sg : {0, 200, 400, 600}) { printf("n = %d\n", sg); run<BF16T, 1, EPI_GELU, 4>("bf16 gelu->pk 2/CU", a, w, o, x, lut, M, 3072, 768, sg); }
-    for (int sg : {0, 300, 600}) { printf("n = %d\n", sg); run<BF16T, 1, EPI_RESID, 4>("bf16 resid 2/CU", a, w, o, x, lut, M, 768, 768, sg); }
-    for (int sg : {0, 800, 1600}) { printf("n = %d\n", sg); run<BF16T, 1, EPI_RESID, 4>("bf16 resid 2/CU", a, w, o, x, lut, M, 768, 3072, sg); }
+    printf("two 128 x 256 blocks per CU:\n");
+    run<BF16T, 1, EPI_GELU, 4>("bf16 gelu->pk 2/CU", a, w, o, x, lut, M, 3072, 768);
+    run<BF16T, 1, EPI_RESID, 4>("bf16 resid 2/CU", a, w, o, x, lut, M, 768, 768);
+    run<BF16T, 1, EPI_RESID, 4>("bf16 resid 2/CU", a, w, o, x, lut, M, 768, 3072);
     printf("chunk-major residual stream (x as [M/32][N/8][32][8]):\n");
     for (int K : {768, 3072}) run<BF16T, 1, EPI_RESID>("bf16 resid tiled", a, w, o, x, lut, M, 768, K, -1);
     run<F16T, 2, EPI_RESID, 8>("f16x3 resid tiled", a, w, o, x, lut, M, 256, 256, -1);
