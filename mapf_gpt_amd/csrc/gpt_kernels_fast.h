@@ -946,7 +946,8 @@ constexpr bool kGemmPkDmaPlace = true;
 constexpr int gemm_pk_kps(int NP) { return 1; }
 // instances compiled WITH the tile loop (see gemm_pk_kernel): the one-plane GELU epilogue, where it measured faster; the split-mode and the
 // natural-orientation (v^T) instances would spill with the loop's state carried through their epilogues, and the residual epilogue at K = 3072
-// got 4 % SLOWER merely by being compiled with the loop (launched one workgroup per tile in both builds: profiles/r05_ab.txt, visit H)
+// got 4.5 % SLOWER compiled with the loop and launched one workgroup per tile (profiles/r05_ab.txt, visit H; 1.3-1.6 % of that is the faster
+// c_fc in front of it taking from the shared power budget, visit I)
 constexpr bool gemm_pk_persistent(int NP, int EPI, bool LNF) { return NP == 1 && EPI == EPI_GELU; }
 constexpr int gemm_pk_nst(int NP, int NWV = 8, int EPI = 0) { return NWV == 8 ? (NP == 2 ? 4 : 6) : (NP == 2 ? 3 : (EPI == EPI_GELU ? 4 : 6)); }
 constexpr int gemm_pk_lds(int NP, int NWV = 8, int EPI = 0) { return gemm_pk_nst(NP, NWV, EPI) * (NWV + 8) * gemm_pk_kps(NP) * NP * 1024; }   // + the Phi table when used
