@@ -6,8 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mapf_gpt_amd.model import build_model
 from mapf_gpt_amd import _lib
-for name in ("6M",):
-    net = build_model(name, seed=0, max_rows=64, precision="f16x3")
+cases = [("6M", "f16x3")] if len(sys.argv) < 3 else [(sys.argv[1], sys.argv[2])]
+for name, precision in cases:
+    print(f"# {name} {precision}, 32 rows")
+    net = build_model(name, seed=0, max_rows=64, precision=precision)
     tok = torch.from_numpy(np.random.default_rng(0).integers(0, 67, (32, 256)).astype(np.uint8)).cuda()
     for _ in range(5): net.logits_tokens(tok)
     _lib.prof_enable(True); _lib.prof_reset()
