@@ -699,6 +699,10 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         // (attn256_kernel<.., HP>, one workgroup per (row, head), y planes) and the packed GEMM projects them (round 5)
         const bool small256 = m->attn256 && !last_short && call_rows <= kSmallRows && rows <= kSmallRows && kSmall256;
         const bool proj_fused = m->attn256 && !last_short && kAttn256Fused && !small256;
+        // the packed-GEMM chain (C = 768) in a small call: its residual GEMMs (N = 768: 3 column tiles) are 96 tiles of 256 rows for 32 rows -- 128-row
+        // tiles put them on twice the CUs (same arithmetic per token: a wave's 64 x 128 sub-tile and its k order do not change).  One-plane mode: 32-row
+        // forward 2.77 -> 2.58 ms (c_proj 70 -> 57 us, out-projection 30 -> 26); in the split mode the 4-wave form has a 3-stage ring and loses (5.8 -> 6.4)
+        const bool small_pk = NP == 1 && m->pk_gemm && !m->attn256 && call_rows <= kSmallRows && rows <= kSmallRows;
         // last layer of a launch that fills the chip: the attention block of token 255 alone, without K and V (attn_last1_kernel)
         const bool last1 = last_short && m->last1_wt != nullptr && m->x_tiled && !head_par && kLast1;
         // small launch (one environment): the last layer's attention block, its MLP block, ln_f and the head are ONE launch, one
@@ -831,7 +835,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                     a.raw_out = m->apk; a.rsum_out = m->ln_parts;
                     a.shift = m->ln_mean; a.shift_stride = ls ? kT : 1; a.shift_offset = ls ? kT - 1 : 0;
                 }
-                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s, small256)) != MGPT_OK) return rc;
+                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s, small256 || (small_pk && !ls))) != MGPT_OK) return rc;
                 a.raw_out = nullptr; a.rsum_out = nullptr; a.shift = nullptr;
             } else if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
@@ -914,7 +918,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if (feeds_next) { a.raw_out = m->apk; a.rsum_out = m->ln_parts; a.shift = m->ln_mean; a.shift_stride = 1; a.shift_offset = 0; }
             {
                 ProfScope ps(P_GEMM_PROJ2, s);
-                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s)) != MGPT_OK) return rc;
+                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s, small_pk && !last_short)) != MGPT_OK) return rc;
             }
             if (feeds_next && (rc = ln_finalize(mlp_M, false)) != MGPT_OK) return rc;
             continue;

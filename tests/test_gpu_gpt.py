@@ -202,6 +202,21 @@ def test_head_parallel_small_launch_vs_row_per_workgroup_path(name, precision):
         assert np.abs(small[:40] - ref).max() <= TOL and np.abs(big[:40] - ref).max() <= TOL
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16x3"])
+def test_small_call_of_the_packed_gemm_chain_is_the_large_call_bit_for_bit(precision):
+    """Round 5: a call of <= 128 rows of the packed-GEMM chain (C = 768, the 85M shape) runs its residual GEMMs in 128-row tiles (twice the
+    workgroups: 96 tiles of 256 rows leave most CUs idle).  A wave's 64 x 128 sub-tile and its k order do not change, so -- unlike the head-parallel
+    attention of the smaller shapes -- the small call must reproduce the same rows of a large call bit for bit."""
+    from mapf_gpt_amd.model import build_model
+    rows = np.load(os.path.join(GOLDEN, "gptbig_2M_s1.npz"))["tokens"][:160]
+    net = build_model("85M", seed=0, max_rows=160, precision=precision)
+    big = net.logits_tokens(torch.from_numpy(rows).cuda()).cpu().numpy()
+    assert np.isfinite(big).all()
+    for n_small in (1, 32, 128):
+        small = net.logits_tokens(torch.from_numpy(np.ascontiguousarray(rows[:n_small])).cuda()).cpu().numpy()
+        assert np.array_equal(small, big[:n_small]), f"85M {precision}, {n_small} rows: {np.abs(small - big[:n_small]).max():.3e}"
+
+
 @pytest.mark.parametrize("name,precision", [("2M", "f16x3"), ("6M", "f16x3"), ("6M", "bf16")])
 def test_persistent_kernels_uneven_grid(name, precision):
     """The persistent attention kernels (attn256o_kernel, attn160o_kernel; grid = min(rows, CUs), a workgroup walks rows b, b + grid, ...)
