@@ -430,6 +430,13 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_RESID, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      fastk::gemm_pk_lds(NP, 4, fastk::EPI_RESID)));
+        // the 128-row forms of the other epilogues (small calls of the C = 768 chain)
+#define MGPT_PK4(EPI_, LNF_, EXTRA_)                                                                                                                  \
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_, 4, 0, LNF_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 fastk::gemm_pk_lds(NP, 4, fastk::EPI_) + (EXTRA_)))
+        MGPT_PK4(EPI_QK, false, 0); MGPT_PK4(EPI_VT, false, 0); MGPT_PK4(EPI_GELU, false, fastk::kGeluLutN * 8);
+        MGPT_PK4(EPI_QK, true, 3072); MGPT_PK4(EPI_VT, true, 3072); MGPT_PK4(EPI_GELU, true, fastk::kGeluLutN * 8 + 3072);
+#undef MGPT_PK4
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      lds + fastk::kGeluLutN * 8));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 8, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds + 3072));
@@ -584,17 +591,23 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s, bool half_tiles = false)
     const bool persist = fastk::gemm_pk_persistent(NP, EPI, lnf);    // one workgroup per CU walking the tiles (gpt_kernels_fast.h: gemm_pk_kernel)
     const unsigned grid8 = (unsigned)(persist ? std::min((a.M / 256) * a.n_tiles_n, n_cu) : (a.M / 256) * a.n_tiles_n);
     const unsigned grid4 = (unsigned)(persist ? std::min((a.M / 128) * a.n_tiles_n, 2 * n_cu) : (a.M / 128) * a.n_tiles_n);
+    // half_tiles (small launches: one environment's rows are 32 tiles of 256 rows per column tile, which leaves most CUs idle): 128-row tiles, 4 waves,
+    // two workgroups per CU -- same arithmetic per token (a wave's 64 x 128 sub-tile and its k order do not change)
+    const size_t lut_b = lut ? (size_t)fastk::kGeluLutN * 8 : 0;
     if (lnf) {                                                       // folded LayerNorm (GemmArgs): the Phi table slot is always reserved
         MGPT_REQUIRE(EPI != fastk::EPI_GELU || lut, MGPT_ERR_STATE, "%s", "folded LayerNorm: the GELU epilogue needs the Phi table");
-        hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8, 0, true>), dim3(grid8), dim3(512),
-                           (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0) + 3072, s, a, (unsigned long long *)nullptr);
-    } else if (EPI == fastk::EPI_RESID && half_tiles) {
-        // small launches (one environment's out-projection: 32 tiles of 256 rows would leave 7 of 8 CUs idle): 128-row tiles, 4 waves
+        if (half_tiles)
+            hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 4, 0, true>), dim3(grid4), dim3(256),
+                               (size_t)fastk::gemm_pk_lds(NP, 4, EPI) + lut_b + 3072, s, a, (unsigned long long *)nullptr);
+        else
+            hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8, 0, true>), dim3(grid8), dim3(512),
+                               (size_t)fastk::gemm_pk_lds(NP) + lut_b + 3072, s, a, (unsigned long long *)nullptr);
+    } else if (half_tiles) {
         hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 4>), dim3(grid4), dim3(256),
-                           (size_t)fastk::gemm_pk_lds(NP, 4, EPI), s, a, (unsigned long long *)nullptr);
+                           (size_t)fastk::gemm_pk_lds(NP, 4, EPI) + lut_b, s, a, (unsigned long long *)nullptr);
     } else {
         hipLaunchKernelGGL((fastk::gemm_pk_kernel<T, NP, EPI, 8>), dim3(grid8), dim3(512),
-                           (size_t)fastk::gemm_pk_lds(NP) + (lut ? fastk::kGeluLutN * 8 : 0), s, a, (unsigned long long *)nullptr);
+                           (size_t)fastk::gemm_pk_lds(NP) + lut_b, s, a, (unsigned long long *)nullptr);
     }
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
@@ -701,7 +714,8 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         const bool proj_fused = m->attn256 && !last_short && kAttn256Fused && !small256;
         // the packed-GEMM chain (C = 768) in a small call: its residual GEMMs (N = 768: 3 column tiles) are 96 tiles of 256 rows for 32 rows -- 128-row
         // tiles put them on twice the CUs (same arithmetic per token: a wave's 64 x 128 sub-tile and its k order do not change).  One-plane mode: 32-row
-        // forward 2.77 -> 2.58 ms (c_proj 70 -> 57 us, out-projection 30 -> 26); in the split mode the 4-wave form has a 3-stage ring and loses (5.8 -> 6.4)
+        // forward 2.77 -> 2.49 ms (c_proj 70 -> 56 us, out-projection 30 -> 25, q|k + v^T 51 -> 47); in the split mode the 4-wave form has a 3-stage ring and
+        // loses (5.8 -> 6.4)
         const bool small_pk = NP == 1 && m->pk_gemm && !m->attn256 && call_rows <= kSmallRows && rows <= kSmallRows;
         // last layer of a launch that fills the chip: the attention block of token 255 alone, without K and V (attn_last1_kernel)
         const bool last1 = last_short && m->last1_wt != nullptr && m->x_tiled && !head_par && kLast1;
@@ -791,11 +805,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             const uint16_t *wq = m->ln_fold ? m->attn_pk2g[l] : m->attn_pk2[l];
             a.a_hi = m->apk; a.w_hi = wq; a.chunk_major = 1;
             if (m->ln_fold) { a.ln_stats = m->stats; a.colsum = m->attn_cs[l]; }
-            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_QK>(a, s)) != MGPT_OK) return rc;
+            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_QK>(a, s, small_pk)) != MGPT_OK) return rc;
             a.w_hi = wq + (size_t)(2 * C / 32) * tile_halves;                // rows 2C.. of c_attn.weight: V
             if (m->ln_fold) a.colsum = m->attn_cs[l] + 2 * C;
             a.N = C; a.o_hi = m->vt[0]; a.o_lo = m->vt[1];
-            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_VT>(a, s)) != MGPT_OK) return rc;
+            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_VT>(a, s, small_pk)) != MGPT_OK) return rc;
             a.ln_stats = nullptr; a.colsum = nullptr;
         } else {
             ProfScope ps(P_GEMM_QKV, s);
@@ -909,6 +923,8 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if (m->ln_fold) { a.ln_stats = m->stats; a.colsum = m->fc_cs[l]; }
             {
                 ProfScope ps(P_GEMM_FC, s);
+                // (c_fc keeps its 256-row tiles in small calls too: 384 of them already cover the CUs, and two 4-wave workgroups per CU move 1.5 x the ring
+                //  pieces per MFMA of one 8-wave workgroup -- 54.6 vs 56.5 us per launch at 32 rows)
                 if ((rc = launch_gemm_pk<T, NP, fastk::EPI_GELU>(a, s)) != MGPT_OK) return rc;
             }
             a.ln_stats = nullptr; a.colsum = nullptr;

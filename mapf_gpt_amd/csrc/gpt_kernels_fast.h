@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
             unsigned char *dst = smem + (size_t)NST * STAGE + (EPI == EPI_GELU ? kGeluLutN * 8 : 0);   // is behind the previous epilogue's reads)
             if (wave == 0)
                 __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.colsum + nt * 256) + lane * 16), (lds_void_t *)dst, 16, 0, 0);
-            if (wave == 1 || wave == 2)                    // (mean, rstd) of the block's 256 rows: 2 KiB
+            if (wave == 1 || (wave == 2 && AF == 8))       // (mean, rstd) of the block's AF x 32 rows: 2 KiB (1 KiB for the 128-row form)
                 __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.ln_stats + (size_t)mt * (AF * 32)) + (wave - 1) * 1024 + lane * 16),
                                                  (lds_void_t *)(dst + wave * 1024), 16, 0, 0);
             // (extra operations YOUNGER than a piece only make a counted wait for that piece stricter; the tail of the k loop waits for everything)
