@@ -39,6 +39,10 @@ struct F16T {
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)      // (probe only: the 16 x 16 x 32 form)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    }
 };
 struct BF16T {
     static __device__ __forceinline__ uint16_t cvt(float v)
@@ -51,6 +55,10 @@ struct BF16T {
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c)
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
     }
 };
 
@@ -938,6 +946,11 @@ constexpr bool kGemmPkPlace = false;
 #else
 constexpr bool kGemmPkPlace = true;
 #endif
+#ifdef MGPT_ABL_GEMM_16X16
+constexpr int kGemmPkMfmaPerTile = 2;       // (timing experiment: two 16 x 16 x 32 MFMAs in the place of every 32 x 32 x 16 one, see `round`)
+#else
+constexpr int kGemmPkMfmaPerTile = 1;
+#endif
 #ifdef MGPT_AB_GEMM_DMA_TOP
 constexpr bool kGemmPkDmaPlace = false;
 #else
@@ -1043,8 +1056,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int j = 0; j < TN; j++)
+            for (int j = 0; j < TN; j++) {
+#ifdef MGPT_ABL_GEMM_16X16
+                // timing experiment (tools/bench_probes/probe_gemm_pk.hip, results are WRONG): every 32 x 32 x 16 MFMA replaced by two 16 x 16 x 32 MFMAs on the
+                // same operand registers (the same flops, the same fragment reads), accumulating into two quads of the tile's registers
+                f32x4 c0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, c1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
+                c0 = T::mfma16(fb[buf][j][pb], fa[buf][i][pa], c0);
+                c1 = T::mfma16(fa[buf][i][pa], fb[buf][j][pb], c1);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { acc[i][j][e] = c0[e]; acc[i][j][4 + e] = c1[e]; }
+#else
                 acc[i][j] = SWAP ? T::mfma(fb[buf][j][pb], fa[buf][i][pa], acc[i][j]) : T::mfma(fa[buf][i][pa], fb[buf][j][pb], acc[i][j]);
+#endif
+            }
         if (!kGemmPkPlace) __builtin_amdgcn_sched_barrier(0);
     };
     auto mfmas = [&](int buf) {
@@ -1099,7 +1123,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
         mfmas(buf);
         // (the refill is a store to LDS as far as hipcc knows: the fragment reads, earlier in program order, stay in front of it -- so the reads go
         //  behind the first MFMAs and the refill pieces behind the ones that follow)
-        constexpr int NMF = TM * TN * (NP == 2 ? 3 : 1), NRD = (TM + TN) * NP, GAP = (NMF - NRD) / PER_WAVE > 0 ? (NMF - NRD) / PER_WAVE : 1;
+        constexpr int NMF = kGemmPkMfmaPerTile * TM * TN * (NP == 2 ? 3 : 1), NRD = (TM + TN) * NP, GAP = (NMF - NRD) / PER_WAVE > 0 ? (NMF - NRD) / PER_WAVE : 1;
 #pragma unroll
         for (int n = 0; n < NMF; n++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
