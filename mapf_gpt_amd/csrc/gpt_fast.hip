@@ -437,6 +437,16 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         MGPT_PK4(EPI_QK, false, 0); MGPT_PK4(EPI_VT, false, 0); MGPT_PK4(EPI_GELU, false, fastk::kGeluLutN * 8);
         MGPT_PK4(EPI_QK, true, 3072); MGPT_PK4(EPI_VT, true, 3072); MGPT_PK4(EPI_GELU, true, fastk::kGeluLutN * 8 + 3072);
 #undef MGPT_PK4
+        if constexpr (NP == 1) {
+#define MGPT_PK16(EPI_, NWV_, LNF_, EXTRA_)                                                                                                            \
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk16_kernel<T, fastk::EPI_, NWV_, LNF_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 fastk::gemm_pk_lds(NP, NWV_, fastk::EPI_) + (EXTRA_)))
+            MGPT_PK16(EPI_QK, 8, false, 0); MGPT_PK16(EPI_VT, 8, false, 0); MGPT_PK16(EPI_RESID, 8, false, 0); MGPT_PK16(EPI_GELU, 8, false, fastk::kGeluLutN * 8);
+            MGPT_PK16(EPI_QK, 4, false, 0); MGPT_PK16(EPI_VT, 4, false, 0); MGPT_PK16(EPI_RESID, 4, false, 0); MGPT_PK16(EPI_GELU, 4, false, fastk::kGeluLutN * 8);
+            MGPT_PK16(EPI_QK, 8, true, 3072); MGPT_PK16(EPI_VT, 8, true, 3072); MGPT_PK16(EPI_GELU, 8, true, fastk::kGeluLutN * 8 + 3072);
+            MGPT_PK16(EPI_QK, 4, true, 3072); MGPT_PK16(EPI_VT, 4, true, 3072); MGPT_PK16(EPI_GELU, 4, true, fastk::kGeluLutN * 8 + 3072);
+#undef MGPT_PK16
+        }
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_GELU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      lds + fastk::kGeluLutN * 8));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::gemm_pk_kernel<T, NP, fastk::EPI_QK, 8, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds + 3072));
@@ -565,6 +575,12 @@ int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
     return MGPT_OK;
 }
 
+#ifdef MGPT_AB_GEMM_32X32
+constexpr bool kGemmPk16 = false;       // A/B: the one-plane packed GEMM on the 32 x 32 x 16 MFMA as in rounds 1-4
+#else
+constexpr bool kGemmPk16 = true;
+#endif
+
 // compute units of the current device (grid of the persistent packed GEMM); asked once
 int gemm_pk_cus()
 {
@@ -594,6 +610,21 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s, bool half_tiles = false)
     // half_tiles (small launches: one environment's rows are 32 tiles of 256 rows per column tile, which leaves most CUs idle): 128-row tiles, 4 waves,
     // two workgroups per CU -- same arithmetic per token (a wave's 64 x 128 sub-tile and its k order do not change)
     const size_t lut_b = lut ? (size_t)fastk::kGeluLutN * 8 : 0;
+    if constexpr (NP == 1 && kGemmPk16) {
+        // one-plane mode: the same GEMM on v_mfma_f32_16x16x32 (gpt_kernels_fast.h: gemm_pk16_kernel), one workgroup per tile
+        if (a.K % 64 == 0 && a.K >= 128 && (EPI != fastk::EPI_GELU || lut)) {
+            const unsigned g8 = (unsigned)((a.M / 256) * a.n_tiles_n), g4 = (unsigned)((a.M / 128) * a.n_tiles_n);
+            if (lnf) {
+                if (half_tiles) hipLaunchKernelGGL((fastk::gemm_pk16_kernel<T, EPI, 4, true>), dim3(g4), dim3(256), (size_t)fastk::gemm_pk_lds(NP, 4, EPI) + lut_b + 3072, s, a);
+                else hipLaunchKernelGGL((fastk::gemm_pk16_kernel<T, EPI, 8, true>), dim3(g8), dim3(512), (size_t)fastk::gemm_pk_lds(NP) + lut_b + 3072, s, a);
+            } else {
+                if (half_tiles) hipLaunchKernelGGL((fastk::gemm_pk16_kernel<T, EPI, 4, false>), dim3(g4), dim3(256), (size_t)fastk::gemm_pk_lds(NP, 4, EPI) + lut_b, s, a);
+                else hipLaunchKernelGGL((fastk::gemm_pk16_kernel<T, EPI, 8, false>), dim3(g8), dim3(512), (size_t)fastk::gemm_pk_lds(NP) + lut_b, s, a);
+            }
+            MGPT_LAUNCH_CHECK();
+            return MGPT_OK;
+        }
+    }
     if (lnf) {                                                       // folded LayerNorm (GemmArgs): the Phi table slot is always reserved
         MGPT_REQUIRE(EPI != fastk::EPI_GELU || lut, MGPT_ERR_STATE, "%s", "folded LayerNorm: the GELU epilogue needs the Phi table");
         if (half_tiles)

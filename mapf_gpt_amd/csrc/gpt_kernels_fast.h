@@ -1217,6 +1217,330 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_pk_kernel(GemmArgs p, unsign
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_pk16_kernel (round 5): the ONE-PLANE packed GEMM on v_mfma_f32_16x16x32 instead of v_mfma_f32_32x32x16.  At the package power limit the small shape delivers
+// 10 % (bf16) to 15 % (f16) more flops per second (profiles/r05_probe_mfma_shape.txt: the same operand bytes per flop, half the accumulator traffic), in this kernel's
+// own loop -6...8 % (same file, "in situ").  Memory layouts do not change (PK fragments in, the epilogues' outputs); what changes is the slicing:
+//   * a ring PAIR = two stages = K 32.  A 16 x 16 x 32 operand (16 rows x 32 k) comes out of the two stages' 32-row fragments with ONE ds_read_b128 per lane: lane
+//     (rho = lane % 16, q = lane / 16) takes row rho (+ 16 for the odd 16-row group) and the 8 k of half (q & 1) from stage 2 p + (q >> 1) -- 16 lanes read 256
+//     contiguous bytes; the two stages of a pair sit in consecutive ring slots (the ring depth is even), so the stage is a per-lane constant offset;
+//   * wave tile 64 tokens x 128 columns = 4 x 8 groups of 16: 32 MFMAs and 12 operand reads per pair (as many reads as two k-steps had), one barrier per PAIR;
+//   * D(ng, mg): a lane holds token 16 mg + rho and the columns 16 ng + 4 q .. + 3 (swapped orientation: q|k, GELU, residual) resp. the tokens
+//     16 mg + 4 q .. + 3 and column 16 ng + rho (v^T) -- a quad of four consecutive columns (tokens) per register quad, as in the 32 x 32 layout, so the
+//     epilogues store the same 8- / 16-byte pieces; a token now sits in FOUR lanes (rho + 16 q), the row sums of the residual epilogue fold over them.
+// Weight fragments are single-buffered (a group's fragment is re-read for the next pair as soon as its four MFMAs are out), token fragments double-buffered.
+// ---------------------------------------------------------------------------------------------
+template <class T, int EPI, bool LNF>
+__device__ __forceinline__ void gemm16x16_epilogue(const GemmArgs &p, f32x4 (&c)[8][4], int64_t m0w, int n0w, int mloc0, int nloc0, int rho, int q,
+                                                   unsigned lut_addr, unsigned cs_addr)
+{
+    // m0w / n0w: first token / column of this wave's 64 x 128 tile; mloc0 / nloc0: the same inside the block (rows of the LNF statistics / column sums in LDS)
+    constexpr int NP = 1;
+    const float os = p.out_scale;
+    if constexpr (EPI == EPI_VT) {
+        // natural orientation: lane = column n (-> head, d), registers = 4 consecutive tokens; v^T planes [rows][n_head][hs][256]
+        const int64_t b = m0w >> 8;
+        const int tb = (int)(m0w & (kT - 1));
+#pragma unroll
+        for (int ng = 0; ng < 8; ng++) {
+            const int n = n0w + 16 * ng + rho;
+            const int head = n / p.hs, d = n - head * p.hs;
+            const int64_t rowbase = ((b * p.n_head + head) * p.hs + d) * kT;
+            float cs = 0.f;
+            if constexpr (LNF) asm volatile("ds_read_b32 %0, %1" : "=v"(cs) : "v"(cs_addr + (unsigned)(nloc0 + 16 * ng + rho) * 4u) : "memory");
+#pragma unroll
+            for (int mg = 0; mg < 4; mg++) {
+                float v[4] = {c[ng][mg][0], c[ng][mg][1], c[ng][mg][2], c[ng][mg][3]};
+                if constexpr (LNF) {                                       // (mean, rstd) of the 4 consecutive tokens, from the block's LDS copy
+                    f32x4 s01, s23;
+                    const unsigned sa = cs_addr + 1024u + (unsigned)(mloc0 + 16 * mg + 4 * q) * 8u;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(s01) : "v"(sa) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(s23) : "v"(sa) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s01), "+v"(s23), "+v"(cs) : : "memory");
+                    const float mean[4] = {s01[0], s01[2], s23[0], s23[2]}, rstd[4] = {s01[1], s01[3], s23[1], s23[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = rstd[e] * fmaf(-mean[e], cs, v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] *= os;
+                const int t = tb + 16 * mg + 4 * q;
+                u32x2 hi, lo;
+                split4<T, NP>(v, hi, lo);
+                const int64_t off = p.chunk_major ? (((b * p.n_head + head) * (kT / 8) + (t >> 3)) * p.hs + d) * 8 + (t & 7) : rowbase + t;
+                *reinterpret_cast<u32x2 *>(p.o_hi + off) = hi;
+            }
+        }
+    } else {
+        // swapped: lane = token, registers = 4 consecutive output columns
+#pragma unroll
+        for (int mg = 0; mg < 4; mg++) {
+            const int64_t m = m0w + 16 * mg + rho;
+            f32x2 st = {0.f, 1.f};
+            if constexpr (LNF && EPI != EPI_RESID) {
+                asm volatile("ds_read_b64 %0, %1" : "=v"(st) : "v"(cs_addr + 1024u + (unsigned)(mloc0 + 16 * mg + rho) * 8u) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st) : : "memory");
+            }
+            const float osi = (LNF && EPI != EPI_RESID) ? os * st[1] : os;
+            if constexpr (LNF && EPI != EPI_RESID) {                       // acc <- acc - mean * colsum; rstd rides on the output scale
+#pragma unroll
+                for (int ng = 0; ng < 8; ng++) {
+                    f32x4 cs;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(cs) : "v"(cs_addr + (unsigned)(nloc0 + 16 * ng + 4 * q) * 4u) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cs) : : "memory");
+#pragma unroll
+                    for (int e = 0; e < 4; e++) c[ng][mg][e] = fmaf(-st[0], cs[e], c[ng][mg][e]);
+                }
+            }
+            if constexpr (EPI == EPI_RESID) {
+                const float sh = (p.raw_out != nullptr && p.shift != nullptr) ? p.shift[m * p.shift_stride + p.shift_offset] : 0.f;
+                float rsum = 0.f, rsq = 0.f;
+                f32x4 cur[8];                                              // the token's eight quads of this wave's 128 columns: all reads in flight before the first store
+#pragma unroll
+                for (int ng = 0; ng < 8; ng++)
+                    cur[ng] = *reinterpret_cast<const f32x4 *>(p.x_out + (p.x_tiled ? xt_off(m, n0w + 16 * ng + 4 * q, p.N) : m * p.N + n0w + 16 * ng + 4 * q));
+#pragma unroll
+                for (int ng = 0; ng < 8; ng++) {
+                    const int n = n0w + 16 * ng + 4 * q;
+                    f32x4 x4 = cur[ng];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) x4[e] += c[ng][mg][e] * os;
+                    *reinterpret_cast<f32x4 *>(p.x_out + (p.x_tiled ? xt_off(m, n, p.N) : m * p.N + n)) = x4;
+                    if (p.raw_out != nullptr) {                            // the next GEMM's A operand: the raw row in operand planes (see gemm16_epilogue)
+                        const float v[4] = {x4[0] - sh, x4[1] - sh, x4[2] - sh, x4[3] - sh};
+                        rsum += (v[0] + v[1]) + (v[2] + v[3]);
+                        rsq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                        u32x2 hi, lo;
+                        split4<T, NP>(v, hi, lo);
+                        *reinterpret_cast<u32x2 *>(p.raw_out + pk_off(m, n, 0, p.N >> 4, NP)) = hi;
+                    } else rsum += (x4[0] + x4[1]) + (x4[2] + x4[3]);
+                }
+                if (p.rsum_out != nullptr) {                               // this wave's 128 columns of the row: the token sits in lanes rho + 16 q
+                    rsum += __shfl_xor(rsum, 16); rsq += __shfl_xor(rsq, 16);
+                    rsum += __shfl_xor(rsum, 32); rsq += __shfl_xor(rsq, 32);
+                    if (q == 0) p.rsum_out[(size_t)(n0w >> 7) * (size_t)p.M + m] = make_float2(rsum, rsq);
+                }
+                continue;
+            }
+            if constexpr (EPI == EPI_GELU) {
+                // Phi table in LDS: 16 gathers (four quads) in flight per LDS round trip
+#pragma unroll
+                for (int nb = 0; nb < 8; nb += 4) {
+                    float v[16], fr[16];
+                    f32x2 tb[16];
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        v[g] = c[nb + (g >> 2)][mg][g & 3] * osi;
+                        const float tt = __builtin_amdgcn_fmed3f(fmaf(v[g], kGeluLutScale, kGeluLutBias), 0.0f, (float)kGeluLutN - 0.002f);
+                        fr[g] = __builtin_amdgcn_fractf(tt);
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(tb[g]) : "v"(lut_addr + (unsigned)tt * 8u) : "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        asm volatile("" : "+v"(tb[g]));
+                        v[g] *= fmaf(fr[g], tb[g][1], tb[g][0]);
+                    }
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; k4++) {
+                        const int n = n0w + 16 * (nb + k4) + 4 * q;
+                        u32x2 hi, lo;
+                        split4<T, NP>(v + 4 * k4, hi, lo);
+                        if (p.o_pk) *reinterpret_cast<u32x2 *>(p.o_hi + pk_off(m, n, 0, p.N >> 4, NP)) = hi;
+                        else *reinterpret_cast<u32x2 *>(p.o_hi + m * p.N + n) = hi;
+                    }
+                }
+                continue;
+            }
+            // EPI_QK: q|k planes [which][rows][n_head][256][hs] (chunk-major: [which][rows][n_head][hs/8][256][8 d])
+#pragma unroll
+            for (int ng = 0; ng < 8; ng++) {
+                const int n = n0w + 16 * ng + 4 * q;
+                const float v[4] = {c[ng][mg][0] * osi, c[ng][mg][1] * osi, c[ng][mg][2] * osi, c[ng][mg][3] * osi};
+                const int which = n / p.C, cc = n - which * p.C;
+                const int head = cc / p.hs, d = cc - head * p.hs;
+                const int64_t bb = m >> 8;
+                const int t = (int)(m & (kT - 1));
+                const int64_t off = (int64_t)which * p.plane + (p.chunk_major ? (((bb * p.n_head + head) * (p.hs >> 3) + (d >> 3)) * kT + t) * 8 + (d & 7)
+                                                                             : ((bb * p.n_head + head) * kT + t) * p.hs + d);
+                u32x2 hi, lo;
+                split4<T, NP>(v, hi, lo);
+                *reinterpret_cast<u32x2 *>(p.o_hi + off) = hi;
+            }
+        }
+    }
+}
+
+#ifndef MGPT_PK16_SALU
+#define MGPT_PK16_SALU 12
+#endif
+constexpr int kPk16SaluBehind = MGPT_PK16_SALU;
+template <class T, int EPI, int NWV, bool LNF = false>
+__global__ __launch_bounds__(NWV * 64, 2) void gemm_pk16_kernel(GemmArgs p)
+{
+    static_assert(NWV == 8 || NWV == 4, "8 or 4 waves of 64 x 128");
+    constexpr int NP = 1;
+    constexpr int AF = NWV;                                // A (token) fragments per k-step = block rows / 32
+    constexpr bool SWAP = (EPI != EPI_VT);
+    constexpr int NST = gemm_pk_nst(NP, NWV, EPI);         // ring depth in stages: even, so that a pair's two stages are consecutive slots
+    static_assert(NST % 2 == 0 && NST >= 4, "ring of whole pairs");
+    constexpr int STAGE = (AF + 8) * 1024;
+    constexpr int PER_WAVE = (AF + 8) / NWV;
+    static_assert((AF + 8) % NWV == 0, "ring shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NST][STAGE] | Phi table | LNF pieces
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // block -> tile map: as gemm_pk_kernel (XCD-aware bands), one workgroup per tile
+    const int nb = gridDim.x, ntn = p.n_tiles_n, mtn = nb / ntn;
+    int id = blockIdx.x;
+    if ((nb & 7) == 0) id = (id & 7) * (nb >> 3) + (id >> 3);
+    constexpr int GM = 32 / AF;
+    const int band = id / (GM * ntn);
+    const int gm = min(GM, mtn - band * GM);
+    const int rem = id - band * GM * ntn;
+    const int nt = rem / gm, mt = band * GM + (rem - nt * gm);
+    const int KS = p.K >> 4, NSTG = KS, NP2 = NSTG / 2;
+    const unsigned char *abase = reinterpret_cast<const unsigned char *>(p.a_hi) + (size_t)mt * AF * KS * 1024 + lane * 16;
+    const unsigned char *bbase = reinterpret_cast<const unsigned char *>(p.w_hi) + (size_t)nt * 8 * KS * 1024 + lane * 16;
+    // stage S -> ring slot `slot` (= S % NST; the k loop carries the slot of its pair instead of dividing)
+    auto issue = [&](int S, int slot) {
+        unsigned char *dst = smem + (size_t)slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; i++) {
+            const int f = wave + NWV * i;
+            const unsigned char *src = (f < AF) ? abase + ((size_t)(f * KS + S)) * 1024 : bbase + ((size_t)((f - AF) * KS + S)) * 1024;
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(dst + (size_t)f * 1024), 16, 0, 0);
+        }
+    };
+    unsigned lut_addr = 0u;
+    if (EPI == EPI_GELU && p.gelu_lut != nullptr) {        // (uniform) Phi table behind the ring, older than every ring piece
+        unsigned char *dst = smem + (size_t)NST * STAGE;
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(p.gelu_lut);
+#pragma unroll
+        for (int i = 0; i < kGeluLutN * 8 / 1024 / NWV; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (size_t)(wave + NWV * i) * 1024 + lane * 16),
+                                             (lds_void_t *)(dst + (size_t)(wave + NWV * i) * 1024), 16, 0, 0);
+        lut_addr = (unsigned)(size_t)dst;
+    }
+    unsigned cs_addr = 0u;
+    if constexpr (LNF) {                                   // column sums + (mean, rstd) of the block's rows: older than every ring piece
+        unsigned char *dst = smem + (size_t)NST * STAGE + (EPI == EPI_GELU ? kGeluLutN * 8 : 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.colsum + nt * 256) + lane * 16), (lds_void_t *)dst, 16, 0, 0);
+        if (wave == 1 || (wave == 2 && AF == 8))
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(reinterpret_cast<const unsigned char *>(p.ln_stats + (size_t)mt * (AF * 32)) + (wave - 1) * 1024 + lane * 16),
+                                             (lds_void_t *)(dst + wave * 1024), 16, 0, 0);
+        cs_addr = (unsigned)(size_t)dst;
+    }
+#pragma unroll
+    for (int S = 0; S < NST; S++) issue(S, S);             // K >= 128 and K % 64 == 0 are checked by the launcher
+
+    f32x4 c[8][4];
+#pragma unroll
+    for (int ng = 0; ng < 8; ng++)
+#pragma unroll
+        for (int mg = 0; mg < 4; mg++) c[ng][mg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this lane's 16 bytes inside a 32-row fragment: row rho of the even 16-row group, k half q & 1; + (q >> 1) stages
+    const unsigned char *lbase = smem + (size_t)(q >> 1) * STAGE + (size_t)(rho + 32 * (q & 1)) * 16;
+    const unsigned char *wfr = lbase + (size_t)(AF + wn * 4) * 1024;       // weight fragments of this wave's 128 columns (4 fragments)
+    const unsigned char *tfr = lbase + (size_t)(wm * 2) * 1024;            // token fragments of this wave's 64 rows (2 fragments)
+    u32x4 wa[8], ta[2][4];
+    auto rd_w = [&](int ps, int ng) { return *reinterpret_cast<const u32x4 *>(wfr + (size_t)(2 * ps) * STAGE + (ng >> 1) * 1024 + (ng & 1) * 256); };
+    auto rd_t = [&](int ps, int mg) { return *reinterpret_cast<const u32x4 *>(tfr + (size_t)(2 * ps) * STAGE + (mg >> 1) * 1024 + (mg & 1) * 256); };
+    // one pair (its stages sit in ring slots 2 ps, 2 ps + 1): 32 MFMAs.  FETCH: the operands of the next pair (slots 2 psn ..) are read behind them, a weight
+    // group's fragment right after the group's four MFMAs.  ISSUE: this pair's slots -- read during the pair before -- are refilled with the stages NST ahead;
+    // the refill stands in front of the last two groups' MFMAs in program order (to hipcc it is a store to LDS: the ten reads before it stay before it, the two
+    // after it stay after) and goes out one piece behind each of their first MFMAs
+    auto pair = [&](int pr, int buf, int ps, int psn, auto fetch_c, auto issue_c) {
+        constexpr bool FETCH = decltype(fetch_c)::value, ISSUE = decltype(issue_c)::value;
+        constexpr int NPIECE = ISSUE ? 2 * PER_WAVE : 0;
+#pragma unroll
+        for (int ng = 0; ng < 8; ng++) {
+            if (ng == 6) { if constexpr (ISSUE) { issue(2 * pr + NST, 2 * ps); issue(2 * pr + NST + 1, 2 * ps + 1); } }
+#pragma unroll
+            for (int mg = 0; mg < 4; mg++)
+                c[ng][mg] = SWAP ? T::mfma16(wa[ng], ta[buf][mg], c[ng][mg]) : T::mfma16(ta[buf][mg], wa[ng], c[ng][mg]);
+            if constexpr (FETCH) {
+                wa[ng] = rd_w(psn, ng);
+                if (ng < 4) ta[buf ^ 1][ng] = rd_t(psn, ng);
+            }
+        }
+        if constexpr (FETCH || ISSUE) {
+#pragma unroll
+            for (int ng = 0; ng < 8; ng++) {
+                if (ng < 6) {
+                    if (ng == 0 && kPk16SaluBehind > 0) {                 // the pair's slot / address arithmetic behind the first MFMA (as in gemm_pk_kernel)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x004, kPk16SaluBehind, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    } else
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    if constexpr (FETCH) { if (ng < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 4; n++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (4 * (ng - 6) + n < NPIECE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    }
+                    if constexpr (FETCH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using Y = std::true_type; using N_ = std::false_type;
+
+    // stages 0, 1 have landed for everyone; the operands of pair 0
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER_WAVE) : "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ng = 0; ng < 8; ng++) wa[ng] = rd_w(0, ng);
+#pragma unroll
+    for (int mg = 0; mg < 4; mg++) ta[0][mg] = rd_t(0, mg);
+    constexpr int NPS = NST / 2;                            // ring slots, in pairs
+    int ps = 0;                                            // pair slot of the pair about to run
+    auto next_ps = [&](int x) { return x + 1 == NPS ? 0 : x + 1; };
+    // main part: pair pr + 1's stages have landed (the NST - 4 stages issued after them may be in flight), everyone holds pair pr's operands in registers.
+    // The last four pairs are written out (which of them still refill the ring is a compile-time fact): K % 64 == 0 and K >= 128 are checked by the launcher.
+    constexpr int TAILP = 4;
+    static_assert(NST / 2 <= TAILP, "every pair that no longer refills is in the written-out tail");
+    int pr = 0;
+#pragma unroll 1
+    for (; pr < NP2 - TAILP; pr += 2) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 4) * PER_WAVE) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int ps1 = next_ps(ps), ps2 = next_ps(ps1);
+        pair(pr, 0, ps, ps1, Y{}, Y{});
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 4) * PER_WAVE) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        pair(pr + 1, 1, ps1, ps2, Y{}, Y{});
+        ps = ps2;
+    }
+    // tail pair t = 0 .. 3 (pr = NP2 - 4 + t): refills while t < 4 - NST / 2, fetches while t < 3; everything issued has to land (vmcnt(0): a counted
+    // form would need a count per pair)
+    auto tail_pair = [&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if constexpr (t < TAILP - 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int psn = next_ps(ps);
+        pair(pr + t, t & 1, ps, psn, std::integral_constant<bool, (t < TAILP - 1)>{}, std::integral_constant<bool, (t < TAILP - NST / 2)>{});
+        ps = psn;
+    };
+    tail_pair(std::integral_constant<int, 0>{}); tail_pair(std::integral_constant<int, 1>{});
+    tail_pair(std::integral_constant<int, 2>{}); tail_pair(std::integral_constant<int, 3>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (nothing is in flight; LNF pieces and the Phi table have landed)
+    gemm16x16_epilogue<T, EPI, LNF>(p, c, (int64_t)mt * (AF * 32) + wm * 64, nt * 256 + wn * 128, wm * 64, wn * 128, rho, q, lut_addr, cs_addr);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Non-causal attention on planes (model.py:58-60): one workgroup per (row, head); K and V^T planes
 // staged once in LDS, each wave owns 2 query tiles of 32.  S^T = K Q^T so a lane owns one query:
 // running (max, sum) softmax is in-lane (+1 exchange with lane^32), P converts in-lane into the
