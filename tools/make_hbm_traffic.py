@@ -32,9 +32,9 @@ KEYS = [  # (json key, kernel substring, grid, note)
 ]
 
 KEYS5 = [  # from the cfg5 passes (bench.py --workload cfg5 --precision bf16, launches of 1024 rows = 262 144 tokens)
-    ("cfg5_bf16_gpt_gemm_mlp_fc", "gemm_pk_kernel<mgpt::fastk::BF16T, 1, 3, 8, 0, true>", 131072,   # persistent: one workgroup per CU
+    ("cfg5_bf16_gpt_gemm_mlp_fc", "gemm_pk16_kernel<mgpt::fastk::BF16T, 3, 8, true>", 6291456,
      "c_fc of the 85M bf16 chain (LayerNorm folded): raw operand planes of 262 144 tokens x 768 in, hidden planes x 3072 out, weight tiles from L2"),
-    ("cfg5_bf16_gpt_gemm_mlp_proj", "gemm_pk_kernel<mgpt::fastk::BF16T, 1, 2, 8, 0, false>", 1572864,
+    ("cfg5_bf16_gpt_gemm_mlp_proj", "gemm_pk16_kernel<mgpt::fastk::BF16T, 2, 8, false>", 1572864,
      "residual GEMMs of the 85M bf16 chain (attention out-projection K = 768 and mlp.c_proj K = 3072 share this instantiation: the average mixes both)"),
 ]
 
