@@ -594,7 +594,7 @@ int gemm_pk_cus()
 }
 
 template <class T, int NP, int EPI>
-int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s, bool half_tiles = false)
+int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s, bool half_tiles = false, bool big_call = true)
 {
     constexpr int NST = fastk::gemm_pk_nst(NP, 8, EPI), KPS = fastk::gemm_pk_kps(NP);
     MGPT_REQUIRE(a.M % 256 == 0 && a.N % 256 == 0 && a.K % 32 == 0 && a.K >= 16 * KPS * NST, MGPT_ERR_UNSUPPORTED,
@@ -612,7 +612,9 @@ int launch_gemm_pk(fastk::GemmArgs a, hipStream_t s, bool half_tiles = false)
     const size_t lut_b = lut ? (size_t)fastk::kGeluLutN * 8 : 0;
     if constexpr (NP == 1 && kGemmPk16) {
         // one-plane mode: the same GEMM on v_mfma_f32_16x16x32 (gpt_kernels_fast.h: gemm_pk16_kernel), one workgroup per tile
-        if (a.K % 64 == 0 && a.K >= 128 && (EPI != fastk::EPI_GELU || lut)) {
+        // -- in LARGE calls only: a 32-row forward is not at the power limit, and there the 12 % more cycles per flop of the small shape show (2.49 -> 2.71 ms);
+        // the choice is a property of the call (as for the other small-launch kernels), so every chunk of a call runs the same arithmetic
+        if (big_call && a.K % 64 == 0 && a.K >= 128 && (EPI != fastk::EPI_GELU || lut)) {
             const unsigned g8 = (unsigned)((a.M / 256) * a.n_tiles_n), g4 = (unsigned)((a.M / 128) * a.n_tiles_n);
             if (lnf) {
                 if (half_tiles) hipLaunchKernelGGL((fastk::gemm_pk16_kernel<T, EPI, 4, true>), dim3(g4), dim3(256), (size_t)fastk::gemm_pk_lds(NP, 4, EPI) + lut_b + 3072, s, a);
@@ -748,6 +750,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         // forward 2.77 -> 2.49 ms (c_proj 70 -> 56 us, out-projection 30 -> 25, q|k + v^T 51 -> 47); in the split mode the 4-wave form has a 3-stage ring and
         // loses (5.8 -> 6.4)
         const bool small_pk = NP == 1 && m->pk_gemm && !m->attn256 && call_rows <= kSmallRows && rows <= kSmallRows;
+        const bool big_call = call_rows > kSmallRows;                      // the one-plane packed GEMMs run on the 16 x 16 x 32 MFMA (launch_gemm_pk)
         // last layer of a launch that fills the chip: the attention block of token 255 alone, without K and V (attn_last1_kernel)
         const bool last1 = last_short && m->last1_wt != nullptr && m->x_tiled && !head_par && kLast1;
         // small launch (one environment): the last layer's attention block, its MLP block, ln_f and the head are ONE launch, one
@@ -836,11 +839,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             const uint16_t *wq = m->ln_fold ? m->attn_pk2g[l] : m->attn_pk2[l];
             a.a_hi = m->apk; a.w_hi = wq; a.chunk_major = 1;
             if (m->ln_fold) { a.ln_stats = m->stats; a.colsum = m->attn_cs[l]; }
-            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_QK>(a, s, small_pk)) != MGPT_OK) return rc;
+            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_QK>(a, s, small_pk, big_call)) != MGPT_OK) return rc;
             a.w_hi = wq + (size_t)(2 * C / 32) * tile_halves;                // rows 2C.. of c_attn.weight: V
             if (m->ln_fold) a.colsum = m->attn_cs[l] + 2 * C;
             a.N = C; a.o_hi = m->vt[0]; a.o_lo = m->vt[1];
-            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_VT>(a, s, small_pk)) != MGPT_OK) return rc;
+            if ((rc = launch_gemm_pk<T, NP, fastk::EPI_VT>(a, s, small_pk, big_call)) != MGPT_OK) return rc;
             a.ln_stats = nullptr; a.colsum = nullptr;
         } else {
             ProfScope ps(P_GEMM_QKV, s);
@@ -880,7 +883,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                     a.raw_out = m->apk; a.rsum_out = m->ln_parts;
                     a.shift = m->ln_mean; a.shift_stride = ls ? kT : 1; a.shift_offset = ls ? kT - 1 : 0;
                 }
-                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s, small256 || (small_pk && !ls))) != MGPT_OK) return rc;
+                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s, small256 || (small_pk && !ls), big_call)) != MGPT_OK) return rc;
                 a.raw_out = nullptr; a.rsum_out = nullptr; a.shift = nullptr;
             } else if ((rc = launch_gemm16<T, NP, fastk::PRO_PLANES, fastk::EPI_RESID>(a, C, s)) != MGPT_OK) return rc;
         }
@@ -956,7 +959,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                 ProfScope ps(P_GEMM_FC, s);
                 // (c_fc keeps its 256-row tiles in small calls too: 384 of them already cover the CUs, and two 4-wave workgroups per CU move 1.5 x the ring
                 //  pieces per MFMA of one 8-wave workgroup -- 54.6 vs 56.5 us per launch at 32 rows)
-                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_GELU>(a, s)) != MGPT_OK) return rc;
+                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_GELU>(a, s, false, big_call)) != MGPT_OK) return rc;
             }
             a.ln_stats = nullptr; a.colsum = nullptr;
             a.a_hi = m->hbuf[0]; a.K = 4 * C; a.N = C; a.w_hi = m->proj2_pk2[l]; a.out_scale = m->proj2[l].inv_scale;
@@ -965,7 +968,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             if (feeds_next) { a.raw_out = m->apk; a.rsum_out = m->ln_parts; a.shift = m->ln_mean; a.shift_stride = 1; a.shift_offset = 0; }
             {
                 ProfScope ps(P_GEMM_PROJ2, s);
-                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s, small_pk && !last_short)) != MGPT_OK) return rc;
+                if ((rc = launch_gemm_pk<T, NP, fastk::EPI_RESID>(a, s, small_pk && !last_short, big_call)) != MGPT_OK) return rc;
             }
             if (feeds_next && (rc = ln_finalize(mlp_M, false)) != MGPT_OK) return rc;
             continue;

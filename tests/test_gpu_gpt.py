@@ -203,18 +203,27 @@ def test_head_parallel_small_launch_vs_row_per_workgroup_path(name, precision):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16x3"])
-def test_small_call_of_the_packed_gemm_chain_is_the_large_call_bit_for_bit(precision):
-    """Round 5: a call of <= 128 rows of the packed-GEMM chain (C = 768, the 85M shape) runs its residual GEMMs in 128-row tiles (twice the
-    workgroups: 96 tiles of 256 rows leave most CUs idle).  A wave's 64 x 128 sub-tile and its k order do not change, so -- unlike the head-parallel
-    attention of the smaller shapes -- the small call must reproduce the same rows of a large call bit for bit."""
+def test_small_call_of_the_packed_gemm_chain_vs_the_large_call(precision):
+    """Round 5: a call of <= 128 rows of the packed-GEMM chain (C = 768, the 85M shape) runs its N = 768 GEMMs in 128-row tiles (twice the
+    workgroups: 96 tiles of 256 rows leave most CUs idle).  A wave's 64 x 128 sub-tile and its k order do not change, so in the split mode the
+    small call reproduces the same rows of a large call BIT FOR BIT.  In the one-plane mode a large call runs the GEMMs on the 16 x 16 x 32
+    MFMA (gemm_pk16_kernel; a small call is not power-limited and keeps the 32 x 32 x 16 kernel): another summation order inside the MFMA,
+    so the two agree to the mode's own class -- and two LARGE calls of different sizes (160 rows in one launch, 200 rows through chunks of
+    160 + 40) agree bit for bit: the kernels are chosen per call, not per chunk."""
     from mapf_gpt_amd.model import build_model
-    rows = np.load(os.path.join(GOLDEN, "gptbig_2M_s1.npz"))["tokens"][:160]
+    rows = np.load(os.path.join(GOLDEN, "gptbig_2M_s1.npz"))["tokens"][:200]
     net = build_model("85M", seed=0, max_rows=160, precision=precision)
-    big = net.logits_tokens(torch.from_numpy(rows).cuda()).cpu().numpy()
+    big = net.logits_tokens(torch.from_numpy(np.ascontiguousarray(rows[:160])).cuda()).cpu().numpy()
     assert np.isfinite(big).all()
     for n_small in (1, 32, 128):
         small = net.logits_tokens(torch.from_numpy(np.ascontiguousarray(rows[:n_small])).cuda()).cpu().numpy()
-        assert np.array_equal(small, big[:n_small]), f"85M {precision}, {n_small} rows: {np.abs(small - big[:n_small]).max():.3e}"
+        d = np.abs(small - big[:n_small]).max()
+        if precision == "f16x3":
+            assert np.array_equal(small, big[:n_small]), f"85M f16x3, {n_small} rows: {d:.3e}"
+        else:
+            assert d <= 5e-2, f"85M bf16, {n_small} rows: small vs large call {d:.3e}"
+    chunked = net.logits_tokens(torch.from_numpy(rows).cuda()).cpu().numpy()          # 200 rows: chunks of 160 + 40, a LARGE call
+    assert np.array_equal(chunked[:160], big), "a row's logits depend on the large call it is in"
 
 
 @pytest.mark.parametrize("name,precision", [("2M", "f16x3"), ("6M", "f16x3"), ("6M", "bf16")])
