@@ -12,7 +12,7 @@
 #include "gpt_ctx.h"
 #include "gpt_kernels_fast.h"
 #include "gpt_kernels_c256.h"
-#include "gpt_kernels_c256p.h"
+#include "gpt_kernels_c256q.h"      // (includes gpt_kernels_c256p.h)
 #include "gpt_kernels_c256a.h"
 #include "gpt_kernels_c160p.h"
 #include "gpt_kernels_c160a.h"
@@ -98,6 +98,7 @@ struct ModeState {          // one precision mode
     // C = 256 (6M): mlp256p_kernel's cyclic weight stream in consumption order (LayerNorm gain folded into c_fc), per layer
     // [period step][pair][plane][lane][8], and the scale c_fc * gain was packed with
     std::vector<uint16_t *> mlp256_pk;
+    std::vector<uint16_t *> mlp256q_pk;         // the same stream in the fragment layout of mlp256q_kernel (16 x 16 x 32 MFMA: large calls)
     std::vector<float> mlp256_inv1;
     std::vector<float> attn256_inv;            // 1 / scale of the attn256 weight stream (c_attn.weight * ln_1.weight)
     float2 *gelu_lut = nullptr;                // the Phi table of the fused MLP kernels (kGeluLutN pairs)
@@ -216,10 +217,12 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
     if (C == 256 && m->mlp_fused) {
         const size_t n16 = (size_t)fastk::kMPPeriod * 16 * NP * 512;
         m->mlp256_pk.assign(g->L, nullptr);
+        m->mlp256q_pk.assign(g->L, nullptr);
         m->mlp256_inv1.assign(g->L, 1.f);
         m->mlp256_lut.assign(g->L, nullptr);
         for (int l = 0; l < g->L; l++) {
             MGPT_HIP(hipMalloc(&m->mlp256_pk[l], n16 * sizeof(uint16_t)));
+            MGPT_HIP(hipMalloc(&m->mlp256q_pk[l], n16 * sizeof(uint16_t)));
             const LayerOff &lo = g->layers[l];
             // the stream carries c_fc.weight * ln_2.weight (model.py:19-20, 86): its own power-of-two scale
             std::vector<float> wg(4 * C * C);
@@ -238,10 +241,16 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, g->params + lo.ln2, m->mlp256_pk[l], sc1,
                                1.0f / m->proj2[l].inv_scale);
             MGPT_LAUNCH_CHECK();
+            hipLaunchKernelGGL((fastk::pack_mlp256q_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)fastk::kMPPeriod * 16 * 64, 256)), dim3(256), 0,
+                               nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, g->params + lo.ln2, m->mlp256q_pk[l], sc1,
+                               1.0f / m->proj2[l].inv_scale);
+            MGPT_LAUNCH_CHECK();
         }
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256p_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      fastk::kMPLds<NP>));
         MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256p_kernel<T, NP, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     fastk::kMPLds<NP>));
+        MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp256q_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      fastk::kMPLds<NP>));
         m->attn256 = (g->hs == 32 && g->nh == 8);
         if (m->attn256) {
@@ -524,6 +533,7 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
     for (auto *p : m->mlp_pk) (void)hipFree(p);
     for (auto *p : m->mlp256_pk) (void)hipFree(p);
+    for (auto *p : m->mlp256q_pk) (void)hipFree(p);
     for (auto *p : m->mlp256_lut) (void)hipFree(p);
     for (auto *p : m->attn256_pk) (void)hipFree(p);
     for (auto *p : m->attn256o_pk) (void)hipFree(p);
@@ -575,6 +585,11 @@ int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
     return MGPT_OK;
 }
 
+#ifdef MGPT_AB_MLP_32X32
+constexpr bool kMlp256Q = false;        // A/B: the 6M MLP block of large calls on mlp256p_kernel (32 x 32 x 16 MFMA) as in rounds 3-4
+#else
+constexpr bool kMlp256Q = true;
+#endif
 #ifdef MGPT_AB_GEMM_32X32
 constexpr bool kGemmPk16 = false;       // A/B: the one-plane packed GEMM on the 32 x 32 x 16 MFMA as in rounds 1-4
 #else
@@ -900,9 +915,14 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                     // small launch: 64-token blocks, four waves with a SIMD each (mlp256p_kernel<.., NPAIR = 2>): twice the workgroups
                     hipLaunchKernelGGL((fastk::mlp256p_kernel<T, NP, 0, 2>), dim3((unsigned)std::min(2 * n_blocks, m->n_cu)), dim3(256), (size_t)fastk::kMPLds<NP>, s,
                                        mlp_x, m->mlp256_pk[l], m->mlp256_inv1[l], m->proj2[l].inv_scale, m->mlp256_lut[l], 2 * n_blocks, (unsigned long long *)nullptr);
-                else
+                else if (small256 || !kMlp256Q)
                 hipLaunchKernelGGL((fastk::mlp256p_kernel<T, NP>), dim3((unsigned)std::min(n_blocks, m->n_cu)), dim3(512), (size_t)fastk::kMPLds<NP>, s,
                                    mlp_x, m->mlp256_pk[l], m->mlp256_inv1[l], m->proj2[l].inv_scale, m->mlp256_lut[l], n_blocks, (unsigned long long *)nullptr);
+                else
+                    // large calls: the same block on v_mfma_f32_16x16x32 (gpt_kernels_c256q.h: 13-15 % more f16 flops per second at the power limit; 2.66 -> 2.45 ms
+                    // per 4096-row launch).  Small calls are not power-limited and keep the 32 x 32 x 16 kernel; the choice is a property of the call
+                    hipLaunchKernelGGL((fastk::mlp256q_kernel<T, NP>), dim3((unsigned)std::min(n_blocks, m->n_cu)), dim3(512), (size_t)fastk::kMPLds<NP>, s,
+                                       mlp_x, m->mlp256q_pk[l], m->mlp256_inv1[l], m->proj2[l].inv_scale, m->mlp256_lut[l], n_blocks, (unsigned long long *)nullptr);
                 if (!m->pk_gemm && l + 1 < g->L) {                       // this kernel leaves no LayerNorm statistics behind
                     MGPT_LAUNCH_CHECK();
                     if ((rc = launch_row_stats(g->x, m->stats, M, C, s)) != MGPT_OK) return rc;
