@@ -17,8 +17,8 @@ def table(path):
 
 
 KEYS = [  # (json key, kernel substring, grid, note)
-    ("cfg3_f16x3_gpt_mlp_fused", "mlp256p_kernel<mgpt::fastk::F16T, 2, 0, 4>", 131072,
-     "mlp256p_kernel (persistent, 256 workgroups x 512 threads): x rows read by the producer for LayerNorm and again by the consumer for the "
+    ("cfg3_f16x3_gpt_mlp_fused", "mlp256q_kernel<mgpt::fastk::F16T, 2, 0, 4>", 131072,
+     "mlp256q_kernel (mlp256p_kernel on the 16 x 16 x 32 MFMA; persistent, 256 workgroups x 512 threads): x rows read by the producer for LayerNorm and again by the consumer for the "
      "residual add (2 x 3.22 GB; the second read comes ~90 us after the first, inside the 256-MiB memory-side cache's reach, and is still "
      "counted: FETCH_SIZE tallies L2 <-> fabric requests), the 2.2 MB cyclic weight stream per 128-token block served by L2, one write of x"),
     ("cfg3_f16x3_gpt_attention", "attn256o_kernel<mgpt::fastk::F16T, 2, 0>", 131072,
