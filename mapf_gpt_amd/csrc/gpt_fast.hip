@@ -13,6 +13,7 @@
 #include "gpt_kernels_fast.h"
 #include "gpt_kernels_c256.h"
 #include "gpt_kernels_c256q.h"      // (includes gpt_kernels_c256p.h)
+#include "gpt_kernels_fused16.h"
 #include "gpt_kernels_c256a.h"
 #include "gpt_kernels_c160p.h"
 #include "gpt_kernels_c160a.h"
@@ -94,6 +95,7 @@ struct ModeState {          // one precision mode
     uint16_t *hbuf[2] = {nullptr, nullptr};    // [M][4C]
     // fused MLP (C = 64 / 160): per layer one packed stream [hidden tile][fragment][plane][lane][8]
     std::vector<uint16_t *> mlp_pk;
+    std::vector<uint16_t *> mlp16_pk;           // the same packets in the fragment layout of mlp_fused16_kernel (16 x 16 x 32 MFMA: large calls)
     bool mlp_fused = false;
     // C = 256 (6M): mlp256p_kernel's cyclic weight stream in consumption order (LayerNorm gain folded into c_fc), per layer
     // [period step][pair][plane][lane][8], and the scale c_fc * gain was packed with
@@ -294,19 +296,26 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
         const size_t frags = C / 16 + 2 * (C / 32), nt = 4 * C / 32;
         const size_t n16 = nt * frags * NP * 512;
         m->mlp_pk.assign(g->L, nullptr);
+        m->mlp16_pk.assign(g->L, nullptr);
         for (int l = 0; l < g->L; l++) {
             MGPT_HIP(hipMalloc(&m->mlp_pk[l], n16 * sizeof(uint16_t)));
+            MGPT_HIP(hipMalloc(&m->mlp16_pk[l], n16 * sizeof(uint16_t)));
             const LayerOff &lo = g->layers[l];
             ProfScope ps(P_PACK, nullptr);
             hipLaunchKernelGGL((fastk::pack_mlp_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)(nt * frags * 64), 256)), dim3(256), 0,
                                nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, m->mlp_pk[l], (int)C,
                                1.0f / m->fc[l].inv_scale, 1.0f / m->proj2[l].inv_scale);
             MGPT_LAUNCH_CHECK();
+            hipLaunchKernelGGL((fastk::pack_mlp16_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)(nt * frags * 64), 256)), dim3(256), 0,
+                               nullptr, g->params + lo.fc_w, g->params + lo.proj2_w, m->mlp16_pk[l], (int)C,
+                               1.0f / m->fc[l].inv_scale, 1.0f / m->proj2[l].inv_scale);
+            MGPT_LAUNCH_CHECK();
         }
         const int pkt = (int)(frags * NP * 1024 * 3) + fastk::kGeluLutN * 8;
 #define MGPT_MLP_ATTR(CT_, NW_) \
     MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, CT_, NW_, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt)); \
-    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, CT_, NW_, CT_>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt))
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused_kernel<T, NP, CT_, NW_, CT_>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt)); \
+    MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp_fused16_kernel<T, NP, CT_, NW_, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, pkt))
         if (C == 160) { MGPT_MLP_ATTR(5, 8); MGPT_MLP_ATTR(5, 4); MGPT_MLP_ATTR(5, 2); }
         else { MGPT_MLP_ATTR(2, 8); MGPT_MLP_ATTR(2, 4); MGPT_MLP_ATTR(2, 2); }
 #undef MGPT_MLP_ATTR
@@ -532,6 +541,7 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     auto fr = [](std::vector<PlaneSet> &v) { for (auto &p : v) { (void)hipFree(p.hi); (void)hipFree(p.lo); } v.clear(); };
     fr(m->attn); fr(m->proj); fr(m->fc); fr(m->proj2);
     for (auto *p : m->mlp_pk) (void)hipFree(p);
+    for (auto *p : m->mlp16_pk) (void)hipFree(p);
     for (auto *p : m->mlp256_pk) (void)hipFree(p);
     for (auto *p : m->mlp256q_pk) (void)hipFree(p);
     for (auto *p : m->mlp256_lut) (void)hipFree(p);
@@ -585,6 +595,11 @@ int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
     return MGPT_OK;
 }
 
+#ifdef MGPT_AB_MLPF_32X32
+constexpr bool kMlpFused16 = false;     // A/B: the fused MLP block of the C = 64 / 160 shapes on the 32 x 32 x 16 MFMA in large calls too
+#else
+constexpr bool kMlpFused16 = true;
+#endif
 #ifdef MGPT_AB_MLP_32X32
 constexpr bool kMlp256Q = false;        // A/B: the 6M MLP block of large calls on mlp256p_kernel (32 x 32 x 16 MFMA) as in rounds 3-4
 #else
@@ -953,7 +968,12 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     hipLaunchKernelGGL((fastk::mlp_fused_kernel<T, NP, CT_, NW_, NF_>), dim3((unsigned)(mlp_M / (32 * NW_))), dim3(64 * NW_), lds, s, mlp_x, \
                        P + lo.ln2, m->mlp_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M, m->gelu_lut, \
                        m->head_parts, part_stride)
-#define MGPT_MLP(CT_, NW_) do { if (fold_parts) MGPT_MLP_(CT_, NW_, CT_); else MGPT_MLP_(CT_, NW_, 0); } while (0)
+    // large calls: the same block on v_mfma_f32_16x16x32 (gpt_kernels_fused16.h); small calls (head_par) are not power-limited and keep the 32 x 32 x 16 kernel
+#define MGPT_MLP16_(CT_, NW_)                                                                                                        \
+    hipLaunchKernelGGL((fastk::mlp_fused16_kernel<T, NP, CT_, NW_, 0>), dim3((unsigned)(mlp_M / (32 * NW_))), dim3(64 * NW_), lds, s, mlp_x, \
+                       P + lo.ln2, m->mlp16_pk[l], m->fc[l].inv_scale, m->proj2[l].inv_scale, last_short ? nullptr : m->stats, (int)mlp_M, m->gelu_lut, \
+                       (const float *)nullptr, (int64_t)0)
+#define MGPT_MLP(CT_, NW_) do { if (fold_parts) MGPT_MLP_(CT_, NW_, CT_); else if (!head_par && kMlpFused16) MGPT_MLP16_(CT_, NW_); else MGPT_MLP_(CT_, NW_, 0); } while (0)
                 // (one wave per workgroup -- 256 workgroups for cfg1's 8192 tokens -- is slower: 63 us per launch against 52, round 4)
                 const int nw = (mlp_M >= (int64_t)256 * m->n_cu) ? 8 : (mlp_M >= (int64_t)128 * m->n_cu ? 4 : 2);
                 // (the heads' partial sums = n_head buffers, and n_head == C / 32 for the shapes of this path;
@@ -962,6 +982,7 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
                 if (C == 160) { if (nw == 8) MGPT_MLP(5, 8); else if (nw == 4) MGPT_MLP(5, 4); else MGPT_MLP(5, 2); }
                 else { if (nw == 8) MGPT_MLP(2, 8); else if (nw == 4) MGPT_MLP(2, 4); else MGPT_MLP(2, 2); }
 #undef MGPT_MLP
+#undef MGPT_MLP16_
 #undef MGPT_MLP_
             }
             MGPT_LAUNCH_CHECK();
