@@ -15,6 +15,7 @@
 #include "gpt_kernels_c256q.h"      // (includes gpt_kernels_c256p.h)
 #include "gpt_kernels_fused16.h"
 #include "gpt_kernels_c256a.h"
+#include "gpt_kernels_c256b.h"      // attn256q_kernel
 #include "gpt_kernels_c160p.h"
 #include "gpt_kernels_c160a.h"
 #include "gpt_kernels_last.h"
@@ -110,6 +111,7 @@ struct ModeState {          // one precision mode
     bool attn256 = false;
     // attn256o_kernel (whole attention block, persistent): c_attn + c_proj stream per layer, and the per-workgroup spill slab
     std::vector<uint16_t *> attn256o_pk;
+    std::vector<uint16_t *> attn256q_pk;   // the same stream in attn256q_kernel's fragment order (gpt_kernels_c256b.h)
     unsigned char *attn256o_spill = nullptr;
     // register-resident LN+QKV (C = 64 / 160): per layer [tile][k-step][plane][lane][8] of c_attn.weight
     std::vector<uint16_t *> qkv_pk;
@@ -275,6 +277,7 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
             {   // the whole attention block in one persistent kernel: 48 steps of c_attn * ln_1 followed by 16 steps of c_proj
                 const size_t n16o = (size_t)fastk::kA256oPeriod * 8 * NP * 512;
                 m->attn256o_pk.assign(g->L, nullptr);
+                m->attn256q_pk.assign(g->L, nullptr);
                 for (int l = 0; l < g->L; l++) {
                     MGPT_HIP(hipMalloc(&m->attn256o_pk[l], n16o * sizeof(uint16_t)));
                     const LayerOff &lo = g->layers[l];
@@ -283,7 +286,13 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                                        nullptr, g->params + lo.attn_w, g->params + lo.ln1, g->params + lo.proj_w, m->attn256o_pk[l],
                                        1.0f / m->attn256_inv[l], 1.0f / m->proj[l].inv_scale);
                     MGPT_LAUNCH_CHECK();
+                    MGPT_HIP(hipMalloc(&m->attn256q_pk[l], n16o * sizeof(uint16_t)));
+                    hipLaunchKernelGGL((fastk::pack_attn256q_kernel<T, NP>), dim3((unsigned)cdiv64((int64_t)fastk::kA256oPeriod * 8 * 64, 256)), dim3(256), 0,
+                                       nullptr, g->params + lo.attn_w, g->params + lo.ln1, g->params + lo.proj_w, m->attn256q_pk[l],
+                                       1.0f / m->attn256_inv[l], 1.0f / m->proj[l].inv_scale);
+                    MGPT_LAUNCH_CHECK();
                 }
+                MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256q_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
                 MGPT_HIP(hipMalloc(&m->attn256o_spill, (size_t)m->n_cu * 8 * 14 * NP * 1024));
                 MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256o_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
             }
@@ -547,6 +556,7 @@ void free_mode(mgpt_gpt *g, ModeState *m)
     for (auto *p : m->mlp256_lut) (void)hipFree(p);
     for (auto *p : m->attn256_pk) (void)hipFree(p);
     for (auto *p : m->attn256o_pk) (void)hipFree(p);
+    for (auto *p : m->attn256q_pk) (void)hipFree(p);
     (void)hipFree(m->attn256o_spill);
     (void)hipFree(m->gelu_lut);
     for (auto *p : m->qkv_pk) (void)hipFree(p);
@@ -599,6 +609,11 @@ int launch_gemm16(fastk::GemmArgs a, int C, hipStream_t s)
 constexpr bool kMlpFused16 = false;     // A/B: the fused MLP block of the C = 64 / 160 shapes on the 32 x 32 x 16 MFMA in large calls too
 #else
 constexpr bool kMlpFused16 = true;
+#endif
+#ifdef MGPT_AB_ATTN_32X32
+constexpr bool kAttn256Q = false;       // A/B: the 6M attention block's projections and tail on the 32 x 32 x 16 MFMA (attn256o_kernel) as in rounds 4-5
+#else
+constexpr bool kAttn256Q = true;
 #endif
 #ifdef MGPT_AB_MLP_32X32
 constexpr bool kMlp256Q = false;        // A/B: the 6M MLP block of large calls on mlp256p_kernel (32 x 32 x 16 MFMA) as in rounds 3-4
@@ -843,9 +858,15 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         } else if (m->attn256 && proj_fused) {
             // ---- the whole attention block (LN1, QKV, attention, out-projection, residual) in one persistent kernel: q, k, v, y stay on chip ----
             ProfScope ps(P_ATTN, s);
-            hipLaunchKernelGGL((fastk::attn256o_kernel<T, NP>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
-                               m->attn256o_pk[l], m->attn256_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn256o_spill, rows,
-                               (unsigned long long *)nullptr);
+            // (gpt_kernels_c256b.h: the projection steps and the tail on v_mfma_f32_16x16x32, the attention phase as it was)
+            if (kAttn256Q)
+                hipLaunchKernelGGL((fastk::attn256q_kernel<T, NP>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
+                                   m->attn256q_pk[l], m->attn256_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn256o_spill, rows,
+                                   (unsigned long long *)nullptr);
+            else
+                hipLaunchKernelGGL((fastk::attn256o_kernel<T, NP>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
+                                   m->attn256o_pk[l], m->attn256_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn256o_spill, rows,
+                                   (unsigned long long *)nullptr);
             MGPT_LAUNCH_CHECK();
         } else if (m->attn256) {
             // ---- LN1 + QKV + attention in one kernel (q, k, v stay on chip) -> y operand planes for the out-projection ----
