@@ -172,6 +172,27 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
         else if (decltype(next_c)::value) { lds_pair(nxt_addr, std::integral_constant<int, 0>{}, wb[0][0]); lds_pair(nxt_addr, std::integral_constant<int, 1>{}, wb[0][1]); }
         __builtin_amdgcn_sched_barrier(0);                 // the requests stay in front of this chunk's MFMAs
     };
+    // The same requests, one at a time: read N of chunk c's list (fragment 2c+2 plane 0 [, plane 1], fragment 2c+3 ...).  Default build: each rides behind one of the
+    // chunk's first MFMAs (the matrix pipe is busy for 16 cycles per MFMA, the LDS request issues in its shadow; -DMGPT_AB_ATTNQ_CLUMPED: all in front, as attn256o_kernel)
+#if defined(MGPT_AB_ATTNQ_CLUMPED)
+    constexpr bool PLACED = false;
+#else
+    constexpr bool PLACED = true;
+#endif
+    auto chunk_wait = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto chunk_read = [&](auto c_c, auto next_c, auto n_c) {
+        constexpr int c = decltype(c_c)::value, n = decltype(n_c)::value;
+        if constexpr (n < 2 * NP) {
+            constexpr int fr = n / NP, pl = n % NP;
+            if constexpr (c < 3) lds_frag(cur_addr, std::integral_constant<int, ((2 * c + 2 + fr) * NP + pl) * 1024>{}, wb[(c + 1) & 1][fr][pl]);
+            else if constexpr (decltype(next_c)::value) lds_frag(nxt_addr, std::integral_constant<int, (fr * NP + pl) * 1024>{}, wb[0][fr][pl]);
+            if constexpr (NP == 1 && (c < 3 || decltype(next_c)::value)) wb[(c + 1) & 1][fr][1] = wb[(c + 1) & 1][fr][0];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto pin6 = [&]() {
 #pragma unroll
         for (int n = 0; n < (NP == 2 ? 12 : 4); n++) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -201,16 +222,33 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
     using I3 = std::integral_constant<int, 3>;
     // fragments w0 (group 0), w1 (group 1) of one k-block against the two token groups x0, x1: slices 2 tg + group of blk.  SWAP: the token planes are the A operand
     // (rows = tokens: the v steps).  Small terms first, the four accumulator chains interleaved
-    auto mma4 = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&x0)[2], const u32x4 (&x1)[2], f32x16 &blk, auto swap_c) {
+    // behind(n): called after the chunk's MFMA n = 0 .. 3 (the placed LDS requests)
+    auto mma4 = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&x0)[2], const u32x4 (&x1)[2], f32x16 &blk, auto swap_c, auto &&behind) {
         constexpr bool SW = decltype(swap_c)::value;
         auto one = [&](const u32x4 &w, const u32x4 &xx, auto s_c) {
             if constexpr (SW) mm16(xx, w, blk, s_c); else mm16(w, xx, blk, s_c);
         };
         if (NP == 2) {
-            one(w0[1], x0[0], I0{}); one(w1[1], x0[0], I1{}); one(w0[1], x1[0], I2{}); one(w1[1], x1[0], I3{});
+            one(w0[1], x0[0], I0{}); behind(I0{}); one(w1[1], x0[0], I1{}); behind(I1{}); one(w0[1], x1[0], I2{}); behind(I2{}); one(w1[1], x1[0], I3{}); behind(I3{});
             one(w0[0], x0[1], I0{}); one(w1[0], x0[1], I1{}); one(w0[0], x1[1], I2{}); one(w1[0], x1[1], I3{});
+            one(w0[0], x0[0], I0{}); one(w1[0], x0[0], I1{}); one(w0[0], x1[0], I2{}); one(w1[0], x1[0], I3{});
+        } else {
+            one(w0[0], x0[0], I0{}); behind(I0{}); one(w1[0], x0[0], I1{}); behind(I1{}); one(w0[0], x1[0], I2{}); one(w1[0], x1[0], I3{});
         }
-        one(w0[0], x0[0], I0{}); one(w1[0], x0[0], I1{}); one(w0[0], x1[0], I2{}); one(w1[0], x1[0], I3{});
+    };
+    // the MFMAs of a chunk with its requests: `mm` runs mma4 with the hook it is given
+    auto chunk_body = [&](auto c_c, auto next_c, auto &&mm) {
+        if constexpr (PLACED) {
+            chunk_wait();
+            mm([&](auto n_c) { __builtin_amdgcn_sched_barrier(0); chunk_read(c_c, next_c, n_c); });
+#pragma unroll
+            for (int n = 0; n < (NP == 2 ? 8 : 2); n++) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            chunk_begin(c_c, next_c);
+            mm([&](auto) {});
+            pin6();
+        }
     };
     // a token's 256 features sit in the four lanes t + 16 q: v_permlane16_swap folds rows 0|1 and 2|3 of 16 lanes, v_permlane32_swap the halves
     auto fold4 = [&](float v) {
@@ -260,11 +298,11 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
         sphase(2);
         auto chunk = [&](auto c_c) {
             constexpr int c = decltype(c_c)::value;
-            chunk_begin(c_c, next_c);
             constexpr int cc = 4 * j + c, kb = cc >> 1;    // even chunks -> qa, odd chunks -> ka
-            if constexpr ((cc & 1) == 0) mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], qa, std::false_type{});
-            else mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], ka, std::false_type{});
-            pin6();
+            chunk_body(c_c, next_c, [&](auto &&behind) {
+                if constexpr ((cc & 1) == 0) mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], qa, std::false_type{}, behind);
+                else mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], ka, std::false_type{}, behind);
+            });
             asm volatile("" : "+v"(qa), "+v"(ka));         // both chains are pinned to this chunk (hipcc otherwise sinks a whole chain -- and
                                                            // the weight fragments it needs -- to the chain's first use, see above)
         };
@@ -392,10 +430,8 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
                 sphase(3);
                 auto chunk = [&](auto c_c) {
                     constexpr int c = decltype(c_c)::value;
-                    chunk_begin(c_c, next_c);
                     constexpr int kb = 4 * j + c;
-                    mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], va, std::true_type{});
-                    pin6();
+                    chunk_body(c_c, next_c, [&](auto &&behind) { mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], va, std::true_type{}, behind); });
                     asm volatile("" : "+v"(va));
                 };
                 chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});

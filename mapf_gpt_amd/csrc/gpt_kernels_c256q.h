@@ -199,6 +199,28 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256q_kernel(float *__restri
         else if (next_step_has_work) { lds_pair(nxt_addr, std::integral_constant<int, MB>{}, wb[0][0]); if (!(kMQAbl & 1)) lds_pair(nxt_addr, std::integral_constant<int, MB + 1>{}, wb[0][1]); }
         __builtin_amdgcn_sched_barrier(0);
     };
+    // the same requests one at a time (the consumer's placed chunks: each behind one of the chunk's first MFMAs, the matrix pipe being busy for 16 cycles per MFMA --
+    // measured on attn256q_kernel, gpt_kernels_c256b.h; -DMGPT_AB_MLPQ_CLUMPED: all in front as in the producer)
+#if defined(MGPT_AB_MLPQ_CLUMPED)
+    constexpr bool PLACED = false;
+#else
+    constexpr bool PLACED = (kMQAbl == 0);
+#endif
+    auto chunk_read = [&](auto mb_c, auto c_c, bool next_step_has_work, auto n_c) {
+        constexpr int MB = decltype(mb_c)::value, c = decltype(c_c)::value, n = decltype(n_c)::value;
+        if constexpr (n < 2 * NP) {
+            constexpr int fr = n / NP, pl = n % NP;
+            if (c < 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wb[(c + 1) & 1][fr][pl]) : "v"(cur_addr), "n"(((MB + 2 * c + 2 + fr) * NP + pl) * 1024) : "memory");
+            else if (next_step_has_work) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wb[0][fr][pl]) : "v"(nxt_addr), "n"(((MB + fr) * NP + pl) * 1024) : "memory");
+            if (NP == 1) wb[(c + 1) & 1][fr][1] = wb[(c + 1) & 1][fr][0];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto pin_rest = [&](auto n_c) {                         // the chunk's MFMAs behind the placed ones
+#pragma unroll
+        for (int n = 0; n < decltype(n_c)::value; n++) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto pin = [&](auto n_valu_c) {
         constexpr int n_valu = decltype(n_valu_c)::value;
 #pragma unroll
@@ -415,15 +437,37 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256q_kernel(float *__restri
 #pragma unroll
             for (int b = 0; b < 2; b++) { hf[a][b] = (u32x4){0u, 0u, 0u, 0u}; wb[0][a][b] = (u32x4){0u, 0u, 0u, 0u}; }   // (the very first chunk runs on these)
         // half a chunk: the feature groups w0 (even fg), w1 (odd fg) of the chunk against the hidden planes of ONE token group; slices 2 (fg % 2) + tg of blk
-        auto pj_half = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&hb)[2], f32x16 &blk, auto tg_c) {
+        auto pj_half_b = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&hb)[2], f32x16 &blk, auto tg_c, auto &&behind) {
             constexpr int tg = decltype(tg_c)::value;
             using S0 = std::integral_constant<int, tg>;
             using S1 = std::integral_constant<int, 2 + tg>;
             if (NP == 2) {
-                mm16(w0[1], hb[0], blk, S0{}); mm16(w1[1], hb[0], blk, S1{});
-                mm16(w0[0], hb[1], blk, S0{}); mm16(w1[0], hb[1], blk, S1{});
+                mm16(w0[1], hb[0], blk, S0{}); behind(I0{}); mm16(w1[1], hb[0], blk, S1{}); behind(I1{});
+                mm16(w0[0], hb[1], blk, S0{}); behind(I2{}); mm16(w1[0], hb[1], blk, S1{}); behind(I3{});
+                mm16(w0[0], hb[0], blk, S0{}); mm16(w1[0], hb[0], blk, S1{});
+            } else {
+                mm16(w0[0], hb[0], blk, S0{}); behind(I0{}); mm16(w1[0], hb[0], blk, S1{}); behind(I1{});
             }
-            mm16(w0[0], hb[0], blk, S0{}); mm16(w1[0], hb[0], blk, S1{});
+        };
+        auto pj_half = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&hb)[2], f32x16 &blk, auto tg_c) {
+            pj_half_b(w0, w1, hb, blk, tg_c, [&](auto) {});
+        };
+        // a whole chunk (both token groups) with its requests placed behind the first MFMAs
+        auto pj_chunk = [&](auto c_c, bool next_has_work, const u32x4 (&w0)[2], const u32x4 (&w1)[2], f32x16 &blk, auto &&between) {
+            if constexpr (PLACED) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                pj_half_b(w0, w1, hf[0], blk, I0{}, [&](auto n_c) { __builtin_amdgcn_sched_barrier(0); chunk_read(MB{}, c_c, next_has_work, n_c); });
+                between();
+                pj_half(w0, w1, hf[1], blk, I1{});
+                pin_rest(std::integral_constant<int, (NP == 2 ? 8 : 2)>{});
+            } else {
+                chunk_begin(MB{}, c_c, next_has_work);
+                pj_half(w0, w1, hf[0], blk, I0{});
+                between();
+                pj_half(w0, w1, hf[1], blk, I1{});
+                pin(E0{});
+            }
         };
         // hidden planes of token group kk (slot kk of the hand-off) of the tile with parity par
         auto load_hidden = [&](auto kk_c, int par) {
@@ -448,21 +492,11 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256q_kernel(float *__restri
             pj_half(wb[0][0], wb[0][kS1], hf[1], acc[4 * kk], I1{});
             pin(E0{});
             mark(2);
-            chunk_begin(MB{}, I1{}, true);
-            pj_half(wb[1][0], wb[1][kS1], hf[0], acc[4 * kk + 1], I0{});
-            pj_half(wb[1][0], wb[1][kS1], hf[1], acc[4 * kk + 1], I1{});
-            pin(E0{});
+            pj_chunk(I1{}, true, wb[1][0], wb[1][kS1], acc[4 * kk + 1], [&]() {});
             mark(3);
-            chunk_begin(MB{}, I2{}, true);
-            pj_half(wb[0][0], wb[0][kS1], hf[0], acc[4 * kk + 2], I0{});
-            pj_half(wb[0][0], wb[0][kS1], hf[1], acc[4 * kk + 2], I1{});
-            pin(E0{});
+            pj_chunk(I2{}, true, wb[0][0], wb[0][kS1], acc[4 * kk + 2], [&]() {});
             mark(4);
-            chunk_begin(MB{}, I3{}, next_step_has_pj);
-            pj_half(wb[1][0], wb[1][kS1], hf[0], acc[4 * kk + 3], I0{});
-            if (kk == 1 && prefetch_next_tile) load_hidden(I0{}, par ^ 1);
-            pj_half(wb[1][0], wb[1][kS1], hf[1], acc[4 * kk + 3], I1{});
-            pin(E0{});
+            pj_chunk(I3{}, next_step_has_pj, wb[1][0], wb[1][kS1], acc[4 * kk + 3], [&]() { if (kk == 1 && prefetch_next_tile) load_hidden(I0{}, par ^ 1); });
         };
 
         // steps 0 .. 7 of a period for the consumer: the block blk_prev is finished (c_proj of its tiles 30, 31, then the

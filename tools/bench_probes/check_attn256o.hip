@@ -7,7 +7,11 @@
 #include <math.h>
 #include <algorithm>
 #include <vector>
-#include "../../mapf_gpt_amd/csrc/gpt_kernels_c256a.h"
+#include "../../mapf_gpt_amd/csrc/gpt_kernels_c256b.h"
+#ifdef MGPT_CHECK_Q                                      // -DMGPT_CHECK_Q: the same probe on attn256q_kernel (gpt_kernels_c256b.h)
+#define attn256o_kernel attn256q_kernel
+#define pack_attn256o_kernel pack_attn256q_kernel
+#endif
 namespace mgpt { void set_error(const char *, ...) {} }
 using namespace mgpt::fastk;
 static float gauss(uint64_t &st)
