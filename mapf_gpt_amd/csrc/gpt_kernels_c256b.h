@@ -142,8 +142,13 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
         __builtin_amdgcn_s_barrier();
     };
     // part 2: the slot of step G - 1 is refilled with step G + 4; addresses of this step's and the next step's slots
+    int slot_refill = 0;                                   // (-DMGPT_AB_ATTNQ_DMA_PLACED: the refill is issued from inside the step's first chunk)
     auto sync_issue = [&]() {
+#if defined(MGPT_AB_ATTNQ_DMA_PLACED) && !defined(MGPT_AB_ATTNQ_CLUMPED)
+        slot_refill = slot_prev;
+#else
         issue(slot_prev);
+#endif
         const int slot_next = slot_cur + 1 == NSLOT ? 0 : slot_cur + 1;
         cur_addr = lds0 + (unsigned)slot_cur * STEP;
         nxt_addr = lds0 + (unsigned)slot_next * STEP;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
     using I3 = std::integral_constant<int, 3>;
     // fragments w0 (group 0), w1 (group 1) of one k-block against the two token groups x0, x1: slices 2 tg + group of blk.  SWAP: the token planes are the A operand
     // (rows = tokens: the v steps).  Small terms first, the four accumulator chains interleaved
-    // behind(n): called after the chunk's MFMA n = 0 .. 3 (the placed LDS requests)
+    // behind(n): called after the chunk's MFMA n = 0 .. 5 (the placed LDS requests and, in a step's first chunk, the ring refill)
     auto mma4 = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&x0)[2], const u32x4 (&x1)[2], f32x16 &blk, auto swap_c, auto &&behind) {
         constexpr bool SW = decltype(swap_c)::value;
         auto one = [&](const u32x4 &w, const u32x4 &xx, auto s_c) {
@@ -230,19 +235,32 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
         };
         if (NP == 2) {
             one(w0[1], x0[0], I0{}); behind(I0{}); one(w1[1], x0[0], I1{}); behind(I1{}); one(w0[1], x1[0], I2{}); behind(I2{}); one(w1[1], x1[0], I3{}); behind(I3{});
-            one(w0[0], x0[1], I0{}); one(w1[0], x0[1], I1{}); one(w0[0], x1[1], I2{}); one(w1[0], x1[1], I3{});
+            one(w0[0], x0[1], I0{}); behind(std::integral_constant<int, 4>{}); one(w1[0], x0[1], I1{}); behind(std::integral_constant<int, 5>{});
+            one(w0[0], x1[1], I2{}); one(w1[0], x1[1], I3{});
             one(w0[0], x0[0], I0{}); one(w1[0], x0[0], I1{}); one(w0[0], x1[0], I2{}); one(w1[0], x1[0], I3{});
         } else {
-            one(w0[0], x0[0], I0{}); behind(I0{}); one(w1[0], x0[0], I1{}); behind(I1{}); one(w0[0], x1[0], I2{}); one(w1[0], x1[0], I3{});
+            one(w0[0], x0[0], I0{}); behind(I0{}); one(w1[0], x0[0], I1{}); behind(I1{}); one(w0[0], x1[0], I2{}); behind(I2{}); one(w1[0], x1[0], I3{});
         }
     };
     // the MFMAs of a chunk with its requests: `mm` runs mma4 with the hook it is given
     auto chunk_body = [&](auto c_c, auto next_c, auto &&mm) {
         if constexpr (PLACED) {
             chunk_wait();
-            mm([&](auto n_c) { __builtin_amdgcn_sched_barrier(0); chunk_read(c_c, next_c, n_c); });
+            // -DMGPT_AB_ATTNQ_DMA_PLACED: a step's first chunk also issues the ring refill (PW direct-to-LDS pieces) two MFMAs behind the last read instead of at the
+            // step's top.  Built and measured (profiles/r05_ab.txt, visit N): SLOWER, attention 48.0 -> 48.2 ms per cfg3 step -- the refill stays at the top
+#if defined(MGPT_AB_ATTNQ_DMA_PLACED)
+            constexpr bool REFILL = decltype(c_c)::value == 0;
+#else
+            constexpr bool REFILL = false;
+#endif
+            constexpr int N_REFILL = NP == 2 ? 5 : 2, N_LAST = REFILL ? N_REFILL : 2 * NP - 1, NMF = NP == 2 ? 12 : 4;
+            mm([&](auto n_c) {
+                constexpr int n = decltype(n_c)::value;
+                if constexpr (n < 2 * NP) { __builtin_amdgcn_sched_barrier(0); chunk_read(c_c, next_c, n_c); }
+                else if constexpr (REFILL && n == N_REFILL) { __builtin_amdgcn_sched_barrier(0); issue(slot_refill); __builtin_amdgcn_sched_barrier(0); }
+            });
 #pragma unroll
-            for (int n = 0; n < (NP == 2 ? 8 : 2); n++) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            for (int n = 0; n < NMF - 1 - N_LAST; n++) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
         } else {
             chunk_begin(c_c, next_c);

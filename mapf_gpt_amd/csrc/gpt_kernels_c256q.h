@@ -453,9 +453,12 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256q_kernel(float *__restri
             pj_half_b(w0, w1, hb, blk, tg_c, [&](auto) {});
         };
         // a whole chunk (both token groups) with its requests placed behind the first MFMAs
-        auto pj_chunk = [&](auto c_c, bool next_has_work, const u32x4 (&w0)[2], const u32x4 (&w1)[2], f32x16 &blk, auto &&between) {
+        // (pre: requests in front of the chunk's MFMAs; between: between its two halves -- 2 NP fragment reads are younger than anything `pre` requested)
+        auto pj_chunk = [&](auto c_c, bool next_has_work, const u32x4 (&w0)[2], const u32x4 (&w1)[2], f32x16 &blk, auto &&pre, auto &&between) {
             if constexpr (PLACED) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                pre();
                 __builtin_amdgcn_sched_barrier(0);
                 pj_half_b(w0, w1, hf[0], blk, I0{}, [&](auto n_c) { __builtin_amdgcn_sched_barrier(0); chunk_read(MB{}, c_c, next_has_work, n_c); });
                 between();
@@ -463,6 +466,7 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256q_kernel(float *__restri
                 pin_rest(std::integral_constant<int, (NP == 2 ? 8 : 2)>{});
             } else {
                 chunk_begin(MB{}, c_c, next_has_work);
+                pre();
                 pj_half(w0, w1, hf[0], blk, I0{});
                 between();
                 pj_half(w0, w1, hf[1], blk, I1{});
@@ -485,18 +489,19 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256q_kernel(float *__restri
             constexpr int kk = decltype(kk_c)::value;
             sync(pending_c);
             mark(1);
-            chunk_begin(MB{}, I0{}, true);
-            if (kk == 0) load_hidden(I1{}, par);
-            pj_half(wb[0][0], wb[0][kS1], hf[0], acc[4 * kk], I0{});
-            if (kk == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hf[1][0]), "+v"(hf[1][1]) : : "memory");
-            pj_half(wb[0][0], wb[0][kS1], hf[1], acc[4 * kk], I1{});
-            pin(E0{});
+            auto none = [&]() {};
+            // (LDS requests return in issue order: the second slot's planes are older than the chunk's placed fragment reads)
+            pj_chunk(I0{}, true, wb[0][0], wb[0][kS1], acc[4 * kk], [&]() { if (kk == 0) load_hidden(I1{}, par); },
+                     [&]() {
+                         u32x4 (&h1)[2] = hf[1];           // (names used only inside asm operands of a generic lambda are not captured)
+                         if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(h1[0]), "+v"(h1[1]) : [n] "n"(PLACED ? 2 * NP : 0) : "memory");
+                     });
             mark(2);
-            pj_chunk(I1{}, true, wb[1][0], wb[1][kS1], acc[4 * kk + 1], [&]() {});
+            pj_chunk(I1{}, true, wb[1][0], wb[1][kS1], acc[4 * kk + 1], none, none);
             mark(3);
-            pj_chunk(I2{}, true, wb[0][0], wb[0][kS1], acc[4 * kk + 2], [&]() {});
+            pj_chunk(I2{}, true, wb[0][0], wb[0][kS1], acc[4 * kk + 2], none, none);
             mark(4);
-            pj_chunk(I3{}, next_step_has_pj, wb[1][0], wb[1][kS1], acc[4 * kk + 3], [&]() { if (kk == 1 && prefetch_next_tile) load_hidden(I0{}, par ^ 1); });
+            pj_chunk(I3{}, next_step_has_pj, wb[1][0], wb[1][kS1], acc[4 * kk + 3], none, [&]() { if (kk == 1 && prefetch_next_tile) load_hidden(I0{}, par ^ 1); });
         };
 
         // steps 0 .. 7 of a period for the consumer: the block blk_prev is finished (c_proj of its tiles 30, 31, then the
