@@ -218,6 +218,13 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
         c = T::mfma16(a, b2, c);
         blk[4 * S] = c[0]; blk[4 * S + 1] = c[1]; blk[4 * S + 2] = c[2]; blk[4 * S + 3] = c[3];
     };
+    // the first term of a slice: C = 0 as the MFMA's inline constant (zeroing a slice by assignment costs four v_mov, see gpt_kernels_c256q.h)
+    auto mm16z = [&](const u32x4 &a, const u32x4 &b2, f32x16 &blk, auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = T::mfma16(a, b2, c);
+        blk[4 * S] = c[0]; blk[4 * S + 1] = c[1]; blk[4 * S + 2] = c[2]; blk[4 * S + 3] = c[3];
+    };
     // (LDS writes and global accesses below are written out with immediate offsets: no per-offset address registers.
     //  Global accesses use the saddr form: vdata, voffset (32-bit lane offset), saddr (uniform base), immediate.
     //  s_nop after a store: a store of more than 8 bytes reads its data registers after issue, and hipcc cannot see through asm.)
@@ -228,18 +235,24 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
     // fragments w0 (group 0), w1 (group 1) of one k-block against the two token groups x0, x1: slices 2 tg + group of blk.  SWAP: the token planes are the A operand
     // (rows = tokens: the v steps).  Small terms first, the four accumulator chains interleaved
     // behind(n): called after the chunk's MFMA n = 0 .. 5 (the placed LDS requests and, in a step's first chunk, the ring refill)
-    auto mma4 = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&x0)[2], const u32x4 (&x1)[2], f32x16 &blk, auto swap_c, auto &&behind) {
-        constexpr bool SW = decltype(swap_c)::value;
+    // FIRST: the block's first chunk -- its slices start from zero
+    auto mma4 = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&x0)[2], const u32x4 (&x1)[2], f32x16 &blk, auto swap_c, auto first_c, auto &&behind) {
+        constexpr bool SW = decltype(swap_c)::value, FIRST = decltype(first_c)::value;
         auto one = [&](const u32x4 &w, const u32x4 &xx, auto s_c) {
             if constexpr (SW) mm16(xx, w, blk, s_c); else mm16(w, xx, blk, s_c);
         };
+        auto onez = [&](const u32x4 &w, const u32x4 &xx, auto s_c) {
+            if constexpr (!FIRST) one(w, xx, s_c);
+            else if constexpr (SW) mm16z(xx, w, blk, s_c);
+            else mm16z(w, xx, blk, s_c);
+        };
         if (NP == 2) {
-            one(w0[1], x0[0], I0{}); behind(I0{}); one(w1[1], x0[0], I1{}); behind(I1{}); one(w0[1], x1[0], I2{}); behind(I2{}); one(w1[1], x1[0], I3{}); behind(I3{});
+            onez(w0[1], x0[0], I0{}); behind(I0{}); onez(w1[1], x0[0], I1{}); behind(I1{}); onez(w0[1], x1[0], I2{}); behind(I2{}); onez(w1[1], x1[0], I3{}); behind(I3{});
             one(w0[0], x0[1], I0{}); behind(std::integral_constant<int, 4>{}); one(w1[0], x0[1], I1{}); behind(std::integral_constant<int, 5>{});
             one(w0[0], x1[1], I2{}); one(w1[0], x1[1], I3{});
             one(w0[0], x0[0], I0{}); one(w1[0], x0[0], I1{}); one(w0[0], x1[0], I2{}); one(w1[0], x1[0], I3{});
         } else {
-            one(w0[0], x0[0], I0{}); behind(I0{}); one(w1[0], x0[0], I1{}); behind(I1{}); one(w0[0], x1[0], I2{}); behind(I2{}); one(w1[0], x1[0], I3{});
+            onez(w0[0], x0[0], I0{}); behind(I0{}); onez(w1[0], x0[0], I1{}); behind(I1{}); onez(w0[0], x1[0], I2{}); behind(I2{}); onez(w1[0], x1[0], I3{});
         }
     };
     // the MFMAs of a chunk with its requests: `mm` runs mma4 with the hook it is given
@@ -318,8 +331,9 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
             constexpr int c = decltype(c_c)::value;
             constexpr int cc = 4 * j + c, kb = cc >> 1;    // even chunks -> qa, odd chunks -> ka
             chunk_body(c_c, next_c, [&](auto &&behind) {
-                if constexpr ((cc & 1) == 0) mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], qa, std::false_type{}, behind);
-                else mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], ka, std::false_type{}, behind);
+                using F = std::integral_constant<bool, (cc < 2)>;      // chunks 0, 1 of a head's (pseudo-head's) first step start qa, ka from zero
+                if constexpr ((cc & 1) == 0) mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], qa, std::false_type{}, F{}, behind);
+                else mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], ka, std::false_type{}, F{}, behind);
             });
             asm volatile("" : "+v"(qa), "+v"(ka));         // both chains are pinned to this chunk (hipcc otherwise sinks a whole chain -- and
                                                            // the weight fragments it needs -- to the chain's first use, see above)
@@ -405,8 +419,7 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
             const unsigned kw_addr = sK + ((unsigned)tok0 + tt) * KROW + qq * 16;                // write side: key tok0 + 16 tg + t, dims 8 q .. 8 q + 7
             const unsigned vw_addr = sV + tt * VROW + (unsigned)wave * 64 + (qq & 1u) * 16 + (qq >> 1) * 8;   // d = 16 dg + t, this wave's keys 16 tg + 4 q .. + 3 at their slots
             // ---- steps 0-3: q and k quads (lane = token 16 tg + t, registers 4 (2 tg + ug) + i = dim 8 blk + 4 ug + i) ----
-#pragma unroll
-            for (int g = 0; g < 16; g++) { qa[g] = 0.f; ka[g] = 0.f; }
+            asm volatile("" : "=v"(qa), "=v"(ka));         // (no instruction: the old values end here -- not zeroed by assignment any more, they would stay live across the prologue)
             // (steps 0-2: the spill stores of the head before are younger than the pieces waited for; for head 0 nothing is in
             //  flight at all after the prologue's vmcnt(0), so the larger count is safe there too)
             step_pair(I0{}, P4S{}, nothing, std::true_type{});
@@ -437,9 +450,7 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
                         asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(kw_addr), "v"(kp[tg][pl]), "n"(pl * kT * KROW + tg * 16 * KROW) : "memory");
             }
             // ---- steps 4-5: v quads (natural: lane = d = 16 dg + t, registers 4 (2 tg + dg) + i = token 16 tg + 4 q + i) ----
-            f32x16 va;
-#pragma unroll
-            for (int g = 0; g < 16; g++) va[g] = 0.f;
+            f32x16 va;                                     // (started from zero by the first chunk)
             auto step_v = [&](auto j_c, auto next_c) {
                 constexpr int j = decltype(j_c)::value;
                 smark();
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
                 auto chunk = [&](auto c_c) {
                     constexpr int c = decltype(c_c)::value;
                     constexpr int kb = 4 * j + c;
-                    chunk_body(c_c, next_c, [&](auto &&behind) { mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], va, std::true_type{}, behind); });
+                    chunk_body(c_c, next_c, [&](auto &&behind) { mma4(wb[c & 1][0], wb[c & 1][1], xn[kb], xn[8 + kb], va, std::true_type{}, std::integral_constant<bool, kb == 0>{}, behind); });
                     asm volatile("" : "+v"(va));
                 };
                 chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{});
@@ -539,12 +550,9 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
         //  the row fetched twice (+3.2 GB per launch), and the kernel is 2 % SLOWER with the touches: 57.7 vs 56.5 ms per cfg3 step.)
         auto tail = [&](int t, auto first_c, auto last_c) {
             constexpr bool FIRST = decltype(first_c)::value, LASTT = decltype(last_c)::value;
-            // (the zero comes out of an opaque asm: as a plain constant hipcc builds a 16-register zero block for the pseudo-head loop BEFORE the first pseudo-head and keeps
-            //  it there -- with it the allocator spilled residual quads that are still in flight)
-            float zero;
-            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-#pragma unroll
-            for (int g = 0; g < 16; g++) { qa[g] = zero; ka[g] = zero; }
+            asm volatile("" : "=v"(qa), "=v"(ka));
+            // (qa, ka are started from zero by the first step's first chunks.  Zeroed by assignment, hipcc built a 16-register zero block for the pseudo-head loop BEFORE the
+            //  first pseudo-head and kept it there -- with it the allocator spilled residual quads that were still in flight)
             unsigned l16t = lane16;
             asm volatile("" : "+v"(l16t));
             const unsigned xoff_t = (l16t >> 9) * 1024 + ((l16t >> 4) & 15u) * 32 + ((l16t >> 8) & 1u) * 16;

@@ -238,6 +238,14 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256q_kernel(float *__restri
         c = T::mfma16(a, b, c);
         blk[4 * S] = c[0]; blk[4 * S + 1] = c[1]; blk[4 * S + 2] = c[2]; blk[4 * S + 3] = c[3];
     };
+    // the first term of a slice: C = 0 as the MFMA's inline constant (a slice zeroed by assignment costs four v_mov per slice: 16 x 16 x 32 has no 16-register
+    // destination to start from zero at once, and hipcc does not fold the assignments into the first MFMA of the slice)
+    auto mm16z = [&](const u32x4 &a, const u32x4 &b, f32x16 &blk, auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = T::mfma16(a, b, c);
+        blk[4 * S] = c[0]; blk[4 * S + 1] = c[1]; blk[4 * S + 2] = c[2]; blk[4 * S + 3] = c[3];
+    };
 
     if (producer) {
         // =============================================== producer ===============================================
@@ -250,12 +258,18 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256q_kernel(float *__restri
         unsigned hw[2][4];                                 // hidden words of one k-step: [plane][word]
         // chunk: unit groups w0 (ug = 0), w1 (ug = 1) of one k-block against the two token groups x0, x1; slice 2 tg + ug.  Small terms first, the four
         // accumulator chains interleaved
-        auto fc_mma = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&x0)[2], const u32x4 (&x1)[2], f32x16 &hd) {
+        // FIRST: the tile's first chunk -- the slices start from zero
+        auto fc_mma = [&](const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&x0)[2], const u32x4 (&x1)[2], f32x16 &hd, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            auto head4 = [&](const u32x4 &a0, const u32x4 &a1, const u32x4 &b0, const u32x4 &b1) {
+                if constexpr (FIRST) { mm16z(a0, b0, hd, I0{}); mm16z(a1, b0, hd, I1{}); mm16z(a0, b1, hd, I2{}); mm16z(a1, b1, hd, I3{}); }
+                else { mm16(a0, b0, hd, I0{}); mm16(a1, b0, hd, I1{}); mm16(a0, b1, hd, I2{}); mm16(a1, b1, hd, I3{}); }
+            };
             if (NP == 2) {
-                mm16(w0[1], x0[0], hd, I0{}); mm16(w1[1], x0[0], hd, I1{}); mm16(w0[1], x1[0], hd, I2{}); mm16(w1[1], x1[0], hd, I3{});
+                head4(w0[1], w1[1], x0[0], x1[0]);
                 mm16(w0[0], x0[1], hd, I0{}); mm16(w1[0], x0[1], hd, I1{}); mm16(w0[0], x1[1], hd, I2{}); mm16(w1[0], x1[1], hd, I3{});
-            }
-            mm16(w0[0], x0[0], hd, I0{}); mm16(w1[0], x0[0], hd, I1{}); mm16(w0[0], x1[0], hd, I2{}); mm16(w1[0], x1[0], hd, I3{});
+                mm16(w0[0], x0[0], hd, I0{}); mm16(w1[0], x0[0], hd, I1{}); mm16(w0[0], x1[0], hd, I2{}); mm16(w1[0], x1[0], hd, I3{});
+            } else head4(w0[0], w1[0], x0[0], x1[0]);
         };
         // GELU of pre-activations 4q .. 4q+3 of hsrc (hidden units tau(4q + e, h)): part 0 forms the table addresses and issues
         // the gathers, part 1 (after the next lgkmcnt(0)) interpolates, multiplies, splits; after q = 1 and q = 3 the finished
@@ -305,28 +319,26 @@ __global__ __launch_bounds__(NPAIR * 128, 2) void mlp256q_kernel(float *__restri
             mark(1);
             chunk_begin(MB{}, I0{}, true);
             if (with_gelu) gelu0(std::integral_constant<int, 2 * half>{}, hsrc);
-            fc_mma(wb[0][0], wb[0][kS1], xn[4 * half], xn[8 + 4 * half], hdst);
+            fc_mma(wb[0][0], wb[0][kS1], xn[4 * half], xn[8 + 4 * half], hdst, std::integral_constant<bool, half == 0>{});
             pin(VN{});
             mark(2);
             chunk_begin(MB{}, I1{}, true);
             if (with_gelu) gelu1(std::integral_constant<int, 2 * half>{}, par);
-            fc_mma(wb[1][0], wb[1][kS1], xn[4 * half + 1], xn[8 + 4 * half + 1], hdst);
+            fc_mma(wb[1][0], wb[1][kS1], xn[4 * half + 1], xn[8 + 4 * half + 1], hdst, std::false_type{});
             pin(VN{});
             mark(3);
             chunk_begin(MB{}, I2{}, true);
             if (with_gelu) gelu0(std::integral_constant<int, 2 * half + 1>{}, hsrc);
-            fc_mma(wb[0][0], wb[0][kS1], xn[4 * half + 2], xn[8 + 4 * half + 2], hdst);
+            fc_mma(wb[0][0], wb[0][kS1], xn[4 * half + 2], xn[8 + 4 * half + 2], hdst, std::false_type{});
             pin(VN{});
             mark(4);
             chunk_begin(MB{}, I3{}, next_step_has_fc);
             if (with_gelu) gelu1(std::integral_constant<int, 2 * half + 1>{}, par);
-            fc_mma(wb[1][0], wb[1][kS1], xn[4 * half + 3], xn[8 + 4 * half + 3], hdst);
+            fc_mma(wb[1][0], wb[1][kS1], xn[4 * half + 3], xn[8 + 4 * half + 3], hdst, std::false_type{});
             pin(VN{});
         };
         auto tile_fc = [&](f32x16 &hdst, const f32x16 &hsrc, int par, bool with_gelu, bool last_of_block) {
-#pragma unroll
-            for (int g = 0; g < 16; g++) hdst[g] = 0.f;
-            step_fc(I0{}, hdst, hsrc, par, with_gelu, true);
+            step_fc(I0{}, hdst, hsrc, par, with_gelu, true);  // (its first chunk starts hdst from zero)
             step_fc(I1{}, hdst, hsrc, par, with_gelu, !last_of_block);
         };
         // GELU of one k-step of hidden planes in a step without MFMAs

@@ -10,7 +10,7 @@ R=$PWD; OUT=gpurun_out/prof_r5; mkdir -p $OUT
 C3="python $R/bench.py --no-secondary --no-cpu-baseline --steps 10 --warmup 2"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/kt3 -o cfg3 -- $C3 > $R/$OUT/cfg3_under_rocprof.json 2> $R/$OUT/kt3.log); echo "kt3 rc=$?"
 python tools/rocpd_summary.py $OUT/kt3/cfg3_results.db $OUT/cfg3_kernel_stats.txt | cut -c1-200 | head -14
-python tools/launch_series.py $OUT/kt3/cfg3_results.db mlp256q_kernel attn256o_kernel attn_last1_kernel > $OUT/launch_series.txt
+python tools/launch_series.py $OUT/kt3/cfg3_results.db mlp256q_kernel attn256q_kernel attn_last1_kernel > $OUT/launch_series.txt
 (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d $R/$OUT/kt -o bench -- python $R/bench.py > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/kt.log); echo "kt rc=$?"
 python tools/rocpd_summary.py $OUT/kt/bench_results.db $OUT/bench_default_kernel_stats.txt | cut -c1-200 | head -24
 B="python $R/bench.py --no-cpu-baseline --no-secondary --steps 4 --warmup 1"
