@@ -48,6 +48,12 @@ __global__ __launch_bounds__(256) void pack_mlp16_kernel(const float *__restrict
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
 }
 
+#if defined(MGPT_AB_MLPF16_CLUMPED)
+constexpr bool kMlpF16Placed = false;
+#else
+constexpr bool kMlpF16Placed = true;
+#endif
+
 template <class T, int NP, int CT, int NW = 8, int NFOLD = 0, int NBUF = 3>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_fused16_kernel(float *__restrict__ x, const float *__restrict__ gain,
                                                               const uint16_t *__restrict__ wpk, float inv1, float inv2,
@@ -203,12 +209,19 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused16_kernel(float *__restri
                 }
                 mm16(w[0][0], xn[kb][0], hd, S0{}); mm16(w[1][0], xn[kb][0], hd, S1{}); mm16(w[0][0], xn[KB + kb][0], hd, S2{}); mm16(w[1][0], xn[KB + kb][0], hd, S3{});
             }
-            // fragment reads run one k-block ahead of the MFMAs that consume them
+            // fragment reads run one k-block ahead of the MFMAs that consume them, one behind each of the block's first MFMAs (-DMGPT_AB_MLPF16_CLUMPED: the
+            // four of them in front of the block)
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) {
-                if (kb + 1 < KB) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NM, 0);
+                if (kMlpF16Placed && kb + 1 < KB) {
+#pragma unroll
+                    for (int n = 0; n < 2 * NP; n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NM - 2 * NP, 0);
+                } else {
+                    if (kb + 1 < KB) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NM, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -259,8 +272,14 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused16_kernel(float *__restri
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
 #pragma unroll
             for (int j = 0; j < CT; j++) {
-                if (j + 1 < CT) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NM, 1);
+                if (kMlpF16Placed && j + 1 < CT) {
+#pragma unroll
+                    for (int n = 0; n < 2 * NP; n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NM - 2 * NP, 1);
+                } else {
+                    if (j + 1 < CT) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NM, 1);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
