@@ -169,6 +169,24 @@ __global__ __launch_bounds__(512, 2) void attn160o_kernel(float *__restrict__ x,
         }
         __builtin_amdgcn_sched_barrier(0);                 // the requests stay in front of this chunk's MFMAs
     };
+    // the same requests one at a time (default build: read n rides behind the chunk's MFMA n -- DESIGN 11.8; -DMGPT_AB_ATTN160_CLUMPED: all in front)
+#if defined(MGPT_AB_ATTN160_CLUMPED)
+    constexpr bool PLACED = false;
+#else
+    constexpr bool PLACED = true;
+#endif
+    auto chunk_read = [&](auto c_c, auto next_c, auto n_c) {
+        constexpr int c = decltype(c_c)::value, n = decltype(n_c)::value;
+        if constexpr (n < 2 * NP) {
+            constexpr int fr = n / NP, pl = n % NP;
+            constexpr int sn = (c + 1 == 4) ? 2 : (c == 4 ? 0 : ((c + 1) & 1));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (c < 4) lds_frag(cur_addr, std::integral_constant<int, ((2 * c + 2 + fr) * NP + pl) * 1024>{}, wb[sn][fr][pl]);
+            else if constexpr (decltype(next_c)::value) lds_frag(nxt_addr, std::integral_constant<int, (fr * NP + pl) * 1024>{}, wb[0][fr][pl]);
+            if constexpr (NP == 1 && (c < 4 || decltype(next_c)::value)) wb[sn][fr][1] = wb[sn][fr][0];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto pin6 = [&]() {
 #pragma unroll
         for (int n = 0; n < (NP == 2 ? 6 : 2); n++) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -217,22 +235,35 @@ __global__ __launch_bounds__(512, 2) void attn160o_kernel(float *__restrict__ x,
         auto chunk = [&](auto c_c) {
             constexpr int c = decltype(c_c)::value;
             constexpr int s = (c == 4) ? 2 : (c & 1);
-            chunk_begin(c_c, next_c);
             constexpr int k0 = MODE == 0 ? 5 * j + c : 2 * c, k1 = MODE == 0 ? 5 * j + c : 2 * c + 1;
+            if constexpr (PLACED) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else chunk_begin(c_c, next_c);
+            auto behind = [&](auto n_c) { if constexpr (PLACED) chunk_read(c_c, next_c, n_c); };
+            using N0 = std::integral_constant<int, 0>; using N1 = std::integral_constant<int, 1>;
+            using N2 = std::integral_constant<int, 2>; using N3 = std::integral_constant<int, 3>;
             if (MODE == 2) {
                 if (NP == 2) {
-                    qa = T::mfma(xn[k0][1], wb[s][0][0], qa); ka = T::mfma(xn[k1][1], wb[s][1][0], ka);
-                    qa = T::mfma(xn[k0][0], wb[s][0][1], qa); ka = T::mfma(xn[k1][0], wb[s][1][1], ka);
+                    qa = T::mfma(xn[k0][1], wb[s][0][0], qa); behind(N0{}); ka = T::mfma(xn[k1][1], wb[s][1][0], ka); behind(N1{});
+                    qa = T::mfma(xn[k0][0], wb[s][0][1], qa); behind(N2{}); ka = T::mfma(xn[k1][0], wb[s][1][1], ka); behind(N3{});
+                    qa = T::mfma(xn[k0][0], wb[s][0][0], qa); ka = T::mfma(xn[k1][0], wb[s][1][0], ka);
+                } else {
+                    qa = T::mfma(xn[k0][0], wb[s][0][0], qa); behind(N0{}); ka = T::mfma(xn[k1][0], wb[s][1][0], ka); behind(N1{});
                 }
-                qa = T::mfma(xn[k0][0], wb[s][0][0], qa); ka = T::mfma(xn[k1][0], wb[s][1][0], ka);
             } else {
                 if (NP == 2) {
-                    qa = T::mfma(wb[s][0][1], xn[k0][0], qa); ka = T::mfma(wb[s][1][1], xn[k1][0], ka);
-                    qa = T::mfma(wb[s][0][0], xn[k0][1], qa); ka = T::mfma(wb[s][1][0], xn[k1][1], ka);
+                    qa = T::mfma(wb[s][0][1], xn[k0][0], qa); behind(N0{}); ka = T::mfma(wb[s][1][1], xn[k1][0], ka); behind(N1{});
+                    qa = T::mfma(wb[s][0][0], xn[k0][1], qa); behind(N2{}); ka = T::mfma(wb[s][1][0], xn[k1][1], ka); behind(N3{});
+                    qa = T::mfma(wb[s][0][0], xn[k0][0], qa); ka = T::mfma(wb[s][1][0], xn[k1][0], ka);
+                } else {
+                    qa = T::mfma(wb[s][0][0], xn[k0][0], qa); behind(N0{}); ka = T::mfma(wb[s][1][0], xn[k1][0], ka); behind(N1{});
                 }
-                qa = T::mfma(wb[s][0][0], xn[k0][0], qa); ka = T::mfma(wb[s][1][0], xn[k1][0], ka);
             }
-            pin6();
+            if constexpr (PLACED) {
+                if (NP == 2) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+            } else pin6();
             asm volatile("" : "+v"(qa), "+v"(ka));         // both chains are pinned to this chunk
         };
         chunk(I0{}); chunk(I1{}); chunk(I2{}); chunk(I3{}); chunk(I4{});
