@@ -511,7 +511,7 @@ def class_flops(prof, f_class, L_, rows, full=None):
     """Algorithmic (reference-executed) flops per step of every kernel class that actually ran; fused classes carry the
     flops of everything they absorbed.  The last-layer shortcut is OUR saving: flops stay the reference's.  `full` = the
     classes that ran FULL-SIZE launches (fold_last): a class that only ran for the last layer's token-255 rows (the 6M shape's
-    out-projection since attn256o_kernel absorbed it everywhere else) has been absorbed, its flops belong to the attention class."""
+    out-projection since attn256o_kernel / attn256q_kernel absorbed it everywhere else) has been absorbed, its flops belong to the attention class."""
     ran = full if full is not None else prof
     cls = {k: f_class[k] * L_ * rows for k in f_class if k in prof and k in ran}
     if "gpt_attention" in cls:

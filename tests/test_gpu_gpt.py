@@ -183,7 +183,7 @@ def test_head_parallel_small_launch_vs_row_per_workgroup_path(name, precision):
     cfg1) is served.  The same rows inside a 160-row launch take the row-per-workgroup kernels.  Same products, another
     summation order of the residual stream: the two must agree to fp32 rounding and both must sit within 1e-5 of the fp32 port
     (the f16x3 mode; bf16: its own class).  Round 5: the 6M shape too -- calls of <= 128 rows run attn256_kernel<HP> (one workgroup per
-    (row, head), y planes) + the packed-GEMM out-projection instead of the persistent attn256o_kernel."""
+    (row, head), y planes) + the packed-GEMM out-projection instead of the persistent attn256q_kernel (attn256o_kernel until the end of round 5)."""
     from mapf_gpt_amd.model import build_model
     rows = np.load(os.path.join(GOLDEN, "gptbig_2M_s1.npz"))["tokens"][:160]
     net = build_model(name, seed=0, max_rows=160, precision=precision)
@@ -228,7 +228,7 @@ def test_small_call_of_the_packed_gemm_chain_vs_the_large_call(precision):
 
 @pytest.mark.parametrize("name,precision", [("2M", "f16x3"), ("6M", "f16x3"), ("6M", "bf16")])
 def test_persistent_kernels_uneven_grid(name, precision):
-    """The persistent attention kernels (attn256o_kernel, attn160o_kernel; grid = min(rows, CUs), a workgroup walks rows b, b + grid, ...)
+    """The persistent attention kernels (attn256q_kernel, attn160o_kernel; grid = min(rows, CUs), a workgroup walks rows b, b + grid, ...)
     with a row count that is not a multiple of the grid: 600 rows on 256 CUs = 88 workgroups take 3 rows, 168 take 2, and the last
     layer's attn_last1_kernel handles 150 workgroups of 4.  A row's logits are bit-identical to the same row in a 200-row launch (one
     row per workgroup) and, in the 1e-5 mode, within the bar of the reference goldens."""
