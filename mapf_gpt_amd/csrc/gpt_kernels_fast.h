@@ -1574,44 +1574,76 @@ __global__ __launch_bounds__(NW * 64) void attn16_kernel(const uint16_t *__restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    // stage K [256][HS] and V^T [HS][256] planes (16-byte chunks)
-    if (chunk_major) {      // planes written by the packed GEMM: [hs/8][256][8] and [256/8][hs][8]; consecutive threads read consecutive 16 B
-        for (int idx = tid; idx < NP * kT * (HS / 8); idx += NW * 64) {
-            const int pl = idx / (kT * (HS / 8)), rem = idx - pl * (kT * (HS / 8)), c = rem / kT, row = rem - c * kT;
-            const uint16_t *src = (pl == 0 ? k_hi : k_lo) + base + (size_t)rem * 8;
-            *reinterpret_cast<u32x4 *>(sK + (size_t)pl * kT * KRS + row * KRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
+    const int qt_first = last_only ? kT / 32 - 1 + (wave == 0 ? 0 : kT) : wave;
+    u32x4 qf[KS][2];                                             // B operand: Q[query r][16 ks + 8 h ..]
+    auto load_q = [&](int qt, u32x4 (&dst)[KS][2]) {
+        if (qt >= kT / 32) return;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++)
+                dst[ks][pl] = *reinterpret_cast<const u32x4 *>((pl == 0 ? q_hi : q_lo) + base +
+                                                              (chunk_major ? ((size_t)(ks * 2 + h) * kT + qt * 32 + r) * 8
+                                                                           : (size_t)(qt * 32 + r) * HS + ks * 16 + h * 8));
+    };
+    // stage K [256][HS] and V^T [HS][256] planes (16-byte chunks).  ALL of a thread's loads are issued before the first LDS store (round 5; rounds 1-4: a
+    // `for (idx = tid; idx < N; idx += threads)` loop, which hipcc cannot unroll -- it ran load, s_waitcnt vmcnt(0), ds_write eight times in sequence, eight
+    // memory round trips per workgroup before its first MFMA: the kernel sat at 0.51 of the HBM rate with 0.22 of the MFMA rate; -DMGPT_AB_ATTN16_SERIAL_STAGE)
+    {
+        constexpr int NCH = NP * kT * (HS / 8);             // 16-byte chunks of the K planes (= of the V^T planes)
+        constexpr int NIT = NCH / (NW * 64);
+        static_assert(NIT * NW * 64 == NCH, "whole chunks per thread");
+        // chunk idx of the K planes: source element offset and LDS byte offset
+        auto k_src = [&](int idx, const uint16_t *&src, unsigned &dst) {
+            const int pl = idx / (kT * (HS / 8)), rem = idx - pl * (kT * (HS / 8));
+            int row, c;
+            if (chunk_major) { c = rem / kT; row = rem - c * kT; src = (pl == 0 ? k_hi : k_lo) + base + (size_t)rem * 8; }   // planes written by the packed GEMM: [hs/8][256][8]
+            else { row = rem / (HS / 8); c = rem - row * (HS / 8); src = (pl == 0 ? k_hi : k_lo) + base + (size_t)row * HS + c * 8; }
+            dst = (unsigned)(pl * kT * KRS + row * KRS + c * 16);
+        };
+        auto v_src = [&](int idx, const uint16_t *&src, unsigned &dst) {
+            const int pl = idx / (HS * (kT / 8)), rem = idx - pl * (HS * (kT / 8));
+            int row, c;
+            if (chunk_major) { c = rem / HS; row = rem - c * HS; src = (pl == 0 ? vt_hi : vt_lo) + base + (size_t)rem * 8; }   // [256/8][hs][8]
+            else { row = rem / (kT / 8); c = rem - row * (kT / 8); src = (pl == 0 ? vt_hi : vt_lo) + base + (size_t)row * kT + c * 8; }
+            dst = (unsigned)(pl * HS * VRS + row * VRS + c * 16);
+        };
+#if defined(MGPT_AB_ATTN16_SERIAL_STAGE)
+        for (int idx = tid; idx < NCH; idx += NW * 64) {
+            const uint16_t *src; unsigned dst;
+            k_src(idx, src, dst);
+            *reinterpret_cast<u32x4 *>(sK + dst) = *reinterpret_cast<const u32x4 *>(src);
         }
-        for (int idx = tid; idx < NP * HS * (kT / 8); idx += NW * 64) {
-            const int pl = idx / (HS * (kT / 8)), rem = idx - pl * (HS * (kT / 8)), c = rem / HS, row = rem - c * HS;
-            const uint16_t *src = (pl == 0 ? vt_hi : vt_lo) + base + (size_t)rem * 8;
-            *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VRS + row * VRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
+        for (int idx = tid; idx < NCH; idx += NW * 64) {
+            const uint16_t *src; unsigned dst;
+            v_src(idx, src, dst);
+            *reinterpret_cast<u32x4 *>(sV + dst) = *reinterpret_cast<const u32x4 *>(src);
         }
-    } else {
-    for (int idx = tid; idx < NP * kT * (HS / 8); idx += NW * 64) {
-        const int pl = idx / (kT * (HS / 8)), rem = idx - pl * (kT * (HS / 8)), row = rem / (HS / 8), c = rem - row * (HS / 8);
-        const uint16_t *src = (pl == 0 ? k_hi : k_lo) + base + (size_t)row * HS + c * 8;
-        *reinterpret_cast<u32x4 *>(sK + (size_t)pl * kT * KRS + row * KRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
-    }
-    for (int idx = tid; idx < NP * HS * (kT / 8); idx += NW * 64) {
-        const int pl = idx / (HS * (kT / 8)), rem = idx - pl * (HS * (kT / 8)), row = rem / (kT / 8), c = rem - row * (kT / 8);
-        const uint16_t *src = (pl == 0 ? vt_hi : vt_lo) + base + (size_t)row * kT + c * 8;
-        *reinterpret_cast<u32x4 *>(sV + (size_t)pl * HS * VRS + row * VRS + c * 16) = *reinterpret_cast<const u32x4 *>(src);
-    }
+#else
+        u32x4 kreg[NIT], vreg[NIT];
+        unsigned kdst[NIT], vdst[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) { const uint16_t *src; k_src(tid + it * NW * 64, src, kdst[it]); kreg[it] = *reinterpret_cast<const u32x4 *>(src); }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) { const uint16_t *src; v_src(tid + it * NW * 64, src, vdst[it]); vreg[it] = *reinterpret_cast<const u32x4 *>(src); }
+        load_q(qt_first, qf);                               // this wave's first query tile rides with the staging loads
+#pragma unroll
+        for (int it = 0; it < NIT; it++) *reinterpret_cast<u32x4 *>(sK + kdst[it]) = kreg[it];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) *reinterpret_cast<u32x4 *>(sV + vdst[it]) = vreg[it];
+#endif
     }
     __syncthreads();
 
     // the S^T tile row this lane feeds as A-operand is key `kperm` of the tile (bits 2 and 3 of r swapped)
     const int kperm = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);
 
-    for (int qt = last_only ? kT / 32 - 1 + (wave == 0 ? 0 : kT) : wave; qt < kT / 32; qt += NW) {
-        u32x4 qf[KS][2];                                         // B operand: Q[query r][16 ks + 8 h ..]
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-            for (int pl = 0; pl < NP; pl++)
-                qf[ks][pl] = *reinterpret_cast<const u32x4 *>((pl == 0 ? q_hi : q_lo) + base +
-                                                             (chunk_major ? ((size_t)(ks * 2 + h) * kT + qt * 32 + r) * 8
-                                                                          : (size_t)(qt * 32 + r) * HS + ks * 16 + h * 8));
+    for (int qt = qt_first; qt < kT / 32; qt += NW) {
+#if defined(MGPT_AB_ATTN16_SERIAL_STAGE)
+        load_q(qt, qf);
+#else
+        if (qt != qt_first) load_q(qt, qf);
+#endif
         f32x16 o[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; dt++)
@@ -1637,21 +1669,45 @@ __global__ __launch_bounds__(NW * 64) void attn16_kernel(const uint16_t *__restr
 #pragma unroll
             for (int g = 1; g < 16; g++) mx = fmaxf(mx, s[g]);
             mx = half_max32(mx);
+            // The kernel runs at the SUM of its MFMA and VALU issue time, so the softmax arithmetic is kept short: the rescale of o and l
+            // (16 DT + 3 instructions) only when some query's running maximum moved (wave-uniform branch; alpha = 1 exactly otherwise), and one fma per
+            // score in front of the exp2 (-DMGPT_AB_ATTN16_PLAIN: round 1's form, rescale every tile and (s - m) * scale)
+#if defined(MGPT_AB_ATTN16_PLAIN)
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) o[dt][g] *= alpha;
+            m_run = m_new;
             float psum = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; g++) {
                 s[g] = __builtin_amdgcn_exp2f((s[g] - m_new) * scale_log2e);
                 psum += s[g];
             }
+#else
+            if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                    for (int g = 0; g < 16; g++) o[dt][g] *= alpha;
+                m_run = m_new;
+            }
+            const float nm = -m_run * scale_log2e;
+            float psum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                s[g] = __builtin_amdgcn_exp2f(fmaf(s[g], scale_log2e, nm));
+                psum += s[g];
+            }
+#endif
             psum = half_sum32(psum);
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < DT; dt++)
-#pragma unroll
-                for (int g = 0; g < 16; g++) o[dt][g] *= alpha;
+            l_run += psum;
 #pragma unroll
             for (int mm = 0; mm < 2; mm++) {                      // two PV MFMAs of 16 keys each
                 const float pv0[4] = {s[8 * mm], s[8 * mm + 1], s[8 * mm + 2], s[8 * mm + 3]};
