@@ -37,7 +37,20 @@ constexpr int kWin = 2 * kR + 1;    // 11
 constexpr int kLimit = 20;          // cost2go_value_limit (inference.py:17)
 constexpr int kSlots = 13;          // num_agents (inference.py:15)
 constexpr int kDefaultStep = 64;    // grid_step the reference passes (inference.py:28); run-time value: mgpt_tokenizer::step
-constexpr int TOK_UNREACH = 41, TOK_NEG = 42, TOK_POS = 43, TOK_N = 44, TOK_BITS0 = 50, TOK_PAD = 66;
+constexpr int TOK_UNREACH = 41, TOK_NEG = 42, TOK_POS = 43, TOK_N = 44, TOK_BITS0 = 50, TOK_PAD = 66;   // the default vocabulary (dataset-side kernels)
+
+// struct InputParameters (observation_generator.h:22-40) as the inference-side kernels see it; validated by mgpt_tokenizer_create.
+// Vocabulary (Encoder::Encoder, cpp:321-350): -L..L -> 0..2L, -4L ("unreachable") -> 2L+1, -2L -> 2L+2, +2L -> 2L+3,
+// n w u d l r -> 2L+4.., "0000".."1111" -> 2L+10.., "!" -> 2L+26.
+struct TokCfg {
+    int L;      // cost2go_value_limit
+    int S;      // num_agents: neighbour records per row (<= 16)
+    int Hn;     // num_previous_actions (<= 5: AgentRec::hist keeps the last five)
+    int R;      // obs_radius (<= 5: two window cells per lane)
+    int A;      // agents_radius (<= 5: twelve distance buckets)
+    __host__ __device__ int tok_n() const { return 2 * L + 4; }
+    __host__ __device__ int tok_bits0() const { return 2 * L + 10; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Distance field.  The reference's tiled / border-table / priority-queue construction (cpp:43-286)
@@ -109,28 +122,28 @@ __global__ __launch_bounds__(256) void bfs_kernel(const uint8_t *__restrict__ gr
 }
 
 // greedy-direction bits, cpp:412-430: order u(-1,0) d(+1,0) l(0,-1) r(0,+1); bit = neighbour strictly closer
-__device__ __forceinline__ int next_action_token(const uint16_t *__restrict__ d, int H, int W, int pr, int pc)
+__device__ __forceinline__ int next_action_token(const uint16_t *__restrict__ d, int H, int W, int pr, int pc, int bits0 = TOK_BITS0)
 {
-    if (pr < 0 || pr >= H || pc < 0 || pc >= W) return TOK_BITS0;
+    if (pr < 0 || pr >= H || pc < 0 || pc >= W) return bits0;
     const int cur = d[pr * W + pc];
     const int u = (pr > 0) ? (int)d[(pr - 1) * W + pc] : kUnreach;
     const int dn = (pr < H - 1) ? (int)d[(pr + 1) * W + pc] : kUnreach;
     const int l = (pc > 0) ? (int)d[pr * W + pc - 1] : kUnreach;
     const int rt = (pc < W - 1) ? (int)d[pr * W + pc + 1] : kUnreach;
-    return TOK_BITS0 + 8 * (u < cur) + 4 * (dn < cur) + 2 * (l < cur) + (rt < cur);
+    return bits0 + 8 * (u < cur) + 4 * (dn < cur) + 2 * (l < cur) + (rt < cur);
 }
 
 // origin of the partial window the reference computes for an agent standing at (pr, pc), cpp:204-207 (H, W <= 16384: a byte each)
-__device__ __forceinline__ void window_origin(AgentRec &r, int gstep)
+__device__ __forceinline__ void window_origin(AgentRec &r, int gstep, int R)
 {
-    r.org[0] = (uint8_t)(max(r.pr - kR, 0) / gstep);
-    r.org[1] = (uint8_t)(max(r.pc - kR, 0) / gstep);
+    r.org[0] = (uint8_t)(max(r.pr - R, 0) / gstep);
+    r.org[1] = (uint8_t)(max(r.pc - R, 0) / gstep);
 }
 
 // create_agents, cpp:391-410 (history <- "n" x 5)
 __global__ __launch_bounds__(256) void tok_create_kernel(AgentRec *__restrict__ recs, const int16_t *__restrict__ pos,
                                                          const int16_t *__restrict__ goal, int total,
-                                                         int *__restrict__ u8_ok, int gstep)
+                                                         int *__restrict__ u8_ok, int gstep, const TokCfg cfg)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) *u8_ok = 1;          // every field is rebuilt next; bfs_kernel clears it if one does not fit a byte
@@ -139,9 +152,9 @@ __global__ __launch_bounds__(256) void tok_create_kernel(AgentRec *__restrict__ 
     r.pr = pos[2 * i]; r.pc = pos[2 * i + 1];
     r.gr = goal[2 * i]; r.gc = goal[2 * i + 1];
 #pragma unroll
-    for (int k = 0; k < 5; k++) r.hist[k] = TOK_N;
-    r.next = TOK_BITS0;
-    window_origin(r, gstep);                                                                        // cpp:408
+    for (int k = 0; k < 5; k++) r.hist[k] = (uint8_t)cfg.tok_n();
+    r.next = (uint8_t)cfg.tok_bits0();
+    window_origin(r, gstep, cfg.R);                                                                 // cpp:408
     recs[i] = r;
 }
 
@@ -151,7 +164,8 @@ __global__ __launch_bounds__(256) void tok_update_kernel(AgentRec *__restrict__ 
                                                          const int16_t *__restrict__ goal,
                                                          const int32_t *__restrict__ actions, uint8_t *__restrict__ dirty,
                                                          int total, int check_goals, const uint16_t *__restrict__ dist,
-                                                         int H, int W, int gstep, const uint8_t *__restrict__ active, int n_agents)
+                                                         int H, int W, int gstep, const uint8_t *__restrict__ active, int n_agents,
+                                                         const TokCfg cfg)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(256) void tok_update_kernel(AgentRec *__restrict__ 
     r.pr = pos[2 * i]; r.pc = pos[2 * i + 1];
     const int act = actions[i];
     r.hist[0] = r.hist[1]; r.hist[1] = r.hist[2]; r.hist[2] = r.hist[3]; r.hist[3] = r.hist[4];   // cpp:463
-    r.hist[4] = (uint8_t)((act >= 0 && act <= 4) ? TOK_N + 1 + act : TOK_N);                        // cpp:442-462
+    r.hist[4] = (uint8_t)((act >= 0 && act <= 4) ? cfg.tok_n() + 1 + act : cfg.tok_n());           // cpp:442-462
     bool moved_goal = false;
     if (check_goals) {
         const int16_t gr = goal[2 * i], gc = goal[2 * i + 1];
@@ -175,58 +189,69 @@ __global__ __launch_bounds__(256) void tok_update_kernel(AgentRec *__restrict__ 
         // window leaves it; only its origin matters here (it decides which cell is the unseeded corner)
         const int left = gstep * r.org[0], top = gstep * r.org[1];
         const int right = min(left + 2 * gstep, H - 1), bottom = min(top + 2 * gstep, W - 1);
-        if (moved_goal || r.pr - kR < left || r.pr + kR > right || r.pc - kR < top || r.pc + kR > bottom) window_origin(r, gstep);
+        const int R = cfg.R;
+        if (moved_goal || r.pr - R < left || r.pr + R > right || r.pc - R < top || r.pc + R > bottom) window_origin(r, gstep, R);
     }
     if (!check_goals) {
-        r.next = (uint8_t)next_action_token(dist + (size_t)i * H * W, H, W, r.pr, r.pc);            // cpp:483-484
+        r.next = (uint8_t)next_action_token(dist + (size_t)i * H * W, H, W, r.pr, r.pc, cfg.tok_bits0());   // cpp:483-484
     }
     recs[i] = r;
 }
 
 __global__ __launch_bounds__(256) void tok_next_kernel(AgentRec *__restrict__ recs, int total,
-                                                       const uint16_t *__restrict__ dist, int H, int W)
+                                                       const uint16_t *__restrict__ dist, int H, int W, int bits0)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int pr = recs[i].pr, pc = recs[i].pc;
-    recs[i].next = (uint8_t)next_action_token(dist + (size_t)i * H * W, H, W, pr, pc);
+    recs[i].next = (uint8_t)next_action_token(dist + (size_t)i * H * W, H, W, pr, pc, bits0);
 }
 
 // ---------------------------------------------------------------------------------------------
 // generate_observations, cpp:516-528.  Workgroup = 4 wavefronts = one chunk of 4*RPW agents of ONE
-// instance; a wavefront owns one agent (one 256-token row) at a time, RPW rows in flight.
-//   LDS: token LUT, the instance's agent records (16 B each) + their biased packed positions, per wave
-//        a row image (token t lives at byte t+1 so the 10-token neighbour records are 2-byte aligned)
-//        and a 12-entry distance-bucket table.
-//   HBM reads per row: the 121-cell window of the agent's own distance field (one byte per cell from
-//        `dist8` when every field fits a byte, else two from `dist`); writes: one coalesced 256-B store.
-// Measured (tools/bench_tokenizer.py, tools/bench_probes/probe_salu.hip): the kernel is instruction-issue bound before
-// it is HBM bound -- a wave64 VALU instruction costs its SIMD ~1.6 ns, a scalar one ~1.8 ns, and an LDS
-// store whose lanes collide on one address serialises -- so the row body is written around issue count:
-//   * window token = LUT[med3(v - (mid-21), 0, 42)] (43 = unreachable);
-//   * neighbour test on packed 16-bit positions (v_pk_sub_u16 / v_pk_max_u16 / v_sad_u16);
-//   * neighbour order = (Manhattan distance, agent id) ascending, first 13 (cpp:496-506):
-//     rank = #candidates in lower distance buckets + #lower ids in the own bucket.  Candidate lanes are in id
-//     order (KP == 1: lane == agent id; KP > 1: the passes' neighbours are compacted into <= 64 lanes by
-//     ballot + mbcnt).  Every candidate ORs its lane bit into bucket[md] in LDS, 16 lanes prefix-sum the bucket
-//     populations (DPP row scan), then each candidate reads its bucket once:
-//     rank = prefix + popcount(bucket mask below my lane).  ~15 VALU, no per-distance loop.
-//     More than 64 neighbours in one window (possible with > 64 agents in an open room): exact slow path that
-//     walks the distance buckets over all passes;
-//   * only the <= 13 ranked lanes write their agent's 10-token record (conflict-free LDS stores);
-//   * a row's chain is ~8 dependent LDS round trips, so a wave works on 4 rows at once, phase by phase.
-// KP = ceil(n_agents / 64) candidate passes per row.
+// instance; a wavefront owns one agent (one 256-token row) at a time, RPW rows in flight, U = 4 of them
+// interleaved phase by phase (a row's chain is ~8 dependent LDS round trips).
+//   LDS: per-row headers, the instance's agent records (16 B each) + their biased packed positions, per wave
+//        U row images (token t at byte t+1 so that 10-token neighbour records are 2-byte aligned), a distance-bucket
+//        table, a (rank -> agent) list per row and (KP > 1) the compacted neighbour keys.
+//   HBM reads per row: the window of the agent's own distance field (one byte per cell from `dist8` when every
+//        field fits a byte, else two from `dist`); writes: one coalesced 256-B store.
+// The kernel is instruction-issue bound (rounds 1-5: DESIGN.md section 11.4), so round 6 rewrote the row body around the
+// DYNAMIC instruction count (profiles/r06_pmc_insts.txt; round 5: 111 VALU + 65 SALU per row at 192 agents):
+//   * the two window cells of a lane are ONE packed 16-bit pair: saturating v_pk_add/sub_u16, v_pk_min_u16 -- the whole
+//     clamp / sentinel / vocabulary chain is branch-free and runs once per pair; the high half is stored with
+//     ds_write_b8_d16_hi (round 5's per-cell ternaries compiled to four exec-mask branches per cell);
+//   * window addresses are (wave-uniform 64-bit base incl. the window origin) + (per-lane constant): no vector address arithmetic;
+//   * neighbour test on packed 16-bit positions (v_pk_sub_u16 / v_pk_max_u16), candidates of the KP passes compacted in id
+//     order by ballot + mbcnt into 16-bit keys (distance << 11 | id) -- the compaction area holds every candidate of the
+//     KP <= 4 instances, so no per-lane overflow test;
+//   * order = (Manhattan distance, agent id) ascending, first S (cpp:496-506): rank = #candidates in lower distance buckets
+//     + #lower ids in the own bucket: every candidate ORs its lane bit into bucket[d] in LDS (ds_or_b64), 16 lanes prefix-sum the
+//     bucket populations (DPP row scan), each candidate reads its bucket once;
+//   * a ranked candidate only leaves its key in list[row][rank]; the records of FOUR rows are then emitted at once by lanes
+//     16 u + rank (round 5 emitted per row with <= 13 of 64 lanes active);
+//   * more than 64 neighbours in one window (> 64 agents in an open room): exact slow path that walks the distance
+//     buckets over all passes and fills the same list.
+// KP = ceil(n_agents / 64) candidate passes per row.  All of InputParameters (limit, slots, history, radii) are kernel
+// arguments: they sit in scalar registers and cost the default configuration nothing.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowsInterleaved = 4; // rows a wave works on at once (U)
 constexpr int kRowBytes = 512;      // one row image: token t at byte t+1; bytes >= 264 are dump space
 constexpr int kRowImage = kRowsInterleaved * kRowBytes;   // per wave
-constexpr int kDumpTok = 320;       // where lanes without a second window cell put their byte (inside the 512-B half image, never read)
-constexpr int kBktBytes = 1024;     // per wave: 64 x 16 B {mask lo, mask hi, prefix, -}; entries 0..10 = distances, 11 = "not a neighbour"
-constexpr int kNoRank = 64;
-constexpr int kLutBytes = 64;
+constexpr int kDumpTok = 320;       // where lanes without a window cell put their byte (inside the 512-B image, never read)
+constexpr int kBktBytes = 1024;     // per wave: 64 x 16 B {mask lo, mask hi, prefix, -}; entry 16 u + d = distance bucket d of row u
+constexpr int kListEntries = 16;    // per row: rank -> key (uint16; kNoKey = empty); num_agents <= 16
+constexpr unsigned kNoKey = 0xffffu;
+constexpr int kIdBits = 11;         // key = distance << 11 | agent id (n_agents <= 2048)
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef short ss2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ us2 as_us2(uint32_t x) { return __builtin_bit_cast(us2, x); }
+__device__ __forceinline__ ss2 as_ss2(uint32_t x) { return __builtin_bit_cast(ss2, x); }
+__device__ __forceinline__ uint32_t as_u32(us2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t as_u32(ss2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t rep16(int v) { return (uint32_t)(v & 0xffff) * 0x10001u; }
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_shr_add(int x)      // x + (x of the lane CTRL-0x110 to the left in its row of 16, 0 if none)
@@ -234,8 +259,8 @@ __device__ __forceinline__ int dpp_shr_add(int x)      // x + (x of the lane CTR
     return x + __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
 }
 
-// one neighbour record = 10 tokens at row bytes 122 + 10*rank (cpp:352-373): rel pos (not clamped, within +-5),
-// rel goal clamped to +-20, five history tokens oldest first, greedy-direction bits
+// one neighbour record of the DEFAULT layout = 10 tokens at row bytes 122 + 10*rank (cpp:352-373): rel pos (not clamped, within +-5),
+// rel goal clamped to +-20, five history tokens oldest first, greedy-direction bits.  (dataset-side kernel; tokens_kernel has its own emission)
 __device__ __forceinline__ void emit_record(uint8_t *rw, int rank, uint4 o, uint32_t my0)
 {
     const ss2 mys = __builtin_bit_cast(ss2, my0);
@@ -251,19 +276,55 @@ __device__ __forceinline__ void emit_record(uint8_t *rw, int rank, uint4 o, uint
     dst[4] = (uint16_t)o.w;
 }
 
+__device__ __forceinline__ void wave_lds_sync()        // this wave's LDS traffic above is visible to its own reads below
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int KP> struct CandWidth { static constexpr int value = KP == 1 ? 0 : (KP <= 4 ? 64 * KP : 64); };
+
+// raw buffer resource over [p, p + 2 GiB): address = base + scalar offset + per-lane offset -- a wave-uniform row / window origin
+// and a per-lane constant meet in the instruction (buffer_load_ubyte v, v_off, s[rsrc], s_off offen), no vector address arithmetic
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint32_t field_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint8_t)
+{
+    return __builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+}
+__device__ __forceinline__ uint32_t field_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint16_t)
+{
+    return __builtin_amdgcn_raw_buffer_load_b16(r, 2 * voff, 2 * soff, 0);
+}
+
 template <class DT, int KP, int RPW>
 __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, const DT *__restrict__ dist, int n_agents,
-                                            int H, int W, int chunks_per_inst, uint8_t *__restrict__ tokens, char *smem, int gstep)
+                                            int H, int W, int chunks_per_inst, uint8_t *__restrict__ tokens, char *smem, int gstep,
+                                            const TokCfg p)
 {
-    constexpr int UNR = sizeof(DT) == 1 ? 255 : kUnreach;
+    constexpr unsigned UNR = sizeof(DT) == 1 ? 255u : (unsigned)kUnreach;
     constexpr int APB = 4 * RPW;
-    uint8_t *lut = reinterpret_cast<uint8_t *>(smem);                                      // LDS offset 0
-    int4 *hdr = reinterpret_cast<int4 *>(smem + kLutBytes);                                // [APB] {pos, centre offset, state}
-    uint4 *srec = reinterpret_cast<uint4 *>(smem + kLutBytes + APB * 16);                  // [n_agents]
-    uint32_t *spos = reinterpret_cast<uint32_t *>(smem + kLutBytes + APB * 16 + (size_t)n_agents * 16);   // [KP*64] biased (r,c)
+    constexpr int U = kRowsInterleaved;
+    constexpr int CW = CandWidth<KP>::value;
+    static_assert(RPW % U == 0, "RPW must be a multiple of U");
+    uint2 *hdr = reinterpret_cast<uint2 *>(smem);                                          // [APB] {packed position, window origin | flags}
+    uint4 *srec = reinterpret_cast<uint4 *>(smem + APB * 8);                               // [n_agents]
+    uint32_t *spos = reinterpret_cast<uint32_t *>(smem + APB * 8 + (size_t)n_agents * 16); // [KP*64] biased (r,c) + agents radius
     uint8_t *srow = reinterpret_cast<uint8_t *>(spos + KP * 64);                           // [4][kRowImage]
     uint8_t *sbkt = srow + 4 * kRowImage;                                                  // [4][kBktBytes]
-    uint32_t *scand = reinterpret_cast<uint32_t *>(sbkt + 4 * kBktBytes);                  // [4][U*64] compacted neighbours (KP > 1)
+    uint16_t *slist = reinterpret_cast<uint16_t *>(sbkt + 4 * kBktBytes);                  // [4][U][kListEntries]
+    uint16_t *scand = slist + 4 * U * kListEntries;                                        // [4][U][CW] compacted neighbour ids (KP > 1)
+
+    const int R = p.R, A = p.A, L = p.L;
+    const int win = 2 * R + 1, ncell = win * win, rec_len = 5 + p.Hn;
+    const int top = 2 * L + 2;                          // window arithmetic: x = clamp(v - mid + L + 1, 0, 2L + 2)
+    const uint32_t top2 = rep16(top), topm2 = rep16(top - 1), one2 = 0x00010001u;
+    const uint32_t unrm2 = rep16((int)UNR - 1), unrtok2 = rep16(2 * L + 1);
+    const uint32_t pad4 = (uint32_t)(2 * L + 26) * 0x01010101u;          // "!" (cpp:375-376,386-387)
+    const uint32_t rad2 = rep16(A), diam2 = rep16(2 * A);
 
     const int inst = blockIdx.x / chunks_per_inst;
     const int chunk = blockIdx.x - inst * chunks_per_inst;
@@ -276,228 +337,257 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
     for (int i = tid; i < KP * 64; i += 256) {
         uint32_t bp = 0xffffffffu;                       // sentinel: never inside a window (H, W <= 16384)
         if (i < n_agents) {
-            const uint4 r = grec[i];                     // {pr|pc<<16, gr|gc<<16, hist0..3, hist4|next<<8}
+            const uint4 r = grec[i];                     // {pr|pc<<16, gr|gc<<16, hist0..3, hist4|next<<8|org<<16}
             srec[i] = r;
             bp = r.x ^ 0x80008000u;                      // int16 -> order-preserving uint16
         }
-        spos[i] = bp;
+        spos[i] = as_u32(as_us2(bp) + as_us2(rad2));     // + (A, A): the test below is then (candidate - me) <= 2A per half
     }
     if (tid < APB) {                                     // per-row scalars, prepared once
         const int a = a_begin + tid;
-        int4 h = make_int4(0, 0, -1, 0);                 // state -1: no such agent
+        uint2 h = make_uint2(0u, 0x80000000u);           // bit 31: no such agent
         if (a < n_agents) {
             const uint4 me = grec[a];
             const uint32_t my0 = me.x;
             const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
-            const bool inside = pr >= kR && pr + kR < H && pc >= kR && pc + kR < W;   // whole window inside the frame
-            // is the unseeded corner of the agent's cached partial window (cpp:178-198) the window cell (10, 10)?
+            const bool inside = pr >= R && pr + R < H && pc >= R && pc + R < W;       // whole window inside the frame
+            // is the unseeded corner of the agent's cached partial window (cpp:178-198) the window's last cell?
             const int cr = gstep * (int)((me.w >> 16) & 0xffu) + 2 * gstep, cc = gstep * (int)(me.w >> 24) + 2 * gstep;
-            const bool corner = cr <= H - 1 && cc <= W - 1 && pr + kR == cr && pc + kR == cc;
-            h = make_int4((int)my0, pr * W + pc, inside ? 1 : 0, corner ? 1 : 0);
+            const bool corner = cr <= H - 1 && cc <= W - 1 && pr + R == cr && pc + R == cc;
+            // bits 0..28: offset of the window's first cell in the field (H * W <= 2^22); bit 30: window not wholly inside; bit 29: corner
+            h = make_uint2(my0, inside ? (uint32_t)((pr - R) * W + (pc - R)) | (corner ? 0x20000000u : 0u) : 0x40000000u);
         }
         hdr[tid] = h;
-    }
-    if (tid >= 64 && tid < 64 + kLutBytes) {             // idx = clamp(w + 21, 0, 42): 0 -> -40, 1..41 -> w+20, 42 -> +40; 43 -> -80
-        const int t = tid - 64;
-        lut[t] = (uint8_t)(t == 0 ? TOK_NEG : t <= 41 ? t - 1 : t == 42 ? TOK_POS : TOK_UNREACH);
     }
     __syncthreads();
 
     uint8_t *row = srow + wave * kRowImage;
     uint4 *bkt = reinterpret_cast<uint4 *>(sbkt + wave * kBktBytes);
-    uint32_t *cand = scand + wave * (kRowsInterleaved * 64);
+    uint16_t *list = slist + wave * (U * kListEntries);
+    uint16_t *cand = scand + wave * (U * CW);
     const int cells = H * W;
-    const int i0 = lane / kWin, j0 = lane - i0 * kWin;                  // window cell of this lane: index lane ...
-    const bool has1 = lane < kWin * kWin - 64;
-    const int l1 = has1 ? lane + 64 : lane;                             // ... and lane + 64 (lanes >= 57 repeat their first cell)
-    const int i1 = l1 / kWin, j1 = l1 - i1 * kWin;
-    const int off0 = (i0 - kR) * W + (j0 - kR), off1 = (i1 - kR) * W + (j1 - kR);
-    uint8_t *tok0_at = row + 1 + lane;
-    uint8_t *tok1_at = row + (has1 ? 65 + lane : kDumpTok + lane);
-    // lane bit and "lanes below me" masks for the bucket ranking
-    const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane < 32 ? 0u : 1u << (lane - 32);
-    const uint32_t lt_lo = lane < 32 ? bit_lo - 1u : 0xffffffffu, lt_hi = lane < 32 ? 0u : bit_hi - 1u;
+    // window cells of this lane: index lane and lane + 64 (lanes without one repeat cell 0 and store into the dump space)
+    const bool has0 = lane < ncell, has1 = lane + 64 < ncell;
+    const int c0 = has0 ? lane : 0, c1 = has1 ? lane + 64 : 0;
+    const int i0 = c0 / win, j0 = c0 - i0 * win, i1 = c1 / win, j1 = c1 - i1 * win;
+    const uint32_t off0 = (uint32_t)(i0 * W + j0), off1 = (uint32_t)(i1 * W + j1);
+    uint8_t *tok0_at = row + (has0 ? 1 + lane : kDumpTok + lane);
+    uint8_t *tok1_at = row + (has1 ? 65 + lane : kDumpTok + 64 + lane);
+    const int centre_lane = R * win + R;                                 // < 64 for every R <= 5
+    // emission: lane 16 u + s writes record s of row u
+    const int eu = lane >> 4, es = lane & 15;
+    uint8_t *rec_at = row + eu * kRowBytes + 1 + ncell + rec_len * es;
+    // the chunk's distance fields and token rows as buffer resources: row q of this wave sits (wave + 4 q) fields / rows in
+    const __amdgpu_buffer_rsrc_t rdist = make_rsrc(dist + (row0 + a_begin) * cells);      // 64 rows x H*W <= 2^22 cells x 2 B < 2 GiB
+    const __amdgpu_buffer_rsrc_t rtok = make_rsrc(tokens + (row0 + a_begin) * 256);
+    const uint32_t lane4 = (uint32_t)lane * 4u;
 
-    // the candidates' packed positions (lane + 64 k: the same agents for every row of the instance): read once per wave, not per row and pass
-    uint32_t cpos[KP];
+    // the candidates' biased packed positions (lane + 64 k: the same agents for every row of the instance) and their ids:
+    // read once per wave, not per row and pass
+    uint32_t cposr[KP], idk[KP];
 #pragma unroll
-    for (int k = 0; k < KP; k++) cpos[k] = spos[lane + 64 * k];
+    for (int k = 0; k < KP; k++) { cposr[k] = spos[lane + 64 * k]; idk[k] = (uint32_t)(lane + 64 * k); }
+    // constants of the row loop, pinned in registers (left alone, hipcc re-materialises each of them with v_mov per row)
+    uint32_t padv = pad4, zerov = 0u, nokeyv = kNoKey;
+    asm volatile("" : "+v"(padv), "+v"(zerov), "+v"(nokeyv));
+    // this wave's row headers: lane q holds row q's (lanes >= RPW repeat)
+    const uint2 hv = hdr[wave + 4 * (lane & (RPW - 1))];
+
     // Issue the window gathers of ALL rows this wave owns before touching any of them (bytes in flight).
-    // (Round 4: reading each row's record straight from global memory (scalar loads) so that the gathers start BEFORE the workgroup stages the
-    //  records into LDS -- one dependent round trip less -- is 7-13 % SLOWER at every launch size: the kernel issues, it does not wait.)
-    int w0[RPW], w1[RPW];
-    uint32_t my0s[RPW];
-    int state[RPW];
+    uint32_t w0[RPW], w1[RPW];
+    uint32_t my0s[RPW], infos[RPW];
 #pragma unroll
     for (int q = 0; q < RPW; q++) {
-        const int4 h = hdr[wave + 4 * q];
-        const uint32_t my0 = __builtin_amdgcn_readfirstlane(h.x);
-        const int centre = __builtin_amdgcn_readfirstlane(h.y);
-        const int st = __builtin_amdgcn_readfirstlane(h.z);
-        my0s[q] = my0; state[q] = st;
+        const uint32_t my0 = __builtin_amdgcn_readlane(hv.x, q);
+        const uint32_t info = __builtin_amdgcn_readlane(hv.y, q);
+        my0s[q] = my0; infos[q] = info;
         w0[q] = UNR; w1[q] = UNR;
-        const DT *d = dist + (row0 + a_begin + wave + 4 * q) * cells;
-        if (st > 0) {                                                   // wave-uniform; always taken for env states
-            w0[q] = (int)d[(uint32_t)(centre + off0)];
-            w1[q] = (int)d[(uint32_t)(centre + off1)];
-            if (__builtin_amdgcn_readfirstlane(h.w) != 0 && lane == kWin * kWin - 1 - 64) {
-                // rare (agent at offset (123, 123) of its cached window): the reference reaches this cell only from its two
-                // in-window neighbours, whose values are exact border seeds (cpp:252-268)
-                const int n1 = (int)d[(uint32_t)(centre + off1 - W)], n2 = (int)d[(uint32_t)(centre + off1 - 1)];
-                const int m = min(n1, n2);
-                // (one-byte field: UNR = 255, so m + 1 is kept below the sentinel; any value > centre + 20 encodes the same token)
-                if (w1[q] != UNR && w1[q] != 0) w1[q] = (m == UNR) ? UNR : min(m + 1, UNR - 1);
+        const uint32_t fld = (uint32_t)(wave + 4 * q) * (uint32_t)cells;   // this row's field inside the chunk (uniform)
+        if ((info >> 30) == 0) {                                        // wave-uniform; always taken for env states
+            const uint32_t org = fld + (info & 0x1fffffffu);            // the window's first cell (uniform)
+            w0[q] = field_load(rdist, off0, org, DT{});
+            w1[q] = field_load(rdist, off1, org, DT{});
+            if ((info & 0x20000000u) != 0 && lane == ((ncell - 1) & 63)) {
+                // rare (agent at offset (123, 123) of its cached window): the reference reaches the window's last cell only from its
+                // two in-window neighbours, whose values are exact border seeds (cpp:252-268)
+                const uint32_t oc = (uint32_t)((win - 1) * W + (win - 1));
+                const uint32_t n1 = field_load(rdist, oc - W, org, DT{}), n2 = field_load(rdist, oc - 1, org, DT{}), m = min(n1, n2);
+                uint32_t v = ncell - 1 < 64 ? w0[q] : w1[q];
+                // (one-byte field: UNR = 255, so m + 1 is kept below the sentinel; any value > centre + limit encodes the same token)
+                if (v != UNR && v != 0) v = (m == UNR) ? UNR : min(m + 1, UNR - 1);
+                if (ncell - 1 < 64) w0[q] = v; else w1[q] = v;
             }
-        } else if (st == 0) {                                           // out-of-frame cells read as walls
+        } else if ((info >> 31) == 0) {                                 // out-of-frame cells read as walls
             const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
-            const int rr0 = pr - kR + i0, cc0 = pc - kR + j0, rr1 = pr - kR + i1, cc1 = pc - kR + j1;
-            if (rr0 >= 0 && rr0 < H && cc0 >= 0 && cc0 < W) w0[q] = (int)d[rr0 * W + cc0];
-            if (rr1 >= 0 && rr1 < H && cc1 >= 0 && cc1 < W) w1[q] = (int)d[rr1 * W + cc1];
+            const int rr0 = pr - R + i0, cc0 = pc - R + j0, rr1 = pr - R + i1, cc1 = pc - R + j1;
+            if (rr0 >= 0 && rr0 < H && cc0 >= 0 && cc0 < W) w0[q] = field_load(rdist, (uint32_t)(rr0 * W + cc0), fld, DT{});
+            if (rr1 >= 0 && rr1 < H && cc1 >= 0 && cc1 < W) w1[q] = field_load(rdist, (uint32_t)(rr1 * W + cc1), fld, DT{});
         }
     }
-    // Rows are processed U at a time, phase by phase: a row's chain is ~8 dependent LDS round trips, so one row
-    // at a time leaves the wave waiting; U interleaved rows share every wait.
-    constexpr int U = kRowsInterleaved;
-    static_assert(RPW % U == 0, "RPW must be a multiple of U");
 #pragma unroll
     for (int q0 = 0; q0 < RPW; q0 += U) {
-        if (state[q0] < 0) break;                                       // wave-uniform: past the last agent
-        bool live[U];
-        bkt[lane] = make_uint4(0u, 0u, 0u, 0u);                         // entries 16u + d: distance bucket d of row u
-        int mdm[U];            // candidate of this lane for row u: Manhattan distance (11 = none) ...
-        int cid[U];            // ... and agent id
+        if ((infos[q0] >> 31) != 0) break;                              // wave-uniform: past the last agent
+        reinterpret_cast<uint2 *>(bkt)[2 * lane] = make_uint2(zerov, zerov);   // entries 16u + d: lane masks of distance bucket d of row u
+        list[lane] = (uint16_t)nokeyv;
+        uint32_t cid[U];       // candidate of this lane for row u: agent id ...
+        uint32_t cmd[U];       // ... its Manhattan distance ...
+        bool have[U];          // ... if any
         int ncand[U];          // KP > 1: number of neighbours found (wave-uniform)
         uint4 *mine[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            live[u] = state[q0 + u] >= 0;
             uint8_t *rw = row + u * kRowBytes;
-            const int v0 = w0[q0 + u], v1 = w1[q0 + u];
             const uint32_t my0 = my0s[q0 + u];
-            reinterpret_cast<uint2 *>(rw)[lane] = make_uint2(0x42424242u, 0x42424242u);   // "!" (66), cpp:375-376,386-387
+            reinterpret_cast<uint2 *>(rw)[lane] = make_uint2(padv, padv);
 
-            // --- window tokens (cpp:288-311 + encoder cpp:352-357) ---
-            int mid = __builtin_amdgcn_readlane(v0, kR * kWin + kR);    // centre cell, cpp:297
-            if (sizeof(DT) == 1 && mid == 255) mid = kUnreach;          // agent on a wall: same arithmetic as the 16-bit field
-            const int midp = mid - (kLimit + 1);
-            int x0 = min(max(v0 - midp, 0), 2 * kLimit + 2);            // -> v_med3_i32
-            int x1 = min(max(v1 - midp, 0), 2 * kLimit + 2);
-            x0 = (v0 == UNR) ? 2 * kLimit + 3 : x0;                     // cpp:308-309 (-80)
-            x1 = (v1 == UNR) ? 2 * kLimit + 3 : x1;
-            // token of x: 0 -> -40 (42), 1..41 -> x - 1, 42 -> +40 (43), 43 -> -80 (41).  Arithmetic instead of the LDS table of rounds 1-4: a
-            // table read cannot move in front of the byte stores of the row before (the same LDS array), so every row paid two dependent
-            // LDS round trips here (-3.6 % on the 524 160-row launch, profiles/r05_tokenizer_ablation.txt)
-            const int t0 = x0 == 0 ? TOK_NEG : x0 >= 2 * kLimit + 2 ? 127 - 2 * x0 : x0 - 1;
-            const int t1 = x1 == 0 ? TOK_NEG : x1 >= 2 * kLimit + 2 ? 127 - 2 * x1 : x1 - 1;
-            tok0_at[u * kRowBytes] = (uint8_t)t0;
-            tok1_at[u * kRowBytes] = (uint8_t)t1;
+            // --- window tokens (cpp:288-311 + vocabulary cpp:321-357), both cells of the lane as one packed pair ---
+            const uint32_t P = (w1[q0 + u] << 16) | w0[q0 + u];
+            uint32_t mid = __builtin_amdgcn_readlane(w0[q0 + u], centre_lane);          // centre cell, cpp:297
+            if (sizeof(DT) == 1 && mid == 255u) mid = kUnreach;                          // agent on a wall: same arithmetic as the 16-bit field
+            const int lo = (int)mid - (L + 1);                                           // x = v - lo, saturating both ways (uniform)
+            const uint32_t add2 = (uint32_t)max(-lo, 0) * 0x10001u, sub2 = (uint32_t)max(lo, 0) * 0x10001u;
+            us2 x = __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(as_us2(P), as_us2(add2)), as_us2(sub2));
+            x = __builtin_elementwise_min(x, as_us2(top2));                              // 0 .. 2L+2
+            // token of x: 0 -> "-2L" (2L+2), 1 .. 2L+1 -> x - 1, 2L+2 -> "+2L" (2L+3); unreachable -> "-4L" (2L+1)
+            us2 t = __builtin_elementwise_min(x - as_us2(one2), as_us2(top2));           // x = 0 wraps to 0xffff -> 2L+2
+            const us2 e = __builtin_elementwise_sub_sat(x, as_us2(topm2));               // 1 iff x = 2L+2
+            t = t + e + e;
+            const us2 isunr = (us2){0, 0} - __builtin_elementwise_sub_sat(as_us2(P), as_us2(unrm2));   // 0xffff iff v = UNR (cpp:308-309)
+            const uint32_t tt = (as_u32(isunr) & unrtok2) | (~as_u32(isunr) & as_u32(t));               // -> one bit-select
+            tok0_at[u * kRowBytes] = (uint8_t)tt;
+            tok1_at[u * kRowBytes] = (uint8_t)(tt >> 16);
 
-            // --- neighbours: the 11x11 scan of cpp:492-495 on the LDS-resident positions ---
+            // --- neighbours: the (2A+1)^2 scan of cpp:492-495 on the LDS-resident positions ---
             const uint32_t myb = my0 ^ 0x80008000u;
-            const us2 lo = __builtin_bit_cast(us2, myb) - (us2){kR, kR};
             ncand[u] = 0;
+            if (KP == 1) {                                                                // lane == agent id
+                const us2 t2 = as_us2(cposr[0]) - as_us2(myb);                            // (dr + A, dc + A) mod 2^16
+                have[u] = as_u32(__builtin_elementwise_max(t2, as_us2(diam2))) == diam2;
+                cid[u] = (uint32_t)lane;
+                cmd[u] = __builtin_amdgcn_sad_u16(cposr[0], myb + rad2, 0u);               // |dr| + |dc|, cpp:498-499
+            } else {
+                bool ink[KP];
+                unsigned long long bm[KP];
 #pragma unroll
-            for (int k = 0; k < KP; k++) {
-                const uint32_t bp = cpos[k];
-                const us2 t = __builtin_bit_cast(us2, bp) - lo;                              // (dr + 5, dc + 5) mod 2^16
-                const us2 mx = __builtin_elementwise_max(t, (us2){2 * kR, 2 * kR});
-                const bool in = __builtin_bit_cast(uint32_t, mx) == (uint32_t)(2 * kR) * 0x00010001u;
-                const int md = (int)__builtin_amdgcn_sad_u16(bp, myb, 0u);                    // |dr| + |dc|, cpp:498-499
-                if (KP == 1) {                                                                // lane == agent id
-                    mdm[u] = in ? md : 2 * kR + 1;
-                    cid[u] = lane;
-                } else {                                                                      // compact the neighbours, id order kept
-                    const unsigned long long bm = __builtin_amdgcn_ballot_w64(in);
-                    const int at = ncand[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
-                                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                    if (in && at < 64) cand[u * 64 + at] = ((uint32_t)md << 16) | (uint32_t)(lane + 64 * k);
-                    ncand[u] += __popcll(bm);
+                for (int k = 0; k < KP; k++) {
+                    const us2 t2 = as_us2(cposr[k]) - as_us2(myb);
+                    ink[k] = as_u32(__builtin_elementwise_max(t2, as_us2(diam2))) == diam2;
+                    bm[k] = __builtin_amdgcn_ballot_w64(ink[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < KP; k++) {                                            // compact the neighbours' ids, id order kept
+                    const int cnt = __popcll(bm[k]);
+                    const bool room = CW > 64 || ncand[u] + cnt <= 64;                    // uniform; KP <= 4: the area holds them all
+                    uint16_t *dstc = cand + u * CW + ncand[u];                            // uniform
+                    if (ink[k] && room)
+                        dstc[__builtin_amdgcn_mbcnt_hi((uint32_t)(bm[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm[k], 0u))] = (uint16_t)idk[k];
+                    ncand[u] += cnt;
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (KP > 1) {
+            wave_lds_sync();
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t key = cand[u * 64 + lane];
-                const bool have = lane < ncand[u] && ncand[u] <= 64;      // > 64 neighbours in one window: exact slow path below
-                mdm[u] = have ? (int)(key >> 16) : 2 * kR + 1;
-                cid[u] = (int)(key & 0xffffu);
+                cid[u] = cand[u * CW + lane];
+                have[u] = lane < ncand[u] && ncand[u] <= 64;      // > 64 neighbours in one window: exact slow path below
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t bpr = have[u] ? spos[cid[u]] : 0u;
+                cmd[u] = __builtin_amdgcn_sad_u16(bpr, (my0s[q0 + u] ^ 0x80008000u) + rad2, 0u);
             }
         }
         // --- rank = position in (Manhattan, id) order (cpp:500-506) = #candidates in lower distance buckets +
         //     #lower ids in the own bucket (candidate lanes are in id order) ---
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            mine[u] = bkt + u * 16 + mdm[u];
-            if (mdm[u] <= 2 * kR)       // divergent on purpose: same-address LDS atomics serialise, so only real neighbours issue one
-                __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(mine[u]), ((unsigned long long)bit_hi << 32) | bit_lo,
+            mine[u] = bkt + u * 16 + cmd[u];
+            if (have[u])                // divergent on purpose: same-address LDS atomics serialise, so only real neighbours issue one
+                __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(mine[u]), 1ull << lane,
                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);        // ds_or_b64, order-independent
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_sync();
         {   // lanes 16u .. 16u+11 prefix-sum the bucket populations of row u (DPP rows are 16 lanes wide)
-            const uint2 pop = *reinterpret_cast<const uint2 *>(bkt + (lane & (16 * U - 1)));
+            const uint2 pop = *reinterpret_cast<const uint2 *>(bkt + lane);
             const int c = __popc(pop.x) + __popc(pop.y);
             int incl = dpp_shr_add<0x111>(c);
             incl = dpp_shr_add<0x112>(incl);
             incl = dpp_shr_add<0x114>(incl);
             incl = dpp_shr_add<0x118>(incl);
-            reinterpret_cast<uint32_t *>(bkt + (lane & (16 * U - 1)))[2] = (uint32_t)(incl - c);   // #candidates in lower buckets
+            reinterpret_cast<uint32_t *>(bkt + lane)[2] = (uint32_t)(incl - c);   // #candidates in lower buckets
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // --- the first 13 write their 10-token record (cpp:352-373, 506-512) ---
+        wave_lds_sync();
+        // --- the first S leave their id at list[row][rank] (cpp:506) ---
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint4 e = *mine[u];
-            const int r = __popc(e.x & lt_lo) + __popc(e.y & lt_hi) + (int)e.z;
-            const int rank = mdm[u] <= 2 * kR ? r : kNoRank;
-            if (rank < kSlots)          // divergent on purpose: <= 13 active lanes make conflict-free LDS stores
-                emit_record(row + u * kRowBytes, rank, srec[cid[u]], my0s[q0 + u]);
+            if (have[u]) {
+                const uint4 e = *mine[u];
+                // lower buckets + the bucket's candidates in lanes below this one (v_mbcnt: the lane mask is implicit)
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi(e.y, __builtin_amdgcn_mbcnt_lo(e.x, e.z));
+                if (r < (uint32_t)p.S) list[u * kListEntries + r] = (uint16_t)cid[u];
+            }
         }
         if (KP > 1) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (ncand[u] <= 64) continue;                                   // wave-uniform
-                // Exact slow path (> 64 agents inside one 11x11 window, i.e. shared cells): walk the distance buckets over
-                // all passes, recomputing the tests; ranks are known as they are met.
-                const uint32_t my0 = my0s[q0 + u];
-                const uint32_t myb = my0 ^ 0x80008000u;
-                const us2 lo = __builtin_bit_cast(us2, myb) - (us2){kR, kR};
+                // Exact slow path (> 64 agents inside one window): walk the distance buckets over all passes,
+                // recomputing the tests; ranks are known as they are met.
+                const uint32_t myb = my0s[q0 + u] ^ 0x80008000u;
                 int placed = 0;
 #pragma unroll 1
-                for (int m = 0; m <= 2 * kR && placed < kSlots; m++) {
+                for (int m = 0; m <= 2 * A && placed < p.S; m++) {
 #pragma unroll 1
-                    for (int k = 0; k < KP && placed < kSlots; k++) {
-                        const uint32_t bp = spos[lane + 64 * k];
-                        const us2 t = __builtin_bit_cast(us2, bp) - lo;
-                        const us2 mx = __builtin_elementwise_max(t, (us2){2 * kR, 2 * kR});
-                        const bool hit = __builtin_bit_cast(uint32_t, mx) == (uint32_t)(2 * kR) * 0x00010001u &&
-                                         (int)__builtin_amdgcn_sad_u16(bp, myb, 0u) == m;
-                        const unsigned long long bm = __builtin_amdgcn_ballot_w64(hit);
-                        const int rank = placed + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
-                                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                        if (hit && rank < kSlots) emit_record(row + u * kRowBytes, rank, srec[lane + 64 * k], my0);
-                        placed += __popcll(bm);
+                    for (int k = 0; k < KP && placed < p.S; k++) {
+                        const uint32_t bpr = spos[lane + 64 * k];
+                        const us2 t2 = as_us2(bpr) - as_us2(myb);
+                        const bool hit = as_u32(__builtin_elementwise_max(t2, as_us2(diam2))) == diam2 &&
+                                         (int)__builtin_amdgcn_sad_u16(bpr, myb + rad2, 0u) == m;
+                        const unsigned long long bmh = __builtin_amdgcn_ballot_w64(hit);
+                        const int rank = placed + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bmh >> 32),
+                                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)bmh, 0u));
+                        if (hit && rank < p.S) list[u * kListEntries + rank] = (uint16_t)(lane + 64 * k);
+                        placed += __popcll(bmh);
                     }
                 }
             }
         }
-        // all LDS traffic above is issued by this wave in program order; make it visible to its own reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_sync();
+        // --- records of the U rows at once: lane 16 u + s = record s of row u (cpp:352-373, 506-512): rel pos (not clamped, within
+        //     +-A), rel goal clamped to +-L, the last Hn history tokens oldest first, greedy-direction bits ---
+        {
+            const uint32_t k16 = list[lane];
+            if (k16 != kNoKey) {
+                const uint4 o = srec[k16];
+                const uint32_t my0 = hdr[wave + 4 * (q0 + eu)].x;
+                const ss2 base = as_ss2(my0) - as_ss2(rep16(L));                               // pos - L
+                const ss2 rel = as_ss2(o.x) - base;                                            // (dr + L, dc + L)
+                ss2 rg = as_ss2(o.y) - base;
+                rg = __builtin_elementwise_min(__builtin_elementwise_max(rg, (ss2){0, 0}), as_ss2(rep16(2 * L)));
+                const uint32_t qa = __builtin_amdgcn_perm(as_u32(rg), as_u32(rel), 0x06040200u);   // {rel.r, rel.c, goal.r, goal.c}
+                if (p.Hn == 5) {                                                               // uniform; 2-byte aligned: 1 + ncell is even
+                    uint16_t *d16 = reinterpret_cast<uint16_t *>(rec_at);
+                    d16[0] = (uint16_t)qa; d16[1] = (uint16_t)(qa >> 16);
+                    d16[2] = (uint16_t)o.z; d16[3] = (uint16_t)(o.z >> 16);
+                    d16[4] = (uint16_t)o.w;
+                } else {
+                    // {hist0..4, next} as one 48-bit value, the oldest 5 - Hn tokens dropped
+                    const unsigned long long hn = (((unsigned long long)(o.w & 0xffffu) << 32) | o.z) >> (8 * (5 - p.Hn));
+                    rec_at[0] = (uint8_t)qa; rec_at[1] = (uint8_t)(qa >> 8); rec_at[2] = (uint8_t)(qa >> 16); rec_at[3] = (uint8_t)(qa >> 24);
+#pragma unroll
+                    for (int j = 0; j < 5; j++)
+                        if (j <= p.Hn) rec_at[4 + j] = (uint8_t)(hn >> (8 * j));
+                }
+            }
+        }
+        wave_lds_sync();
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            if (!live[u]) break;
+            if ((infos[q0 + u] >> 31) != 0) break;
             const uint32_t *row32 = reinterpret_cast<const uint32_t *>(row + u * kRowBytes);
             const uint32_t packed = __builtin_amdgcn_alignbyte(row32[lane + 1], row32[lane], 1);   // tokens 4*lane .. 4*lane+3
-            reinterpret_cast<uint32_t *>(tokens + (row0 + a_begin + wave + 4 * (q0 + u)) * 256)[lane] = packed;
+            __builtin_amdgcn_raw_buffer_store_b32(packed, rtok, lane4, (uint32_t)(wave + 4 * (q0 + u)) * 256u, 0);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -507,13 +597,13 @@ template <int KP, int RPW>
 __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict__ recs, const uint16_t *__restrict__ dist,
                                                      const uint8_t *__restrict__ dist8, const int *__restrict__ u8_ok,
                                                      int n_agents, int H, int W, int chunks_per_inst,
-                                                     uint8_t *__restrict__ tokens, int gstep)
+                                                     uint8_t *__restrict__ tokens, int gstep, const TokCfg cfg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (*u8_ok)                                                         // uniform
-        tokens_body<uint8_t, KP, RPW>(recs, dist8, n_agents, H, W, chunks_per_inst, tokens, smem, gstep);
+        tokens_body<uint8_t, KP, RPW>(recs, dist8, n_agents, H, W, chunks_per_inst, tokens, smem, gstep, cfg);
     else
-        tokens_body<uint16_t, KP, RPW>(recs, dist, n_agents, H, W, chunks_per_inst, tokens, smem, gstep);
+        tokens_body<uint16_t, KP, RPW>(recs, dist, n_agents, H, W, chunks_per_inst, tokens, smem, gstep, cfg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -682,6 +772,7 @@ __global__ __launch_bounds__(256) void ds_tokens_kernel(const AgentRec *__restri
 struct mgpt_tokenizer {
     int n_inst, n_agents, H, W, n_grids;
     int step = kDefaultStep;            // grid_step: side of the reference's cost-to-go tiles (decides the unseeded window corner)
+    TokCfg cfg = {kLimit, kSlots, 5, kR, kR};
     uint8_t *grids = nullptr;
     uint16_t *dist = nullptr;
     uint8_t *dist8 = nullptr;
@@ -697,10 +788,22 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
     MGPT_REQUIRE(out && cfg, MGPT_ERR_ARG, "NULL argument");
     MGPT_REQUIRE(n_inst > 0 && n_agents > 0 && H > 0 && W > 0 && n_grids > 0 && n_grids <= n_inst, MGPT_ERR_ARG,
                  "bad sizes n_inst=%d n_agents=%d H=%d W=%d n_grids=%d", n_inst, n_agents, H, W, n_grids);
-    MGPT_REQUIRE(cfg->cost2go_value_limit == kLimit && cfg->num_agents == kSlots && cfg->num_previous_actions == 5 &&
-                     cfg->context_size == MGPT_CONTEXT && cfg->obs_radius == kR && cfg->agents_radius == kR,
+    // InputParameters (h:22-40).  What the kernels' layouts bound: ids below 256 (2L + 26 <= 255), AgentRec::hist (five tokens),
+    // two window cells per lane ((2R+1)^2 <= 128), twelve distance buckets (2A <= 10), sixteen emission lanes per row, and a
+    // row of exactly 256 tokens (cpp:386-387 pads to 256 whatever context_size says; a longer row has no place in this ABI).
+    // agents_radius > cost2go_value_limit makes the reference itself throw (int_vocab.at of a relative position, cpp:358-359).
+    MGPT_REQUIRE(cfg->context_size == MGPT_CONTEXT, MGPT_ERR_UNSUPPORTED, "context_size=%d: rows are %d tokens (cpp:386)",
+                 cfg->context_size, MGPT_CONTEXT);
+    MGPT_REQUIRE(cfg->cost2go_value_limit >= 1 && cfg->cost2go_value_limit <= 100 && cfg->num_agents >= 1 && cfg->num_agents <= 16 &&
+                     cfg->num_previous_actions >= 0 && cfg->num_previous_actions <= 5 && cfg->obs_radius >= 1 && cfg->obs_radius <= 5 &&
+                     cfg->agents_radius >= 0 && cfg->agents_radius <= 5 && cfg->agents_radius <= cfg->cost2go_value_limit,
                  MGPT_ERR_UNSUPPORTED,
-                 "only the reference's InputParameters (20,13,5,256,5,5) are implemented (inference.py:15-29)");
+                 "InputParameters (limit %d, agents %d, previous actions %d, obs radius %d, agents radius %d) outside the implemented ranges "
+                 "(1..100, 1..16, 0..5, 1..5, 0..min(5, limit))",
+                 cfg->cost2go_value_limit, cfg->num_agents, cfg->num_previous_actions, cfg->obs_radius, cfg->agents_radius);
+    MGPT_REQUIRE((2 * cfg->obs_radius + 1) * (2 * cfg->obs_radius + 1) + cfg->num_agents * (5 + cfg->num_previous_actions) <= MGPT_CONTEXT,
+                 MGPT_ERR_UNSUPPORTED, "window %d + %d records of %d tokens do not fit a %d-token row",
+                 (2 * cfg->obs_radius + 1) * (2 * cfg->obs_radius + 1), cfg->num_agents, 5 + cfg->num_previous_actions, MGPT_CONTEXT);
     MGPT_REQUIRE(cfg->grid_step > 0, MGPT_ERR_ARG, "grid_step=%d", cfg->grid_step);
     // the per-agent window origin is kept as (row / grid_step, col / grid_step) in one byte each
     MGPT_REQUIRE((int64_t)256 * cfg->grid_step >= H && (int64_t)256 * cfg->grid_step >= W, MGPT_ERR_UNSUPPORTED,
@@ -713,6 +816,7 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
     mgpt_tokenizer *t = new mgpt_tokenizer();
     t->n_inst = n_inst; t->n_agents = n_agents; t->H = H; t->W = W; t->n_grids = n_grids;
     t->step = cfg->grid_step;
+    t->cfg = TokCfg{cfg->cost2go_value_limit, cfg->num_agents, cfg->num_previous_actions, cfg->obs_radius, cfg->agents_radius};
     const size_t cells = (size_t)H * W, total = (size_t)n_inst * n_agents;
     hipError_t e = hipMalloc(&t->grids, (size_t)n_grids * cells);
     if (e == hipSuccess) e = hipMalloc(&t->dist, total * cells * sizeof(uint16_t));
@@ -772,14 +876,14 @@ extern "C" int mgpt_tokenizer_create_agents(mgpt_tokenizer *t, const int16_t *d_
     {
         ProfScope ps(P_TOK_UPDATE, s);
         hipLaunchKernelGGL(tok_create_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, d_pos, d_goal, total,
-                           t->u8_ok, t->step);
+                           t->u8_ok, t->step, t->cfg);
         MGPT_LAUNCH_CHECK();
     }
     int rc = launch_bfs(t, nullptr, s);
     if (rc != MGPT_OK) return rc;
     {
         ProfScope ps(P_TOK_NEXT, s);
-        hipLaunchKernelGGL(tok_next_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, total, t->dist, t->H, t->W);
+        hipLaunchKernelGGL(tok_next_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, total, t->dist, t->H, t->W, t->cfg.tok_bits0());
         MGPT_LAUNCH_CHECK();
     }
     t->have_agents = true;
@@ -803,14 +907,14 @@ extern "C" int mgpt_tokenizer_update_agents_masked(mgpt_tokenizer *t, const int1
     {
         ProfScope ps(P_TOK_UPDATE, s);
         hipLaunchKernelGGL(tok_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, d_pos, d_goal, d_actions,
-                           t->dirty, total, goals_may_change ? 1 : 0, t->dist, t->H, t->W, t->step, d_active, t->n_agents);
+                           t->dirty, total, goals_may_change ? 1 : 0, t->dist, t->H, t->W, t->step, d_active, t->n_agents, t->cfg);
         MGPT_LAUNCH_CHECK();
     }
     if (goals_may_change) {
         int rc = launch_bfs(t, t->dirty, s);
         if (rc != MGPT_OK) return rc;
         ProfScope ps(P_TOK_NEXT, s);
-        hipLaunchKernelGGL(tok_next_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, total, t->dist, t->H, t->W);
+        hipLaunchKernelGGL(tok_next_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, total, t->dist, t->H, t->W, t->cfg.tok_bits0());
         MGPT_LAUNCH_CHECK();
     }
     return MGPT_OK;
@@ -822,28 +926,30 @@ extern "C" int mgpt_tokenizer_generate_observations(mgpt_tokenizer *t, uint8_t *
     MGPT_REQUIRE(t->have_agents, MGPT_ERR_STATE, "create_agents must precede generate_observations");
     hipStream_t s = (hipStream_t)stream;
     const int kp = cdiv(t->n_agents, 64);
-    const int kpp = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 8 ? 8 : kp <= 16 ? 16 : 32;
+    const int kpp = kp <= 4 ? kp : kp <= 8 ? 8 : kp <= 16 ? 16 : 32;
     // rows per wavefront: 16 (more bytes in flight, records staged once per 64 rows) when the launch still fills the GPU
     const bool big = (int64_t)t->n_inst * cdiv(t->n_agents, 64) >= 4096;
     // (round 4, tools/tok_cfg4_time.py: 8 rows per wavefront -- every wave resident in ONE generation on cfg4's 65 536-row launch --
     //  is not faster, 22.9 vs 21.2 us: the kernel is instruction-issue bound, ~15.5 us per 65 536 rows of 128 agents + ~5.5 us fixed)
     const int apb = big ? 64 : 16;
     const int chunks = cdiv(t->n_agents, apb);
-    const size_t smem = kLutBytes + (size_t)apb * 16 + (size_t)t->n_agents * 16 + (size_t)kpp * 64 * 4 + 4 * kRowImage +
-                        4 * kBktBytes + (kpp == 1 ? 0 : 4 * kRowsInterleaved * 64 * 4);
+    const int cw = kpp == 1 ? 0 : (kpp <= 4 ? 64 * kpp : 64);                      // CandWidth<KP>
+    const size_t smem = (size_t)apb * 8 + (size_t)t->n_agents * 16 + (size_t)kpp * 64 * 4 + 4 * kRowImage + 4 * kBktBytes +
+                        4 * kRowsInterleaved * kListEntries * 2 + (size_t)4 * kRowsInterleaved * cw * 2;
     ProfScope ps(P_TOKENS, s);
 #define MGPT_TOKENS(KP_)                                                                                              \
     do {                                                                                                              \
         if (big)                                                                                                      \
             hipLaunchKernelGGL((tokens_kernel<KP_, 16>), dim3(t->n_inst * chunks), dim3(256), smem, s, t->recs, t->dist, \
-                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step);               \
+                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step, t->cfg);       \
         else                                                                                                          \
             hipLaunchKernelGGL((tokens_kernel<KP_, 4>), dim3(t->n_inst * chunks), dim3(256), smem, s, t->recs, t->dist, \
-                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step);               \
+                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step, t->cfg);       \
     } while (0)
     switch (kpp) {
     case 1: MGPT_TOKENS(1); break;
     case 2: MGPT_TOKENS(2); break;
+    case 3: MGPT_TOKENS(3); break;
     case 4: MGPT_TOKENS(4); break;
     case 8: MGPT_TOKENS(8); break;
     case 16: MGPT_TOKENS(16); break;
