@@ -16,6 +16,8 @@
 //   ds_* kernels      dataset-side bulk tokenizer (dataset/tokenizer/*): all-pairs BFS table per map, one row per
 //                     (agent, timestep) of a logged episode
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 using namespace mgpt;
 
@@ -48,6 +50,7 @@ struct TokCfg {
     int Hn;     // num_previous_actions (<= 5: AgentRec::hist keeps the last five)
     int R;      // obs_radius (<= 5: two window cells per lane)
     int A;      // agents_radius (<= 5: twelve distance buckets)
+    int rwin;   // 65536 / (2R + 1) + 1: cell index / window side = (index * rwin) >> 16, exact below 128 (checked at create)
     __host__ __device__ int tok_n() const { return 2 * L + 4; }
     __host__ __device__ int tok_bits0() const { return 2 * L + 10; }
 };
@@ -291,26 +294,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ uint32_t field_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint8_t)
+// one cell of a distance field: the one-byte field (255 = wall / unreached) while every finite distance fits it, else the 16-bit one
+// (65535); everything after the load is the same packed 16-bit arithmetic with another sentinel
+template <bool U8>
+__device__ __forceinline__ uint32_t field_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
-    return __builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
-}
-__device__ __forceinline__ uint32_t field_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint16_t)
-{
-    return __builtin_amdgcn_raw_buffer_load_b16(r, 2 * voff, 2 * soff, 0);
+    if constexpr (U8) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+    else return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, 2 * voff, 2 * soff, 0);
 }
 
-template <class DT, int KP, int RPW>
-__device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, const DT *__restrict__ dist, int n_agents,
-                                            int H, int W, int chunks_per_inst, uint8_t *__restrict__ tokens, char *smem, int gstep,
-                                            const TokCfg p)
+template <int KP, int RPW>
+__global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict__ recs, const uint16_t *__restrict__ dist,
+                                                     const uint8_t *__restrict__ dist8, const int *__restrict__ u8_ok,
+                                                     int n_agents, int H, int W, int chunks_per_inst,
+                                                     uint8_t *__restrict__ tokens, int gstep, const TokCfg p)
 {
-    constexpr unsigned UNR = sizeof(DT) == 1 ? 255u : (unsigned)kUnreach;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (read here, consumed at the window gathers: the flag's round trip overlaps the record loads below.  Rounds 1-5 branched on it
+    //  into two copies of the body -- one dependent memory round trip in front of everything a workgroup does)
+    const bool u8 = *u8_ok != 0;
+    const unsigned UNR = u8 ? 255u : (unsigned)kUnreach;
     constexpr int APB = 4 * RPW;
     constexpr int U = kRowsInterleaved;
     constexpr int CW = CandWidth<KP>::value;
     static_assert(RPW % U == 0, "RPW must be a multiple of U");
-    uint2 *hdr = reinterpret_cast<uint2 *>(smem);                                          // [APB] {packed position, window origin | flags}
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(smem);                                    // [4][RPW] packed position of a wave's rows
     uint4 *srec = reinterpret_cast<uint4 *>(smem + APB * 8);                               // [n_agents]
     uint32_t *spos = reinterpret_cast<uint32_t *>(smem + APB * 8 + (size_t)n_agents * 16); // [KP*64] biased (r,c) + agents radius
     uint8_t *srow = reinterpret_cast<uint8_t *>(spos + KP * 64);                           // [4][kRowImage]
@@ -321,45 +329,44 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
     const int R = p.R, A = p.A, L = p.L;
     const int win = 2 * R + 1, ncell = win * win, rec_len = 5 + p.Hn;
     const int top = 2 * L + 2;                          // window arithmetic: x = clamp(v - mid + L + 1, 0, 2L + 2)
-    const uint32_t top2 = rep16(top), topm2 = rep16(top - 1), one2 = 0x00010001u;
+    const uint32_t top2 = rep16(top), topm2 = rep16(top - 1), one2 = 0x00010001u, lp1_2 = rep16(L + 1);
     const uint32_t unrm2 = rep16((int)UNR - 1), unrtok2 = rep16(2 * L + 1);
     const uint32_t pad4 = (uint32_t)(2 * L + 26) * 0x01010101u;          // "!" (cpp:375-376,386-387)
     const uint32_t rad2 = rep16(A), diam2 = rep16(2 * A);
 
-    const int inst = blockIdx.x / chunks_per_inst;
-    const int chunk = blockIdx.x - inst * chunks_per_inst;
+    const int inst = blockIdx.x, chunk = blockIdx.y;    // (a 2-D grid: no division)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t row0 = (size_t)inst * n_agents;
     const uint4 *grec = reinterpret_cast<const uint4 *>(recs) + row0;
     const int a_begin = chunk * APB;
 
-    for (int i = tid; i < KP * 64; i += 256) {
-        uint32_t bp = 0xffffffffu;                       // sentinel: never inside a window (H, W <= 16384)
-        if (i < n_agents) {
-            const uint4 r = grec[i];                     // {pr|pc<<16, gr|gc<<16, hist0..3, hist4|next<<8|org<<16}
-            srec[i] = r;
-            bp = r.x ^ 0x80008000u;                      // int16 -> order-preserving uint16
-        }
-        spos[i] = as_u32(as_us2(bp) + as_us2(rad2));     // + (A, A): the test below is then (candidate - me) <= 2A per half
-    }
-    if (tid < APB) {                                     // per-row scalars, prepared once
-        const int a = a_begin + tid;
-        uint2 h = make_uint2(0u, 0x80000000u);           // bit 31: no such agent
-        if (a < n_agents) {
-            const uint4 me = grec[a];
+    // This wave's rows first: lane q reads the record of row q (agent a_begin + wave + 4 q) straight from memory, so that the window
+    // gathers below start one round trip earlier than the records staged for the neighbour search (which every row of the chunk shares)
+    uint2 hv = make_uint2(0u, 0x80000000u);              // {packed position, window origin | flags}; bit 31: no such agent
+    {
+        const int a = a_begin + wave + 4 * (lane & (RPW - 1));
+        const uint4 me = grec[min(a, n_agents - 1)];     // (one unconditional 16-byte load: under the condition hipcc split it into two dependent ones)
+        {   // (branch-free, 24-bit multiplies: this block runs once per wave, but a wave owns only RPW rows)
             const uint32_t my0 = me.x;
             const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
             const bool inside = pr >= R && pr + R < H && pc >= R && pc + R < W;       // whole window inside the frame
             // is the unseeded corner of the agent's cached partial window (cpp:178-198) the window's last cell?
-            const int cr = gstep * (int)((me.w >> 16) & 0xffu) + 2 * gstep, cc = gstep * (int)(me.w >> 24) + 2 * gstep;
+            const int cr = __mul24(gstep, (int)((me.w >> 16) & 0xffu) + 2), cc = __mul24(gstep, (int)(me.w >> 24) + 2);
             const bool corner = cr <= H - 1 && cc <= W - 1 && pr + R == cr && pc + R == cc;
             // bits 0..28: offset of the window's first cell in the field (H * W <= 2^22); bit 30: window not wholly inside; bit 29: corner
-            h = make_uint2(my0, inside ? (uint32_t)((pr - R) * W + (pc - R)) | (corner ? 0x20000000u : 0u) : 0x40000000u);
+            const uint32_t org = (uint32_t)(__mul24(pr - R, W) + (pc - R)) | (corner ? 0x20000000u : 0u);
+            hv = make_uint2(my0, a < n_agents ? (inside ? org : 0x40000000u) : 0x80000000u);
         }
-        hdr[tid] = h;
     }
-    __syncthreads();
+    uint4 stage[(KP * 64 + 255) / 256];                  // the instance's records, on their way to LDS
+#pragma unroll
+    for (int j = 0; j < (KP * 64 + 255) / 256; j++) {
+        const int i = tid + 256 * j;
+        stage[j] = make_uint4(0x7fff7fffu, 0u, 0u, 0u);  // sentinel position: never inside a window (H, W <= 16384)
+        if (i < n_agents) stage[j] = grec[i];            // {pr|pc<<16, gr|gc<<16, hist0..3, hist4|next<<8|org<<16}
+    }
+    if (lane < RPW) hdr[wave * RPW + lane] = hv.x;       // (read back by this wave's emission lanes only)
 
     uint8_t *row = srow + wave * kRowImage;
     uint4 *bkt = reinterpret_cast<uint4 *>(sbkt + wave * kBktBytes);
@@ -369,8 +376,8 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
     // window cells of this lane: index lane and lane + 64 (lanes without one repeat cell 0 and store into the dump space)
     const bool has0 = lane < ncell, has1 = lane + 64 < ncell;
     const int c0 = has0 ? lane : 0, c1 = has1 ? lane + 64 : 0;
-    const int i0 = c0 / win, j0 = c0 - i0 * win, i1 = c1 / win, j1 = c1 - i1 * win;
-    const uint32_t off0 = (uint32_t)(i0 * W + j0), off1 = (uint32_t)(i1 * W + j1);
+    const int i0 = __mul24(c0, p.rwin) >> 16, j0 = c0 - __mul24(i0, win), i1 = __mul24(c1, p.rwin) >> 16, j1 = c1 - __mul24(i1, win);
+    const uint32_t off0 = (uint32_t)(__mul24(i0, W) + j0), off1 = (uint32_t)(__mul24(i1, W) + j1);
     uint8_t *tok0_at = row + (has0 ? 1 + lane : kDumpTok + lane);
     uint8_t *tok1_at = row + (has1 ? 65 + lane : kDumpTok + 64 + lane);
     const int centre_lane = R * win + R;                                 // < 64 for every R <= 5
@@ -378,55 +385,83 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
     const int eu = lane >> 4, es = lane & 15;
     uint8_t *rec_at = row + eu * kRowBytes + 1 + ncell + rec_len * es;
     // the chunk's distance fields and token rows as buffer resources: row q of this wave sits (wave + 4 q) fields / rows in
-    const __amdgpu_buffer_rsrc_t rdist = make_rsrc(dist + (row0 + a_begin) * cells);      // 64 rows x H*W <= 2^22 cells x 2 B < 2 GiB
+    const __amdgpu_buffer_rsrc_t rd8 = make_rsrc(dist8 + (row0 + a_begin) * cells);       // 64 rows x H*W <= 2^22 cells ...
+    const __amdgpu_buffer_rsrc_t rd16 = make_rsrc(dist + (row0 + a_begin) * cells);       // ... x 2 B < 2 GiB
     const __amdgpu_buffer_rsrc_t rtok = make_rsrc(tokens + (row0 + a_begin) * 256);
     const uint32_t lane4 = (uint32_t)lane * 4u;
 
+    // constants of the row loop, pinned in registers (left alone, hipcc re-materialises each of them with v_mov per row)
+    uint32_t padv = pad4, zerov = 0u, nokeyv = kNoKey;
+    asm volatile("" : "+v"(padv), "+v"(zerov), "+v"(nokeyv));
+
+    // Window gathers: the first two groups of U rows before anything else, then one group ahead of the group being processed.
+    // (Measured, profiles/r06_tokenizer_rpw.txt: all 16 rows of a wave up front -- rounds 1-5 -- makes a launch whose workgroups are
+    //  all resident at once spend memory + arithmetic instead of their maximum, 46 against 35 us per 131 072 rows of 128 agents; one
+    //  group ahead only costs the large launches 3 %; 8 rows per wave with both groups up front is the fastest large-launch form.)
+    uint32_t w0[RPW], w1[RPW];
+    uint32_t my0s[RPW], infos[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; q++) {
+        my0s[q] = __builtin_amdgcn_readlane(hv.x, q);
+        infos[q] = __builtin_amdgcn_readlane(hv.y, q);
+    }
+    auto gather = [&](auto u8_c, const __amdgpu_buffer_rsrc_t rd, auto g_c) {
+        constexpr bool U8 = decltype(u8_c)::value;
+        constexpr unsigned UNRC = U8 ? 255u : (unsigned)kUnreach;
+        constexpr int QB = decltype(g_c)::value;
+#pragma unroll
+        for (int q = QB; q < QB + U; q++) {
+            const uint32_t my0 = my0s[q], info = infos[q];
+            w0[q] = UNRC; w1[q] = UNRC;
+            const uint32_t fld = (uint32_t)(wave + 4 * q) * (uint32_t)cells;   // this row's field inside the chunk (uniform)
+            if ((info >> 30) == 0) {                                        // wave-uniform; always taken for env states
+                const uint32_t org = fld + (info & 0x1fffffffu);            // the window's first cell (uniform)
+                w0[q] = field_load<U8>(rd, off0, org);
+                w1[q] = field_load<U8>(rd, off1, org);
+                if ((info & 0x20000000u) != 0 && lane == ((ncell - 1) & 63)) {
+                    // rare (agent at offset (123, 123) of its cached window): the reference reaches the window's last cell only from its
+                    // two in-window neighbours, whose values are exact border seeds (cpp:252-268)
+                    const uint32_t oc = (uint32_t)((win - 1) * W + (win - 1));
+                    const uint32_t n1 = field_load<U8>(rd, oc - W, org), n2 = field_load<U8>(rd, oc - 1, org), m = min(n1, n2);
+                    uint32_t v = ncell - 1 < 64 ? w0[q] : w1[q];
+                    // (one-byte field: UNR = 255, so m + 1 is kept below the sentinel; any value > centre + limit encodes the same token)
+                    if (v != UNRC && v != 0) v = (m == UNRC) ? UNRC : min(m + 1, UNRC - 1);
+                    if (ncell - 1 < 64) w0[q] = v; else w1[q] = v;
+                }
+            } else if ((info >> 31) == 0) {                                 // out-of-frame cells read as walls
+                const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
+                const int rr0 = pr - R + i0, cc0 = pc - R + j0, rr1 = pr - R + i1, cc1 = pc - R + j1;
+                if (rr0 >= 0 && rr0 < H && cc0 >= 0 && cc0 < W) w0[q] = field_load<U8>(rd, (uint32_t)(rr0 * W + cc0), fld);
+                if (rr1 >= 0 && rr1 < H && cc1 >= 0 && cc1 < W) w1[q] = field_load<U8>(rd, (uint32_t)(rr1 * W + cc1), fld);
+            }
+        }
+    };
+    auto gather_group = [&](auto g_c) {
+        if (u8) gather(std::true_type{}, rd8, g_c);      // uniform
+        else gather(std::false_type{}, rd16, g_c);
+    };
+    gather_group(std::integral_constant<int, 0>{});
+    if constexpr (RPW >= 8) {
+        if ((infos[U] >> 31) == 0) gather_group(std::integral_constant<int, U>{});
+    }
+    // the instance's records and biased positions for the neighbour search (every wave's gathers are in flight by now)
+#pragma unroll
+    for (int j = 0; j < (KP * 64 + 255) / 256; j++) {
+        const int i = tid + 256 * j;
+        if (i < n_agents) srec[i] = stage[j];
+        if (i < KP * 64)                                 // + (A, A): the test below is then (candidate - me) <= 2A per half
+            spos[i] = as_u32(as_us2(stage[j].x ^ 0x80008000u) + as_us2(rad2));     // int16 -> order-preserving uint16
+    }
+    __syncthreads();
     // the candidates' biased packed positions (lane + 64 k: the same agents for every row of the instance) and their ids:
     // read once per wave, not per row and pass
     uint32_t cposr[KP], idk[KP];
 #pragma unroll
     for (int k = 0; k < KP; k++) { cposr[k] = spos[lane + 64 * k]; idk[k] = (uint32_t)(lane + 64 * k); }
-    // constants of the row loop, pinned in registers (left alone, hipcc re-materialises each of them with v_mov per row)
-    uint32_t padv = pad4, zerov = 0u, nokeyv = kNoKey;
-    asm volatile("" : "+v"(padv), "+v"(zerov), "+v"(nokeyv));
-    // this wave's row headers: lane q holds row q's (lanes >= RPW repeat)
-    const uint2 hv = hdr[wave + 4 * (lane & (RPW - 1))];
-
-    // Issue the window gathers of ALL rows this wave owns before touching any of them (bytes in flight).
-    uint32_t w0[RPW], w1[RPW];
-    uint32_t my0s[RPW], infos[RPW];
-#pragma unroll
-    for (int q = 0; q < RPW; q++) {
-        const uint32_t my0 = __builtin_amdgcn_readlane(hv.x, q);
-        const uint32_t info = __builtin_amdgcn_readlane(hv.y, q);
-        my0s[q] = my0; infos[q] = info;
-        w0[q] = UNR; w1[q] = UNR;
-        const uint32_t fld = (uint32_t)(wave + 4 * q) * (uint32_t)cells;   // this row's field inside the chunk (uniform)
-        if ((info >> 30) == 0) {                                        // wave-uniform; always taken for env states
-            const uint32_t org = fld + (info & 0x1fffffffu);            // the window's first cell (uniform)
-            w0[q] = field_load(rdist, off0, org, DT{});
-            w1[q] = field_load(rdist, off1, org, DT{});
-            if ((info & 0x20000000u) != 0 && lane == ((ncell - 1) & 63)) {
-                // rare (agent at offset (123, 123) of its cached window): the reference reaches the window's last cell only from its
-                // two in-window neighbours, whose values are exact border seeds (cpp:252-268)
-                const uint32_t oc = (uint32_t)((win - 1) * W + (win - 1));
-                const uint32_t n1 = field_load(rdist, oc - W, org, DT{}), n2 = field_load(rdist, oc - 1, org, DT{}), m = min(n1, n2);
-                uint32_t v = ncell - 1 < 64 ? w0[q] : w1[q];
-                // (one-byte field: UNR = 255, so m + 1 is kept below the sentinel; any value > centre + limit encodes the same token)
-                if (v != UNR && v != 0) v = (m == UNR) ? UNR : min(m + 1, UNR - 1);
-                if (ncell - 1 < 64) w0[q] = v; else w1[q] = v;
-            }
-        } else if ((info >> 31) == 0) {                                 // out-of-frame cells read as walls
-            const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
-            const int rr0 = pr - R + i0, cc0 = pc - R + j0, rr1 = pr - R + i1, cc1 = pc - R + j1;
-            if (rr0 >= 0 && rr0 < H && cc0 >= 0 && cc0 < W) w0[q] = field_load(rdist, (uint32_t)(rr0 * W + cc0), fld, DT{});
-            if (rr1 >= 0 && rr1 < H && cc1 >= 0 && cc1 < W) w1[q] = field_load(rdist, (uint32_t)(rr1 * W + cc1), fld, DT{});
-        }
-    }
-#pragma unroll
-    for (int q0 = 0; q0 < RPW; q0 += U) {
-        if ((infos[q0] >> 31) != 0) break;                              // wave-uniform: past the last agent
+    auto group = [&](auto q0_c) -> bool {
+        constexpr int q0 = decltype(q0_c)::value;
+        if ((infos[q0] >> 31) != 0) return false;                       // wave-uniform: past the last agent
+        if constexpr (q0 + 2 * U < RPW) gather_group(std::integral_constant<int, q0 + 2 * U>{});
         reinterpret_cast<uint2 *>(bkt)[2 * lane] = make_uint2(zerov, zerov);   // entries 16u + d: lane masks of distance bucket d of row u
         list[lane] = (uint16_t)nokeyv;
         uint32_t cid[U];       // candidate of this lane for row u: agent id ...
@@ -443,10 +478,10 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
             // --- window tokens (cpp:288-311 + vocabulary cpp:321-357), both cells of the lane as one packed pair ---
             const uint32_t P = (w1[q0 + u] << 16) | w0[q0 + u];
             uint32_t mid = __builtin_amdgcn_readlane(w0[q0 + u], centre_lane);          // centre cell, cpp:297
-            if (sizeof(DT) == 1 && mid == 255u) mid = kUnreach;                          // agent on a wall: same arithmetic as the 16-bit field
-            const int lo = (int)mid - (L + 1);                                           // x = v - lo, saturating both ways (uniform)
-            const uint32_t add2 = (uint32_t)max(-lo, 0) * 0x10001u, sub2 = (uint32_t)max(lo, 0) * 0x10001u;
-            us2 x = __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(as_us2(P), as_us2(add2)), as_us2(sub2));
+            if (mid == UNR) mid = kUnreach;                                              // agent on a wall: the 16-bit field's arithmetic
+            // x = (v + L + 1) - mid, saturating both ways (the add overflows only for 16-bit values that clamp to the top anyway)
+            const unsigned short mid16 = (unsigned short)mid;
+            us2 x = __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(as_us2(P), as_us2(lp1_2)), (us2){mid16, mid16});
             x = __builtin_elementwise_min(x, as_us2(top2));                              // 0 .. 2L+2
             // token of x: 0 -> "-2L" (2L+2), 1 .. 2L+1 -> x - 1, 2L+2 -> "+2L" (2L+3); unreachable -> "-4L" (2L+1)
             us2 t = __builtin_elementwise_min(x - as_us2(one2), as_us2(top2));           // x = 0 wraps to 0xffff -> 2L+2
@@ -468,10 +503,14 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
             } else {
                 bool ink[KP];
                 unsigned long long bm[KP];
+                us2 t2[KP];                                                               // (stage by stage: back-to-back dependent packed
+#pragma unroll                                                                            //  operations cost a wait state each)
+                for (int k = 0; k < KP; k++) t2[k] = as_us2(cposr[k]) - as_us2(myb);
+#pragma unroll
+                for (int k = 0; k < KP; k++) t2[k] = __builtin_elementwise_max(t2[k], as_us2(diam2));
 #pragma unroll
                 for (int k = 0; k < KP; k++) {
-                    const us2 t2 = as_us2(cposr[k]) - as_us2(myb);
-                    ink[k] = as_u32(__builtin_elementwise_max(t2, as_us2(diam2))) == diam2;
+                    ink[k] = as_u32(t2[k]) == diam2;
                     bm[k] = __builtin_amdgcn_ballot_w64(ink[k]);
                 }
 #pragma unroll
@@ -494,7 +533,8 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t bpr = have[u] ? spos[cid[u]] : 0u;
+                // (lanes without a candidate read some word of the workgroup's LDS: the mask keeps a stale id inside it)
+                const uint32_t bpr = spos[cid[u] & (uint32_t)((KP == 3 ? 4 : KP) * 64 - 1)];
                 cmd[u] = __builtin_amdgcn_sad_u16(bpr, (my0s[q0 + u] ^ 0x80008000u) + rad2, 0u);
             }
         }
@@ -560,7 +600,7 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
             const uint32_t k16 = list[lane];
             if (k16 != kNoKey) {
                 const uint4 o = srec[k16];
-                const uint32_t my0 = hdr[wave + 4 * (q0 + eu)].x;
+                const uint32_t my0 = hdr[wave * RPW + q0 + eu];
                 const ss2 base = as_ss2(my0) - as_ss2(rep16(L));                               // pos - L
                 const ss2 rel = as_ss2(o.x) - base;                                            // (dr + L, dc + L)
                 ss2 rg = as_ss2(o.y) - base;
@@ -590,20 +630,15 @@ __device__ __forceinline__ void tokens_body(const AgentRec *__restrict__ recs, c
             __builtin_amdgcn_raw_buffer_store_b32(packed, rtok, lane4, (uint32_t)(wave + 4 * (q0 + u)) * 256u, 0);
         }
         __builtin_amdgcn_wave_barrier();
+        return true;
+    };
+    static_assert(RPW == 4 || RPW == 8 || RPW == 16, "rows per wavefront");
+    if (!group(std::integral_constant<int, 0>{})) return;
+    if constexpr (RPW >= 8) { if (!group(std::integral_constant<int, 4>{})) return; }
+    if constexpr (RPW >= 16) {
+        if (!group(std::integral_constant<int, 8>{})) return;
+        (void)group(std::integral_constant<int, 12>{});
     }
-}
-
-template <int KP, int RPW>
-__global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict__ recs, const uint16_t *__restrict__ dist,
-                                                     const uint8_t *__restrict__ dist8, const int *__restrict__ u8_ok,
-                                                     int n_agents, int H, int W, int chunks_per_inst,
-                                                     uint8_t *__restrict__ tokens, int gstep, const TokCfg cfg)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (*u8_ok)                                                         // uniform
-        tokens_body<uint8_t, KP, RPW>(recs, dist8, n_agents, H, W, chunks_per_inst, tokens, smem, gstep, cfg);
-    else
-        tokens_body<uint16_t, KP, RPW>(recs, dist, n_agents, H, W, chunks_per_inst, tokens, smem, gstep, cfg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -772,7 +807,7 @@ __global__ __launch_bounds__(256) void ds_tokens_kernel(const AgentRec *__restri
 struct mgpt_tokenizer {
     int n_inst, n_agents, H, W, n_grids;
     int step = kDefaultStep;            // grid_step: side of the reference's cost-to-go tiles (decides the unseeded window corner)
-    TokCfg cfg = {kLimit, kSlots, 5, kR, kR};
+    TokCfg cfg = {kLimit, kSlots, 5, kR, kR, 65536 / kWin + 1};
     uint8_t *grids = nullptr;
     uint16_t *dist = nullptr;
     uint8_t *dist8 = nullptr;
@@ -816,7 +851,10 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
     mgpt_tokenizer *t = new mgpt_tokenizer();
     t->n_inst = n_inst; t->n_agents = n_agents; t->H = H; t->W = W; t->n_grids = n_grids;
     t->step = cfg->grid_step;
-    t->cfg = TokCfg{cfg->cost2go_value_limit, cfg->num_agents, cfg->num_previous_actions, cfg->obs_radius, cfg->agents_radius};
+    t->cfg = TokCfg{cfg->cost2go_value_limit, cfg->num_agents, cfg->num_previous_actions, cfg->obs_radius, cfg->agents_radius,
+                    65536 / (2 * cfg->obs_radius + 1) + 1};
+    for (int c = 0; c < 128; c++)                       // the kernel's division of a cell index by the window side
+        MGPT_REQUIRE(((c * t->cfg.rwin) >> 16) == c / (2 * cfg->obs_radius + 1), MGPT_ERR_UNSUPPORTED, "reciprocal of the window side inexact at %d", c);
     const size_t cells = (size_t)H * W, total = (size_t)n_inst * n_agents;
     hipError_t e = hipMalloc(&t->grids, (size_t)n_grids * cells);
     if (e == hipSuccess) e = hipMalloc(&t->dist, total * cells * sizeof(uint16_t));
@@ -927,24 +965,27 @@ extern "C" int mgpt_tokenizer_generate_observations(mgpt_tokenizer *t, uint8_t *
     hipStream_t s = (hipStream_t)stream;
     const int kp = cdiv(t->n_agents, 64);
     const int kpp = kp <= 4 ? kp : kp <= 8 ? 8 : kp <= 16 ? 16 : 32;
-    // rows per wavefront: 16 (more bytes in flight, records staged once per 64 rows) when the launch still fills the GPU
-    const bool big = (int64_t)t->n_inst * cdiv(t->n_agents, 64) >= 4096;
-    // (round 4, tools/tok_cfg4_time.py: 8 rows per wavefront -- every wave resident in ONE generation on cfg4's 65 536-row launch --
-    //  is not faster, 22.9 vs 21.2 us: the kernel is instruction-issue bound, ~15.5 us per 65 536 rows of 128 agents + ~5.5 us fixed)
-    const int apb = big ? 64 : 16;
+    // rows per wavefront: 8 (more bytes in flight, records staged once per 32 rows) when the launch still fills the GPU
+    const int64_t wg64 = (int64_t)t->n_inst * cdiv(t->n_agents, 64);               // workgroups at 64 rows each
+    int rpw = wg64 >= 4096 ? 8 : 4;
+    {
+        static const int forced = [] { const char *e = getenv("MGPT_TOK_RPW"); return e ? atoi(e) : 0; }();   // experiments only
+        if (forced == 4 || forced == 8 || forced == 16) rpw = forced;
+    }
+    const int apb = 4 * rpw;
     const int chunks = cdiv(t->n_agents, apb);
     const int cw = kpp == 1 ? 0 : (kpp <= 4 ? 64 * kpp : 64);                      // CandWidth<KP>
     const size_t smem = (size_t)apb * 8 + (size_t)t->n_agents * 16 + (size_t)kpp * 64 * 4 + 4 * kRowImage + 4 * kBktBytes +
                         4 * kRowsInterleaved * kListEntries * 2 + (size_t)4 * kRowsInterleaved * cw * 2;
     ProfScope ps(P_TOKENS, s);
+#define MGPT_TOKENS_R(KP_, RPW_)                                                                                       \
+    hipLaunchKernelGGL((tokens_kernel<KP_, RPW_>), dim3(t->n_inst, chunks), dim3(256), smem, s, t->recs, t->dist,      \
+                       t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step, t->cfg)
 #define MGPT_TOKENS(KP_)                                                                                              \
     do {                                                                                                              \
-        if (big)                                                                                                      \
-            hipLaunchKernelGGL((tokens_kernel<KP_, 16>), dim3(t->n_inst * chunks), dim3(256), smem, s, t->recs, t->dist, \
-                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step, t->cfg);       \
-        else                                                                                                          \
-            hipLaunchKernelGGL((tokens_kernel<KP_, 4>), dim3(t->n_inst * chunks), dim3(256), smem, s, t->recs, t->dist, \
-                               t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step, t->cfg);       \
+        if (rpw == 16) MGPT_TOKENS_R(KP_, 16);                                                                        \
+        else if (rpw == 8) MGPT_TOKENS_R(KP_, 8);                                                                     \
+        else MGPT_TOKENS_R(KP_, 4);                                                                                   \
     } while (0)
     switch (kpp) {
     case 1: MGPT_TOKENS(1); break;
@@ -955,6 +996,7 @@ extern "C" int mgpt_tokenizer_generate_observations(mgpt_tokenizer *t, uint8_t *
     case 16: MGPT_TOKENS(16); break;
     default: MGPT_TOKENS(32); break;
     }
+#undef MGPT_TOKENS_R
 #undef MGPT_TOKENS
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;

@@ -44,8 +44,18 @@ def test_argument_validation_without_gpu(L):
     h = ctypes.c_void_p()
     assert L.mgpt_gpt_create(ctypes.byref(h), 2, 2, 64, 161, 4) == _lib.ERR_UNSUPPORTED      # block_size must be 256
     assert L.mgpt_gpt_create(ctypes.byref(h), 2, 3, 64, 256, 4) == _lib.ERR_ARG              # n_embd % n_head
-    st = _lib.InputParametersStruct(20, 12, 5, 256, 5, 5, 64, 0)                              # 12 slots: unsupported
-    assert L.mgpt_tokenizer_create(ctypes.byref(h), ctypes.byref(st), 1, 4, 20, 20, 1) == _lib.ERR_UNSUPPORTED
+    # InputParameters (observation_generator.h:22-40): non-default values are honoured inside the kernels' layout bounds
+    # (tests/test_gpu_tokenizer.py::test_non_default_input_parameters_vs_reference_goldens); outside them the call refuses
+    for bad in [(20, 17, 5, 256, 5, 5),      # more than 16 record slots
+                (20, 13, 6, 256, 5, 5),      # more than five previous actions (AgentRec::hist)
+                (20, 13, 5, 256, 6, 5),      # obs radius 6: 169 window cells
+                (20, 13, 5, 256, 5, 6),      # agents radius 6
+                (3, 13, 5, 256, 5, 5),       # agents radius above the value limit: the reference throws (cpp:358-359)
+                (20, 16, 5, 256, 5, 5),      # 121 + 16 * 10 tokens do not fit a 256-token row
+                (20, 13, 5, 128, 5, 5),      # rows are 256 tokens whatever context_size says (cpp:386)
+                (0, 13, 5, 256, 5, 5)]:
+        st = _lib.InputParametersStruct(*bad, 64, 0)
+        assert L.mgpt_tokenizer_create(ctypes.byref(h), ctypes.byref(st), 1, 4, 20, 20, 1) == _lib.ERR_UNSUPPORTED, bad
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")
