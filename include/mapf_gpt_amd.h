@@ -48,9 +48,16 @@ int mgpt_device_count(int *count);
  * (observation_generator.cpp:546-563), batched over many env instances.
  * ------------------------------------------------------------------------------------------ */
 
-/* = struct InputParameters, observation_generator.h:22-40 / ctor args cpp:551.
- * The kernels implement the configuration the reference always passes (inference.py:15-29):
- * limit 20, 13 agents, 5 previous actions, context 256, radii 5; other values -> MGPT_ERR_UNSUPPORTED.
+/* = struct InputParameters, observation_generator.h:22-40 / ctor args cpp:551.  All fields are honoured (kernel arguments: the
+ * vocabulary -L..L -> 0..2L, -4L, -2L, +2L, six action letters, sixteen bit strings, "!" = 2L+26 of Encoder::Encoder cpp:321-350,
+ * the (2 obs_radius + 1)^2 window cpp:288-311, the (2 agents_radius + 1)^2 neighbour scan and the num_agents records of
+ * 5 + num_previous_actions tokens cpp:352-389, 487-512) within what the kernels' layouts hold:
+ *   1 <= cost2go_value_limit <= 100, 1 <= num_agents <= 16, 0 <= num_previous_actions <= 5, 1 <= obs_radius <= 5,
+ *   0 <= agents_radius <= min(5, cost2go_value_limit)   (beyond the limit the reference itself throws: int_vocab.at, cpp:358-359),
+ *   (2 obs_radius + 1)^2 + num_agents (5 + num_previous_actions) <= 256 and context_size == 256: the reference pads every row to
+ *   256 tokens whatever context_size says (cpp:386-387) and returns LONGER rows when they do not fit; this ABI's rows are 256 tokens.
+ * Anything else -> MGPT_ERR_UNSUPPORTED.  Pinned by rows written by the compiled reference for six non-default sets
+ * (tests/golden/tokp_*.npz).  The reference itself only ever passes (20, 13, 5, 256, 5, 5) (inference.py:15-29).
  * save_cost2go only steers the reference's CPU caching of distance fields (cpp:43-132) and is ignored.  grid_step (> 0,
  * and >= max(H, W) / 256) is the side of the reference's cost-to-go tiles: it changes no token except through the one
  * unseeded corner cell of an agent's cached 2*grid_step + 1 window (cpp:178-198), which is reproduced. */
@@ -96,8 +103,8 @@ int mgpt_tokenizer_update_agents_masked(mgpt_tokenizer *tok, const int16_t *d_po
                                         const int32_t *d_actions, const uint8_t *d_active, int goals_may_change, void *stream);
 
 /* = generate_observations(), cpp:516-528.  d_tokens: uint8 [n_inst * n_agents, 256], row-major,
- * row = inst * n_agents + agent.  Token ids are < 67 and fit a byte (the reference widens them to
- * int64 only for torch.nn.Embedding, inference.py:91,97).  Positions of one instance must be
+ * row = inst * n_agents + agent.  Token ids are < 2 * cost2go_value_limit + 27 (67 by default) and fit a byte (the reference
+ * widens them to int64 only for torch.nn.Embedding, inference.py:91,97).  Positions of one instance must be
  * pairwise distinct (always true for env states). */
 int mgpt_tokenizer_generate_observations(mgpt_tokenizer *tok, uint8_t *d_tokens, void *stream);
 

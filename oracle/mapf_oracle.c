@@ -24,15 +24,21 @@
 #include <string.h>
 
 #define ORC_UNREACH 65535
-#define ORC_CTX 256       /* cpp:386 hard-codes 256 */
+#define ORC_CTX 256       /* cpp:386 hard-codes 256 (InputParameters.context_size is never read by the reference) */
+/* defaults of struct InputParameters (h:24; the values inference.py:15-19 passes); orc_gen_set_params changes them per generator */
 #define ORC_NHIST 5       /* inf:16 num_previous_actions */
 #define ORC_NAGENTS 13    /* inf:15 num_agents */
 #define ORC_R 5           /* inf:18-19 agents_radius == cost2go_radius == 5 */
 #define ORC_LIMIT 20      /* inf:17 cost2go_value_limit */
 
-/* Vocabulary, cpp:321-350: ints -20..20 -> 0..40, -80 -> 41, -40 -> 42, +40 -> 43,
- * n,w,u,d,l,r -> 44..49, "0000".."1111" -> 50..65, "!" -> 66. */
-enum { TOK_UNREACH = 41, TOK_NEG = 42, TOK_POS = 43, TOK_N = 44, TOK_BITS0 = 50, TOK_PAD = 66 };
+/* Vocabulary, Encoder::Encoder cpp:321-350, for cost2go_value_limit L: ints -L..L -> 0..2L, -4L -> 2L+1, -2L -> 2L+2, +2L -> 2L+3,
+ * n,w,u,d,l,r -> 2L+4..2L+9, "0000".."1111" -> 2L+10..2L+25, "!" -> 2L+26.  (L = 20: 41, 42, 43, 44.., 50.., 66.) */
+#define TOK_UNREACH(L) (2 * (L) + 1)
+#define TOK_NEG(L) (2 * (L) + 2)
+#define TOK_POS(L) (2 * (L) + 3)
+#define TOK_N(L) (2 * (L) + 4)
+#define TOK_BITS0(L) (2 * (L) + 10)
+#define TOK_PAD(L) (2 * (L) + 26)
 
 /* cpp:200-286 (+ cpp:134-176 for small grids).  The reference's tiled border/priority-queue
  * machinery yields the 4-connected BFS distance from the goal over free cells and 65535
@@ -73,14 +79,14 @@ void orc_bfs(const uint8_t *grid, int H, int W, int gr, int gc, uint16_t *dist)
 
 /* cpp:412-430 + vocabulary cpp:330-343: bits in the order u(-1,0) d(+1,0) l(0,-1) r(0,+1),
  * bit set iff the neighbour's distance is strictly smaller than the cell's own. */
-static uint8_t next_action_token(const uint16_t *dist, int W, int r, int c)
+static uint8_t next_action_token(const uint16_t *dist, int W, int r, int c, int bits0)
 {
     int cur = dist[r * W + c];
     int u = dist[(r - 1) * W + c] < cur;
     int d = dist[(r + 1) * W + c] < cur;
     int l = dist[r * W + c - 1] < cur;
     int rr = dist[r * W + c + 1] < cur;
-    return (uint8_t)(TOK_BITS0 + 8 * u + 4 * d + 2 * l + rr);
+    return (uint8_t)(bits0 + 8 * u + 4 * d + 2 * l + rr);
 }
 
 typedef struct {
@@ -89,11 +95,12 @@ typedef struct {
     int32_t *occ;       /* agents_locations, h:116: -1 or agent id */
     int32_t *pos;       /* n*2 (row, col) padded coords */
     int32_t *goal;      /* n*2 */
-    uint8_t *hist;      /* n*5 tokens, oldest -> newest */
+    uint8_t *hist;      /* n*nhist tokens, oldest -> newest */
     uint8_t *next;      /* n */
     uint16_t *dist;     /* n*H*W */
     int32_t *org;       /* n*2: (left_border, top_border) of the agent's cached partial window, cpp:204-207 */
     int step;           /* cfg.grid_step, h:38 */
+    int limit, nslots, nhist, obs_r, ag_r;   /* cfg.cost2go_value_limit, num_agents, num_previous_actions, obs_radius, agents_radius (h:32-37) */
 } orc_gen;
 
 orc_gen *orc_gen_create(const uint8_t *grid, int H, int W)
@@ -101,6 +108,7 @@ orc_gen *orc_gen_create(const uint8_t *grid, int H, int W)
     orc_gen *g = (orc_gen *)calloc(1, sizeof(orc_gen));
     g->H = H; g->W = W; g->n = 0;
     g->step = ORC_STEP;
+    g->limit = ORC_LIMIT; g->nslots = ORC_NAGENTS; g->nhist = ORC_NHIST; g->obs_r = ORC_R; g->ag_r = ORC_R;
     g->grid = (uint8_t *)malloc((size_t)H * W);
     memcpy(g->grid, grid, (size_t)H * W);
     g->occ = (int32_t *)malloc(sizeof(int32_t) * (size_t)H * W);
@@ -116,14 +124,25 @@ void orc_gen_destroy(orc_gen *g)
 }
 
 /* cpp:204-207: origin of the partial window computed for an agent standing at (r, c) */
-static void window_origin(int r, int c, int step, int32_t *org)
+static void window_origin(int r, int c, int step, int R, int32_t *org)
 {
-    org[0] = (r - ORC_R > 0 ? r - ORC_R : 0) / step * step;
-    org[1] = (c - ORC_R > 0 ? c - ORC_R : 0) / step * step;
+    org[0] = (r - R > 0 ? r - R : 0) / step * step;
+    org[1] = (c - R > 0 ? c - R : 0) / step * step;
 }
 
 /* InputParameters.grid_step (h:38, cpp:551); call before create_agents */
 void orc_gen_set_grid_step(orc_gen *g, int step) { if (step > 0) g->step = step; }
+
+/* the other fields of InputParameters (h:22-40, pybind ctor cpp:551); call before create_agents.  Returns 0, or -1 for values
+ * the reference itself cannot run: a row longer than 256 tokens is returned longer than 256 (cpp:386-387), agents_radius above
+ * the limit makes int_vocab.at throw on a relative position (cpp:358-359). */
+int orc_gen_set_params(orc_gen *g, int limit, int nslots, int nhist, int obs_r, int ag_r)
+{
+    if (limit < 1 || 2 * limit + 26 > 255 || nslots < 0 || nhist < 0 || obs_r < 0 || ag_r < 0 || ag_r > limit) return -1;
+    if ((2 * obs_r + 1) * (2 * obs_r + 1) + nslots * (5 + nhist) > ORC_CTX) return -1;
+    g->limit = limit; g->nslots = nslots; g->nhist = nhist; g->obs_r = obs_r; g->ag_r = ag_r;
+    return 0;
+}
 
 /* cpp:391-410: history = "n" x5, distance field, greedy bits.  Does NOT touch agents_locations. */
 void orc_gen_create_agents(orc_gen *g, int n, const int32_t *pos, const int32_t *goal)
@@ -133,17 +152,17 @@ void orc_gen_create_agents(orc_gen *g, int n, const int32_t *pos, const int32_t 
     g->org = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n);
     g->pos = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n);
     g->goal = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n);
-    g->hist = (uint8_t *)malloc((size_t)n * ORC_NHIST);
+    g->hist = (uint8_t *)malloc((size_t)n * g->nhist + 1);
     g->next = (uint8_t *)malloc((size_t)n);
     g->dist = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)n * g->H * g->W);
     memcpy(g->pos, pos, sizeof(int32_t) * 2 * (size_t)n);
     memcpy(g->goal, goal, sizeof(int32_t) * 2 * (size_t)n);
-    memset(g->hist, TOK_N, (size_t)n * ORC_NHIST);           /* cpp:403-406 */
+    memset(g->hist, TOK_N(g->limit), (size_t)n * g->nhist);  /* cpp:403-406 */
     for (int a = 0; a < n; a++) {
         uint16_t *d = g->dist + (size_t)a * g->H * g->W;
         orc_bfs(g->grid, g->H, g->W, goal[2 * a], goal[2 * a + 1], d);
-        window_origin(pos[2 * a], pos[2 * a + 1], g->step, g->org + 2 * a);   /* cpp:408 compute_cost2go_partial */
-        g->next[a] = next_action_token(d, g->W, pos[2 * a], pos[2 * a + 1]);
+        window_origin(pos[2 * a], pos[2 * a + 1], g->step, g->obs_r, g->org + 2 * a);   /* cpp:408 compute_cost2go_partial */
+        g->next[a] = next_action_token(d, g->W, pos[2 * a], pos[2 * a + 1], TOK_BITS0(g->limit));
     }
 }
 
@@ -158,27 +177,30 @@ void orc_gen_update_agents(orc_gen *g, const int32_t *pos, const int32_t *goal, 
         g->occ[pos[2 * a] * W + pos[2 * a + 1]] = a;          /* cpp:440, id order: highest id wins a shared cell */
         g->pos[2 * a] = pos[2 * a];
         g->pos[2 * a + 1] = pos[2 * a + 1];
-        uint8_t *h = g->hist + (size_t)a * ORC_NHIST;
         int act = actions[a];
-        memmove(h, h + 1, ORC_NHIST - 1);                     /* cpp:463 pop_front */
-        h[ORC_NHIST - 1] = (uint8_t)((act >= 0 && act <= 4) ? TOK_N + 1 + act : TOK_N);   /* cpp:442-462 */
+        if (g->nhist > 0) {
+            uint8_t *h = g->hist + (size_t)a * g->nhist;
+            memmove(h, h + 1, (size_t)g->nhist - 1);          /* cpp:463 pop_front */
+            h[g->nhist - 1] = (uint8_t)((act >= 0 && act <= 4) ? TOK_N(g->limit) + 1 + act : TOK_N(g->limit));   /* cpp:442-462 */
+        }                                                     /* (num_previous_actions = 0: push_back + pop_front leave the deque empty) */
         if (g->goal[2 * a] != goal[2 * a] || g->goal[2 * a + 1] != goal[2 * a + 1]) {       /* cpp:464-468 */
             g->goal[2 * a] = goal[2 * a];
             g->goal[2 * a + 1] = goal[2 * a + 1];
             orc_bfs(g->grid, g->H, g->W, goal[2 * a], goal[2 * a + 1], g->dist + (size_t)a * g->H * W);
-            window_origin(pos[2 * a], pos[2 * a + 1], g->step, g->org + 2 * a);
+            window_origin(pos[2 * a], pos[2 * a + 1], g->step, g->obs_r, g->org + 2 * a);
         } else {
             /* cpp:469-477: the observation window left the cached partial box -> recomputed around the new position.
              * The full-grid field needs no recompute; only the box origin moves (it decides the corner cell below). */
             int left = g->org[2 * a], top = g->org[2 * a + 1];
             int right = left + 2 * g->step < g->H - 1 ? left + 2 * g->step : g->H - 1;
             int bottom = top + 2 * g->step < W - 1 ? top + 2 * g->step : W - 1;
-            if (pos[2 * a] - ORC_R < left || pos[2 * a] + ORC_R > right || pos[2 * a + 1] - ORC_R < top || pos[2 * a + 1] + ORC_R > bottom)
-                window_origin(pos[2 * a], pos[2 * a + 1], g->step, g->org + 2 * a);
+            int R = g->obs_r;
+            if (pos[2 * a] - R < left || pos[2 * a] + R > right || pos[2 * a + 1] - R < top || pos[2 * a + 1] + R > bottom)
+                window_origin(pos[2 * a], pos[2 * a + 1], g->step, R, g->org + 2 * a);
         }
     }
     for (int a = 0; a < n; a++)                               /* cpp:483-484 */
-        g->next[a] = next_action_token(g->dist + (size_t)a * g->H * W, W, g->pos[2 * a], g->pos[2 * a + 1]);
+        g->next[a] = next_action_token(g->dist + (size_t)a * g->H * W, W, g->pos[2 * a], g->pos[2 * a + 1], TOK_BITS0(g->limit));
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -187,38 +209,41 @@ static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v
 void orc_gen_generate_observations(const orc_gen *g, uint8_t *out /* n*256 */)
 {
     int n = g->n, H = g->H, W = g->W;
+    const int L = g->limit, R = g->obs_r, A = g->ag_r, win = 2 * g->obs_r + 1, rec = 5 + g->nhist;
+    int *cand = (int *)malloc(sizeof(int) * (size_t)(2 * A + 1) * (2 * A + 1));
+    int *key = (int *)malloc(sizeof(int) * (size_t)(2 * A + 1) * (2 * A + 1));
     for (int a = 0; a < n; a++) {
         uint8_t *row = out + (size_t)a * ORC_CTX;
         const uint16_t *d = g->dist + (size_t)a * g->H * W;
         int pr = g->pos[2 * a], pc = g->pos[2 * a + 1];
-        memset(row, TOK_PAD, ORC_CTX);                        /* cpp:375-376, 386-387 */
+        memset(row, TOK_PAD(L), ORC_CTX);                     /* cpp:375-376, 386-387 */
         int mid = d[pr * W + pc];                             /* cpp:297 */
         /* the unseeded corner of the cached partial window (cpp:178-198), if it exists and is in view */
         int cr = g->org[2 * a] + 2 * g->step, cc = g->org[2 * a + 1] + 2 * g->step;
-        int corner_in_view = cr <= H - 1 && cc <= W - 1 && pr + ORC_R == cr && pc + ORC_R == cc;
-        for (int i = 0; i <= 2 * ORC_R; i++)
-            for (int j = 0; j <= 2 * ORC_R; j++) {
-                int v = d[(pr - ORC_R + i) * W + (pc - ORC_R + j)];
-                if (corner_in_view && i == 2 * ORC_R && j == 2 * ORC_R && v != ORC_UNREACH && v != 0) {
+        int corner_in_view = cr <= H - 1 && cc <= W - 1 && pr + R == cr && pc + R == cc;
+        for (int i = 0; i <= 2 * R; i++)
+            for (int j = 0; j <= 2 * R; j++) {
+                int v = d[(pr - R + i) * W + (pc - R + j)];
+                if (corner_in_view && i == 2 * R && j == 2 * R && v != ORC_UNREACH && v != 0) {
                     /* reached only from its two in-window neighbours (exact border seeds): cpp:252-268 */
                     int n1 = d[(cr - 1) * W + cc], n2 = d[cr * W + cc - 1];
                     int m = n1 < n2 ? n1 : n2;
                     v = m == ORC_UNREACH ? ORC_UNREACH : m + 1;
                 }
                 uint8_t t;
-                if (v == ORC_UNREACH) t = TOK_UNREACH;        /* cpp:308-309: -80 -> 41 */
+                if (v == ORC_UNREACH) t = (uint8_t)TOK_UNREACH(L);   /* cpp:308-309: -4L */
                 else {
                     v -= mid;                                 /* cpp:304 */
-                    if (v > ORC_LIMIT) t = TOK_POS;           /* +40 -> 43 */
-                    else if (v < -ORC_LIMIT) t = TOK_NEG;     /* -40 -> 42 */
-                    else t = (uint8_t)(v + ORC_LIMIT);
+                    if (v > L) t = (uint8_t)TOK_POS(L);       /* +2L */
+                    else if (v < -L) t = (uint8_t)TOK_NEG(L); /* -2L */
+                    else t = (uint8_t)(v + L);
                 }
-                row[i * (2 * ORC_R + 1) + j] = t;
+                row[i * win + j] = t;
             }
         /* cpp:487-505: row-major scan of agents_locations, sort by (Manhattan, id) */
-        int cand[(2 * ORC_R + 1) * (2 * ORC_R + 1)], key[(2 * ORC_R + 1) * (2 * ORC_R + 1)], nc = 0;
-        for (int i = -ORC_R; i <= ORC_R; i++)
-            for (int j = -ORC_R; j <= ORC_R; j++) {
+        int nc = 0;
+        for (int i = -A; i <= A; i++)
+            for (int j = -A; j <= A; j++) {
                 int b = g->occ[(pr + i) * W + (pc + j)];
                 if (b >= 0) {
                     int md = abs(g->pos[2 * b] - pr) + abs(g->pos[2 * b + 1] - pc);
@@ -230,19 +255,20 @@ void orc_gen_generate_observations(const orc_gen *g, uint8_t *out /* n*256 */)
             while (y >= 0 && key[y] > k) { key[y + 1] = key[y]; cand[y + 1] = cand[y]; y--; }
             key[y + 1] = k; cand[y + 1] = b;
         }
-        int m = nc < ORC_NAGENTS ? nc : ORC_NAGENTS;          /* cpp:506 */
+        int m = nc < g->nslots ? nc : g->nslots;              /* cpp:506 */
         for (int s = 0; s < m; s++) {
             int b = cand[s];
-            uint8_t *o = row + 121 + 10 * s;
-            /* cpp:358-361: relative pos via int_vocab.at (always within +-5), goal clamped to +-20 */
-            o[0] = (uint8_t)(g->pos[2 * b] - pr + ORC_LIMIT);
-            o[1] = (uint8_t)(g->pos[2 * b + 1] - pc + ORC_LIMIT);
-            o[2] = (uint8_t)(clampi(g->goal[2 * b] - pr, -ORC_LIMIT, ORC_LIMIT) + ORC_LIMIT);
-            o[3] = (uint8_t)(clampi(g->goal[2 * b + 1] - pc, -ORC_LIMIT, ORC_LIMIT) + ORC_LIMIT);
-            memcpy(o + 4, g->hist + (size_t)b * ORC_NHIST, ORC_NHIST);   /* cpp:364-367 */
-            o[9] = g->next[b];                                            /* cpp:368 */
+            uint8_t *o = row + win * win + rec * s;
+            /* cpp:358-361: relative pos via int_vocab.at (always within +-A <= L), goal clamped to +-L */
+            o[0] = (uint8_t)(g->pos[2 * b] - pr + L);
+            o[1] = (uint8_t)(g->pos[2 * b + 1] - pc + L);
+            o[2] = (uint8_t)(clampi(g->goal[2 * b] - pr, -L, L) + L);
+            o[3] = (uint8_t)(clampi(g->goal[2 * b + 1] - pc, -L, L) + L);
+            memcpy(o + 4, g->hist + (size_t)b * g->nhist, (size_t)g->nhist);   /* cpp:364-367 */
+            o[4 + g->nhist] = g->next[b];                                       /* cpp:368 */
         }
     }
+    free(cand); free(key);
 }
 
 /* read-back helpers for tests */

@@ -46,6 +46,8 @@ def lib():
         L.orc_gen_destroy.argtypes = [vp]
         L.orc_gen_set_grid_step.argtypes = [vp, i32]
         L.orc_gen_set_grid_step.restype = None
+        L.orc_gen_set_params.argtypes = [vp, i32, i32, i32, i32, i32]
+        L.orc_gen_set_params.restype = i32
         L.orc_gen_create_agents.argtypes = [vp, i32, vp, vp]
         L.orc_gen_update_agents.argtypes = [vp, vp, vp, vp]
         L.orc_gen_generate_observations.argtypes = [vp, vp]
@@ -73,14 +75,20 @@ def bfs(grid, goal):
 
 
 class OracleGenerator:
-    """One env instance; mirrors ObservationGenerator(grid, cfg) with the default InputParameters
-    of inference.py:15-29 (the only ones the reference ever passes)."""
+    """One env instance; mirrors ObservationGenerator(grid, cfg).  `params` = (cost2go_value_limit, num_agents,
+    num_previous_actions, obs_radius, agents_radius) of struct InputParameters (observation_generator.h:22-40); default:
+    the values inference.py:15-29 passes."""
 
-    def __init__(self, grid, grid_step=64):
+    def __init__(self, grid, grid_step=64, params=None):
         self.grid = np.ascontiguousarray(np.asarray(grid) != 0, dtype=np.uint8)
         self.H, self.W = self.grid.shape
         self._h = lib().orc_gen_create(self.grid.ctypes.data, self.H, self.W)
         lib().orc_gen_set_grid_step(self._h, int(grid_step))          # InputParameters.grid_step (inference.py:28)
+        self.nhist = 5
+        if params is not None:
+            if lib().orc_gen_set_params(self._h, *[int(v) for v in params]) != 0:
+                raise ValueError(f"InputParameters {tuple(params)} cannot be run by the reference either")
+            self.nhist = int(params[2])
         self.n = 0
 
     def __del__(self):
@@ -114,7 +122,7 @@ class OracleGenerator:
 
     def hist_tokens(self):
         ptr = lib().orc_gen_hist(self._h)
-        return np.frombuffer((ctypes.c_uint8 * (self.n * 5)).from_address(ptr), dtype=np.uint8).reshape(self.n, 5).copy()
+        return np.frombuffer((ctypes.c_uint8 * (self.n * self.nhist)).from_address(ptr), dtype=np.uint8).reshape(self.n, self.nhist).copy()
 
 
 RULE_NO_FOLLOW, RULE_LOWEST_WINS = 1, 2          # mapf_oracle.c: the two switchable (RECALLED) collision rules

@@ -20,10 +20,23 @@ def load_tok(name):
     return np.load(os.path.join(GOLDEN, f"tok_{name}.npz"))
 
 
+def tokp_cases():
+    """goldens of NON-DEFAULT InputParameters (tests/golden/make_golden_params.py, from the compiled reference)"""
+    return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN, "tokp_*.npz")))
+
+
+def load_tokp(name):
+    return np.load(os.path.join(GOLDEN, f"tokp_{name}.npz"))
+
+
 def replay_oracle(case):
     """Run the C oracle over a golden trajectory -> uint8 [S, n, 256] (all agents)."""
     grid, P, G, A = case["grid"], case["pos"], case["goal"], case["actions"]
-    gen = orc.OracleGenerator(grid, grid_step=int(case["grid_step"]) if "grid_step" in case else 64)
+    params = None
+    if "params" in case:                   # (limit, num_agents, previous actions, context, obs radius, agents radius)
+        L, S, Hn, _, R, Ar = [int(v) for v in case["params"]]
+        params = (L, S, Hn, R, Ar)
+    gen = orc.OracleGenerator(grid, grid_step=int(case["grid_step"]) if "grid_step" in case else 64, params=params)
     out = []
     for t in range(P.shape[0]):
         if t == 0:

@@ -7,7 +7,7 @@ import torch
 
 from mapf_gpt_amd import maps
 from oracle import oracle as orc
-from tests.helpers import GOLDEN, load_tok, sha_rows, tok_cases
+from tests.helpers import GOLDEN, load_tok, load_tokp, sha_rows, tok_cases, tokp_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,10 @@ def replay_gpu(case, n_inst=1, check_dist=False):
     from mapf_gpt_amd.observation_generator import BatchedTokenizer, InputParameters
     grid, P, G, A = case["grid"], case["pos"], case["goal"], case["actions"]
     S, n = P.shape[0], P.shape[1]
-    tok = BatchedTokenizer(grid, n_inst, n, InputParameters(grid_step=int(case["grid_step"]) if "grid_step" in case else 64))
+    cfg = InputParameters(grid_step=int(case["grid_step"]) if "grid_step" in case else 64)
+    if "params" in case:
+        cfg = InputParameters(*[int(v) for v in case["params"]], 64, False)
+    tok = BatchedTokenizer(grid, n_inst, n, cfg)
     out = []
     for t in range(S):
         pos = _dev(np.broadcast_to(P[t], (n_inst, n, 2)), torch.int16)
@@ -55,6 +58,19 @@ def test_golden_trajectories_bit_exact(name):
     got = replay_gpu(case, n_inst=1, check_dist=True)[:, 0]
     assert sha_rows(got) == str(case["sha256_all_rows"])
     assert np.array_equal(got[:, case["keep"]], case["tokens"])
+
+
+@pytest.mark.parametrize("name", tokp_cases())
+@pytest.mark.parametrize("n_inst", [1, 3])
+def test_non_default_input_parameters_vs_reference_goldens(name, n_inst):
+    """struct InputParameters (observation_generator.h:22-40) beyond what inference.py passes: other value limits (vocabulary), record
+    slots, history lengths (7-, 9- and 5-token records: odd record alignment), obs radii (49- and 25-cell windows: lanes without a
+    window cell) and agents radii, bit-exact against rows written by the compiled reference (tests/golden/make_golden_params.py)."""
+    case = load_tokp(name)
+    got = replay_gpu(case, n_inst=n_inst)
+    for i in range(n_inst):
+        assert np.array_equal(got[:, i][:, case["keep"]], case["tokens"]), f"instance slot {i}"
+    assert sha_rows(got[:, 0]) == str(case["sha256_all_rows"])
 
 
 def test_batched_instances_share_one_map():

@@ -7,7 +7,7 @@ import pytest
 from mapf_gpt_amd import weights
 from oracle import gpt_oracle
 from oracle import oracle as orc
-from tests.helpers import GOLDEN, load_tok, replay_oracle, sha_rows, tok_cases
+from tests.helpers import GOLDEN, load_tok, load_tokp, replay_oracle, sha_rows, tok_cases, tokp_cases
 
 
 def test_known_answer_cpp_main():
@@ -24,6 +24,16 @@ def test_known_answer_cpp_main():
     assert np.array_equal(blk, 20 - j + i)
     assert row[0, 121:131].tolist() == [20, 20, 0, 40, 44, 44, 44, 44, 45, 59]
     assert (row[0, 131:] == 66).all()
+
+
+@pytest.mark.parametrize("name", tokp_cases())
+def test_tokenizer_oracle_matches_reference_vectors_of_other_input_parameters(name):
+    """struct InputParameters (observation_generator.h:22-40) with values inference.py never passes: limit, record slots, history
+    length and the two radii change the vocabulary and the row layout (cpp:321-389, 487-512)."""
+    case = load_tokp(name)
+    got = replay_oracle(case)
+    assert sha_rows(got) == str(case["sha256_all_rows"])
+    assert np.array_equal(got[:, case["keep"]], case["tokens"])
 
 
 @pytest.mark.parametrize("name", tok_cases())
