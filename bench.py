@@ -500,11 +500,50 @@ def timed_steps(w, steps, warmup, world, use_prof, coll_dev, sample_clock=None, 
     if use_prof:
         _lib.prof_enable(False)
         prof = _lib.prof_read()
+    w["local_dt"] = dt                           # this rank's own wall time between its two barriers (per_rank below)
     if collective:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     return dt, prof
+
+
+def per_rank_records(w, steps, rank, world, local_rank, coll_dev, collective):
+    """One record per rank -- {rank, ms_per_step, sclk_mhz_mean, socket_power_w_mean, pci} -- so that an N-GPU line says on its face
+    whether a shortfall was clocks, binding (two ranks on one PCI address) or a straggler.  One tiny all_gather
+    of 8 float64 per rank, outside the timed region (the job's data path has no collective)."""
+    cp = w.get("clock_power") or {}
+    pr = torch.cuda.get_device_properties(local_rank)
+    mine = [float(rank), 1e3 * w["local_dt"] / steps, float(cp.get("sclk_mhz_mean", float("nan"))), float(cp.get("socket_power_w_mean", float("nan"))),
+            float(getattr(pr, "pci_domain_id", 0)), float(pr.pci_bus_id), float(pr.pci_device_id), float(local_rank)]
+    rows = [mine]
+    if collective:
+        import torch.distributed as dist
+        t = torch.tensor(mine, dtype=torch.float64, device=coll_dev)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        rows = [o.cpu().tolist() for o in out]
+    recs = [{"rank": int(r[0]), "ms_per_step": r[1], "sclk_mhz_mean": (None if r[2] != r[2] else r[2]),
+             "socket_power_w_mean": (None if r[3] != r[3] else r[3]), "pci": "%04x:%02x:%02x.0" % (int(r[4]), int(r[5]), int(r[6])),
+             "local_rank": int(r[7])} for r in rows]
+    return recs
+
+
+def reset_cost(w, reps=3):
+    """The episode boundary, which the timed region of a default run never crosses (steps < max_episode_steps): env reset + tokenizer
+    create_agents (record init, one BFS distance field per agent: bfs_kernel, greedy bits) -- observation_generator.cpp:391-410 --
+    HIP-event timed on the run's stream, outside the headline.  -> ms per episode of this rank's shard."""
+    run, pos, goal = w["run"], w["pos"], w["goal"]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        e0.record()
+        run.reset(pos, goal)
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return float(min(ms))
 
 
 def class_flops(prof, f_class, L_, rows, full=None):
@@ -559,11 +598,11 @@ def secondary_shard(name, precision, steps, warmup, local_rank, coll_dev, instan
     return out
 
 
-TRAFFIC_FILE = "r05_hbm_traffic.json"
+TRAFFIC_FILE = "r06_hbm_traffic.json"
 
 
 def traffic_for(kernel_key, rows_per_launch=None):
-    """HBM bytes per launch from THIS round's committed PMC passes (profiles/r05_hbm_traffic.json; no fallback to earlier
+    """HBM bytes per launch from THIS round's committed PMC passes (profiles/r06_hbm_traffic.json; no fallback to earlier
     rounds' files -- VERDICT r03: a stale entry is worse than null): a replay of a rocprofv3 run of this command, NOT a
     measurement of this run.  An entry that records the launch size it was measured at is only used for launches of that size."""
     tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
@@ -633,13 +672,20 @@ def main():
     name = a.workload or ("cfg3" if world == 1 else "cfg4")
     w = build_workload(name, a.precision, rank, world, local_rank, a.instances, chunk_rows=a.chunk_rows)
     use_prof = not a.no_prof
-    dt, prof_raw = timed_steps(w, a.steps, a.warmup, world, use_prof, coll_dev, sample_clock=(local_rank if rank == 0 else None),
-                               collective=collective)
+    dt, prof_raw = timed_steps(w, a.steps, a.warmup, world, use_prof, coll_dev, sample_clock=local_rank, collective=collective)
+    per_rank = per_rank_records(w, a.steps, rank, world, local_rank, coll_dev, collective)
     prof, prof_full, prof_last = fold_last(prof_raw)
     local_metrics = w["run"].metrics().to(coll_dev)
     metrics = gather_metrics(local_metrics, w["n_total"], rank, world, force=collective)       # the job's one collective
     gathered_on = str(metrics.device) if collective else None
     torch.cuda.synchronize()
+    reset_ms = reset_cost(w) if rank == 0 else None          # (after the timed region and the metrics: the reset starts a new episode)
+    eff_prec = None
+    if rank == 0 and a.precision == "f16x3":
+        try:
+            eff_prec = w["net"].envelope()
+        except Exception:
+            eff_prec = None
 
     if rank == 0:
         model, n_agents, n_total, rows, map_name = w["model"], w["n_agents"], w["n_total"], w["rows"], w["map_name"]
@@ -656,10 +702,20 @@ def main():
                                       f"{w['inst_per_gpu']} instances/GPU ({n_total} total), {n_total * n_agents} rows/step",
                           "parallelism": f"instances sharded x{world}, no per-step collective",
                           "gflop_per_agent_step": f_total / 1e9,
-                          "mean_ISR_after_run": float(metrics[:, 1].mean().item())},
+                          "mean_ISR_after_run": float(metrics[:, 1].mean().item()),
+                          "max_episode_steps": w["max_steps"],
+                          "timed_region_crosses_episode_boundary": bool(a.warmup + a.steps > w["max_steps"]),
+                          "reset_ms_per_episode": reset_ms,
+                          "amortised_reset_ms_per_step": (reset_ms / w["max_steps"] if reset_ms is not None else None),
+                          "reset_note": "env reset + tokenizer create_agents (one BFS field per agent, observation_generator.cpp:391-410) of this rank's "
+                                        "shard, HIP-event timed once outside the headline; a default run's timed region ends before max_episode_steps"},
+               "per_rank": per_rank,
+               "effective_precision": ((eff_prec or {}).get("effective_precision") if a.precision == "f16x3" else a.precision),
+               "precision_envelope": eff_prec,
                "note": "weights are seeded synthetic N(0, 0.02) tensors of the reference's shapes; the released checkpoints are "
                        "unreachable offline, so the 1e-5 logit parity of the f16x3 mode is established on synthetic weights "
-                       "(tests/test_gpu_gpt.py) and not on the released ones"}
+                       "(tests/test_gpu_gpt.py) and not on the released ones; the f16x3 figures hold while the loaded checkpoint's precision "
+                       "envelope stays 'inside' (effective_precision / precision_envelope: a checkpoint outside it is served by the fp32 kernels)"}
         if prof:
             cls = class_flops(prof, f_class, margs["n_layer"], rows, prof_full)
             if cls:

@@ -80,6 +80,7 @@ SYMBOLS = {
     "mgpt_gpt_debug_counter": (_i, [_i, ctypes.POINTER(_u64), _i]),
     "mgpt_gpt_set_envelope_policy": (_i, [_vp, _i]),
     "mgpt_gpt_envelope": (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
+    "mgpt_gpt_envelope_probe": (_i, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "mgpt_sample_actions": (_i, [_vp, _i, _vp, _i, _u64, _u64, _u64, _vp]),
     "mgpt_prof_enable": (_i, [_i]),
     "mgpt_prof_reset": (_i, []),

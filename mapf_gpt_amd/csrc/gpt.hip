@@ -210,7 +210,8 @@ extern "C" int mgpt_gpt_finalize(mgpt_gpt *g)
     int rc = gpt_fast_finalize(g);
     if (rc != MGPT_OK) return rc;
     if ((rc = envelope_stats(g)) != MGPT_OK) return rc;
-    g->env_state = 0; g->env_probe_err = -1.f; g->env_logged = false;
+    g->env_state = 0; g->env_probe_err = g->env_probe_err_small = g->env_probe_err_large = -1.f; g->env_logged = false;
+    g->env_probe_tol = 0.f; g->env_probe_max_logit = 0.f;
     g->finalized = true;
     return MGPT_OK;
 }
@@ -227,6 +228,13 @@ extern "C" int mgpt_gpt_envelope(mgpt_gpt *g, float *out3, int *state)
     MGPT_REQUIRE(g && out3 && state, MGPT_ERR_ARG, "NULL argument");
     out3[0] = g->env_max_w; out3[1] = g->env_max_rms; out3[2] = g->env_probe_err;
     *state = g->env_state;
+    return MGPT_OK;
+}
+
+extern "C" int mgpt_gpt_envelope_probe(mgpt_gpt *g, float *out4)
+{
+    MGPT_REQUIRE(g && out4, MGPT_ERR_ARG, "NULL argument");
+    out4[0] = g->env_probe_err_small; out4[1] = g->env_probe_err_large; out4[2] = g->env_probe_tol; out4[3] = g->env_probe_max_logit;
     return MGPT_OK;
 }
 
@@ -355,29 +363,51 @@ static int envelope_decide(mgpt_gpt *g, hipStream_t s)
 {
     const int n = std::min(g->max_rows, MGPT_ENVELOPE_PROBE_ROWS);
     bool inside = g->env_max_w <= MGPT_ENVELOPE_MAX_W && g->env_max_rms <= MGPT_ENVELOPE_MAX_RMS;
+    {   // the probe allocates, copies back and synchronises: it cannot run inside a stream capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            set_error("the first MGPT_PREC_F16X3 forward of a checkpoint probes its precision envelope and cannot be captured: "
+                      "run one eager forward first (or mgpt_gpt_set_envelope_policy(MGPT_ENVELOPE_IGNORE))");
+            return MGPT_ERR_STATE;
+        }
+    }
     if (inside) {
         std::vector<uint8_t> h_tok((size_t)n * kT);
         uint64_t st = 0x9e3779b97f4a7c15ull;
         for (auto &t : h_tok) { st = st * 6364136223846793005ull + 1442695040888963407ull; t = (uint8_t)((st >> 33) % (uint64_t)kV); }
         uint8_t *d_tok = nullptr; float *d_lg = nullptr;
         MGPT_HIP(hipMalloc(&d_tok, h_tok.size()));
-        if (hipMalloc(&d_lg, (size_t)2 * n * kV * sizeof(float)) != hipSuccess) { (void)hipFree(d_tok); set_error("hipMalloc failed in the envelope probe"); return MGPT_ERR_HIP; }
+        if (hipMalloc(&d_lg, (size_t)3 * n * kV * sizeof(float)) != hipSuccess) { (void)hipFree(d_tok); set_error("hipMalloc failed in the envelope probe"); return MGPT_ERR_HIP; }
         int rc = MGPT_OK;
-        std::vector<float> h_lg((size_t)2 * n * kV);
+        // BOTH call regimes: the same rows once as a call of n rows (the small-call kernels: head-parallel attention, 32 x 32 x 16 MLP
+        // block, fp32 last layer) and once as a chunk of a call of more than kSmallRows rows (attn256q / attn160o, mlp256q /
+        // mlp_fused16, gemm_pk16, attn_last1: other arithmetic) -- ADVICE r05: the probe used to see the small-call kernels only
+        std::vector<float> h_lg((size_t)3 * n * kV);
         if (hipMemcpyAsync(d_tok, h_tok.data(), h_tok.size(), hipMemcpyHostToDevice, s) != hipSuccess) rc = MGPT_ERR_HIP;
         if (rc == MGPT_OK) rc = forward_f32_chunk(g, d_tok, n, d_lg, s);
         if (rc == MGPT_OK) rc = gpt_fast_forward(g, d_tok, n, d_lg + (size_t)n * kV, MGPT_PREC_F16X3, s, n);
+        if (rc == MGPT_OK) rc = gpt_fast_forward(g, d_tok, n, d_lg + (size_t)2 * n * kV, MGPT_PREC_F16X3, s, kSmallRows + 1);
         if (rc == MGPT_OK && hipMemcpyAsync(h_lg.data(), d_lg, h_lg.size() * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) rc = MGPT_ERR_HIP;
         if (rc == MGPT_OK && hipStreamSynchronize(s) != hipSuccess) rc = MGPT_ERR_HIP;
         (void)hipFree(d_tok); (void)hipFree(d_lg);
         if (rc != MGPT_OK) { if (rc == MGPT_ERR_HIP) set_error("envelope probe failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
-        float err = 0.f;
+        float err[2] = {0.f, 0.f}, max_logit = 0.f;
         for (size_t i = 0; i < (size_t)n * kV; i++) {
-            const float d = fabsf(h_lg[i] - h_lg[(size_t)n * kV + i]);
-            err = (d == d) ? std::max(err, d) : INFINITY;  // NaN counts as outside
+            max_logit = std::max(max_logit, fabsf(h_lg[i]));
+            for (int r = 0; r < 2; r++) {
+                const float d = fabsf(h_lg[i] - h_lg[(size_t)(r + 1) * n * kV + i]);
+                err[r] = (d == d) ? std::max(err[r], d) : INFINITY;  // NaN counts as outside
+            }
         }
-        g->env_probe_err = err;
-        inside = err <= MGPT_ENVELOPE_PROBE_TOL;
+        // The bar: MGPT_ENVELOPE_PROBE_TOL absolute while the logits are of order one (where the 1e-5 of the north star was
+        // established); relative to the largest fp32 logit beyond that -- fp32 itself moves by ~eps * |logit| * sqrt(depth) between
+        // summation orders (3.6e-5 at |logits| ~ 4), so an absolute bar would send every trained checkpoint with
+        // logits of 10 to the fp32 kernels on rounding noise alone
+        g->env_probe_err_small = err[0]; g->env_probe_err_large = err[1];
+        g->env_probe_err = std::max(err[0], err[1]);
+        g->env_probe_max_logit = (max_logit == max_logit) ? max_logit : INFINITY;
+        g->env_probe_tol = std::max(MGPT_ENVELOPE_PROBE_TOL, MGPT_ENVELOPE_PROBE_REL * g->env_probe_max_logit);
+        inside = g->env_probe_err <= g->env_probe_tol;
     }
     g->env_state = inside ? 1 : 2;
     return MGPT_OK;
@@ -396,13 +426,16 @@ static int gpt_forward_impl(mgpt_gpt *g, const uint8_t *d_tokens, int rows, floa
             if (rc != MGPT_OK) return rc;
         }
         if (g->env_state == 2) {
+            char probe[160];
+            if (g->env_probe_err < 0.f) snprintf(probe, sizeof(probe), "not probed: the weight statistics decide");
+            else snprintf(probe, sizeof(probe), "probe |f16x3 - f32| %.3g (small calls) / %.3g (large calls) of %.3g at max |logit| %.3g",
+                          g->env_probe_err_small, g->env_probe_err_large, g->env_probe_tol, g->env_probe_max_logit);
             MGPT_REQUIRE(g->env_policy != MGPT_ENVELOPE_REFUSE, MGPT_ERR_UNSUPPORTED,
-                         "checkpoint outside the validated f16x3 envelope (max|w| %.3g, rms %.3g, probe |f16x3 - f32| %.3g)",
-                         g->env_max_w, g->env_max_rms, g->env_probe_err);
+                         "checkpoint outside the validated f16x3 envelope (max|w| %.3g, rms %.3g; %s)", g->env_max_w, g->env_max_rms, probe);
             if (!g->env_logged) {
-                fprintf(stderr, "mapf_gpt_amd: checkpoint outside the validated f16x3 envelope (max|w| %.3g of %.3g, rms %.3g of %.3g, probe |f16x3 - f32| %.3g of %.3g): "
+                fprintf(stderr, "mapf_gpt_amd: checkpoint outside the validated f16x3 envelope (max|w| %.3g of %.3g, rms %.3g of %.3g; %s): "
                                 "MGPT_PREC_F16X3 requests run the exact-fp32 kernels (mgpt_gpt_set_envelope_policy to refuse or to ignore)\n",
-                        g->env_max_w, MGPT_ENVELOPE_MAX_W, g->env_max_rms, MGPT_ENVELOPE_MAX_RMS, g->env_probe_err, MGPT_ENVELOPE_PROBE_TOL);
+                        g->env_max_w, MGPT_ENVELOPE_MAX_W, g->env_max_rms, MGPT_ENVELOPE_MAX_RMS, probe);
                 g->env_logged = true;
             }
             precision = MGPT_PREC_F32;

@@ -24,12 +24,18 @@ struct mgpt_gpt {
     uint64_t generation = 1;          // bumped when weight planes / workspaces are freed or rebuilt (common.h: gpt_generation)
     // precision envelope of the split-fp16 mode (gpt.hip: envelope_*; include/mapf_gpt_amd.h: mgpt_gpt_envelope)
     float env_max_w = 0.f, env_max_rms = 0.f;   // over the 2-D matrices of the blocks, computed by mgpt_gpt_finalize
-    float env_probe_err = -1.f;                 // max |f16x3 - f32| over the probe rows' logits (-1: not probed yet)
+    float env_probe_err = -1.f;                 // max |f16x3 - f32| over the probe rows' logits, both call regimes (-1: not probed)
+    float env_probe_err_small = -1.f, env_probe_err_large = -1.f;   // ... by regime: the kernels of calls <= / > kSmallRows rows
+    float env_probe_tol = 0.f, env_probe_max_logit = 0.f;           // the bar it was held to, and max |logit| of the fp32 path
     int env_policy = 0;                         // MGPT_ENVELOPE_FALLBACK / _REFUSE / _IGNORE
     int env_state = 0;                          // 0 not decided, 1 inside, 2 outside
     bool env_logged = false;
 };
 
+
+// calls of up to kSmallRows rows (one environment) run other kernels than larger ones (head-parallel attention, 32 x 32 x 16 MLP
+// block, one-launch last layer): gpt_fast.hip, DESIGN.md section 3.2
+constexpr int kSmallRows = 128;
 
 // gpt_fast.hip: 16-bit-MFMA path (packed operand planes, own workspace)
 int gpt_fast_finalize(mgpt_gpt *g);

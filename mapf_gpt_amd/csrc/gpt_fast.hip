@@ -74,9 +74,8 @@ constexpr bool kLast1 = false;
 constexpr bool kLast1 = true;
 #endif
 
-// rows up to which the C = 64 / 160 attention block runs head-parallel: beyond ~164 rows of 5 heads the (row, head) workgroups
-// need more rounds on 256 CUs than one workgroup per row takes (25 us against 80 us per workgroup, profiles/r02_cfg1_step_trace.txt)
-constexpr int kSmallRows = 128;
+// kSmallRows (gpt_ctx.h): rows up to which the C = 64 / 160 attention block runs head-parallel: beyond ~164 rows of 5 heads the (row, head)
+// workgroups need more rounds on 256 CUs than one workgroup per row takes (25 us against 80 us per workgroup, profiles/r02_cfg1_step_trace.txt)
 
 struct PlaneSet {           // one weight matrix [N][K] as 16-bit planes
     uint16_t *hi = nullptr, *lo = nullptr;

@@ -114,7 +114,11 @@ class GPT:
         _lib.check(_lib.lib().mgpt_gpt_envelope(self._h, out, ctypes.byref(st)))
         state = ("undecided", "inside", "outside")[st.value]
         eff = "f32" if (state == "outside" and self.envelope_policy == "fallback") else "f16x3"
+        pr = (ctypes.c_float * 4)()
+        _lib.check(_lib.lib().mgpt_gpt_envelope_probe(self._h, pr))
         return {"max_abs_w": float(out[0]), "max_rms_w": float(out[1]), "probe_err": (None if out[2] < 0 else float(out[2])),
+                "probe_err_small_calls": (None if pr[0] < 0 else float(pr[0])), "probe_err_large_calls": (None if pr[1] < 0 else float(pr[1])),
+                "probe_tol": (None if out[2] < 0 else float(pr[2])), "probe_max_logit": (None if out[2] < 0 else float(pr[3])),
                 "state": state, "policy": self.envelope_policy, "effective_precision": eff}
 
     # ---- compute ---------------------------------------------------------------------------

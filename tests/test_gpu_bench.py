@@ -48,6 +48,12 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     assert "32 total" in j["config"]["workload"] and f"{8 * 4 * 128} rows/step" in j["config"]["workload"]
     assert abs(j["value"] - 8 * 4 * 128 * 2 / (j["ms_per_step"] * 2e-3)) <= 1e-6 * j["value"]
     assert j["rccl_ranks"] is None                       # only the RCCL ("nccl") backend reports its rank count
+    # the N > 1 line explains itself -- every rank's own time, clock, power and the PCI address it bound to
+    pr = j["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(8)) and all(r["ms_per_step"] > 0 and len(r["pci"]) == 12 for r in pr), pr
+    assert max(r["ms_per_step"] for r in pr) <= j["ms_per_step"] * (1 + 1e-6) + 1e-6        # the headline is the max over ranks
+    assert len({r["pci"] for r in pr}) == 1                                                 # the dry run shares one GPU -- and the line shows it
+    assert all("sclk_mhz_mean" in r and "socket_power_w_mean" in r for r in pr)
 
 
 def test_bench_single_rank_line():
@@ -59,6 +65,12 @@ def test_bench_single_rank_line():
     assert j["n_gpus"] == 1 and j["config"]["workload"].startswith("cfg3: wfi_warehouse, 192 agents, MAPF-GPT-6M")
     assert j["unit"] == "agent-steps/s" and j["dtype"] == "f16x3" and j["vs_baseline"] is None
     assert j["roofline"]["bound"] == "mfma" and j["roofline_tokenizer"]["bound"] == "hbm"
+    # the episode boundary in a reported number and what the f16x3 request actually ran
+    c = j["config"]
+    assert c["reset_ms_per_episode"] > 0 and abs(c["amortised_reset_ms_per_step"] * c["max_episode_steps"] - c["reset_ms_per_episode"]) < 1e-9
+    assert c["timed_region_crosses_episode_boundary"] is False
+    assert j["effective_precision"] == "f16x3" and j["precision_envelope"]["state"] == "inside"
+    assert len(j["per_rank"]) == 1 and j["per_rank"][0]["rank"] == 0
 
 
 def test_bench_rccl_branch_with_one_rank():

@@ -327,6 +327,19 @@ def test_precision_envelope_is_a_runtime_property():
     ok.logits_tokens(tok)
     e = ok.envelope()
     assert e["state"] == "inside" and e["effective_precision"] == "f16x3" and e["probe_err"] <= 1e-5 and e["max_abs_w"] < 0.2, e
+    # the probe covers BOTH call regimes (the kernels of calls <= 128 rows and of larger calls differ in arithmetic), and its
+    # bar is absolute (1e-5) only while the logits are of order one
+    assert e["probe_err_small_calls"] is not None and e["probe_err_large_calls"] is not None, e
+    assert e["probe_err"] == max(e["probe_err_small_calls"], e["probe_err_large_calls"]) and 0 < e["probe_max_logit"] < 3.0, e
+    assert e["probe_tol"] == pytest.approx(max(1e-5, 64 * 2.0 ** -23 * e["probe_max_logit"]), rel=1e-5), e
+    # ... and the large-call error it saw is the error a large call has: the same 16 rows as a chunk of a 200-row call
+    big = build_model("6M", seed=0, max_rows=256, precision="f16x3", envelope="ignore")
+    pad = torch.from_numpy(np.concatenate([rows] * 13)[:200]).cuda()
+    exact = build_model("6M", seed=0, max_rows=256, precision="f32")
+    d_large = float((big.logits_tokens(pad) - exact.logits_tokens(pad)).abs().max())
+    assert d_large <= 1e-5 and e["probe_err_large_calls"] <= 1e-5, (d_large, e)
+    record_parity(test="envelope_probe_regimes", shape="6M", probe_small=e["probe_err_small_calls"], probe_large=e["probe_err_large_calls"],
+                  large_call_200_rows=d_large, probe_tol=e["probe_tol"], probe_max_logit=e["probe_max_logit"])
     sd = weights.synthetic_state_dict("6M", seed=3)
     for k, v in sd.items():
         if v.ndim == 2 and "wte" not in k and "wpe" not in k:
@@ -349,6 +362,52 @@ def test_precision_envelope_is_a_runtime_property():
     x8 = build_model("6M", seed=0, scale=8.0, precision="f16x3", max_rows=16)
     x8.logits_tokens(tok)
     assert x8.envelope()["state"] == "outside" and x8.envelope()["max_rms_w"] > 0.1
+
+
+def test_envelope_bar_is_relative_once_the_logits_are_large():
+    """a checkpoint whose logits are of order ten (what trained checkpoints produce) sits 1e-5 .. 1e-4 from ANY fp32 forward by
+    rounding alone (the reference's own fp32 run is 3.6e-5 from its fp64 run at |logits| ~ 4).  The probe's bar is
+    max(1e-5, 64 eps |logit|max): wte x 6 scales the tied head's logits without leaving the weight-statistics envelope (wte / wpe are not block
+    matrices), the checkpoint stays inside, and the split path is as close to the fp64 port as torch's own fp32 forward."""
+    from mapf_gpt_amd.model import build_model
+    from oracle import gpt_oracle
+    rows = np.load(os.path.join(GOLDEN, "gptbig_6M_s1.npz"))["tokens"][:16]
+    tok = torch.from_numpy(rows).cuda()
+    sd = {k: np.array(v, copy=True) for k, v in weights.synthetic_state_dict("6M", seed=0).items()}
+    sd["transformer.wte.weight"] = sd["transformer.wte.weight"] * np.float32(6.0)
+    sd["lm_head.weight"] = sd["transformer.wte.weight"]                      # tied
+    net = build_model("6M", precision="f16x3", max_rows=16, state_dict=sd)
+    got = net.logits_tokens(tok).cpu().numpy()
+    e = net.envelope()
+    ref64 = gpt_oracle.forward_logits(sd, weights.model_args("6M"), rows, dtype=torch.float64).numpy()
+    ref32 = gpt_oracle.forward_logits(sd, weights.model_args("6M"), rows).numpy().astype(np.float64)
+    e_ref, e_got = np.abs(ref32 - ref64).max(), np.abs(got - ref64).max()
+    record_parity(test="envelope_relative_bar", shape="6M", max_abs_logit=float(np.abs(ref64).max()), probe_err=e["probe_err"], probe_tol=e["probe_tol"],
+                  probe_max_logit=e["probe_max_logit"], e_split_vs_fp64=e_got, e_torch_fp32_vs_fp64=e_ref, state=e["state"])
+    assert e["probe_max_logit"] > 2.0 and e["probe_tol"] > 1e-5, e
+    assert e["state"] == "inside" and e["effective_precision"] == "f16x3", e
+    assert e_got <= max(TOL, 3.0 * e_ref), f"split path {e_got:.3e} against the fp64 port, torch fp32 {e_ref:.3e}"
+
+
+def test_first_f16x3_forward_refuses_a_stream_capture():
+    """the envelope probe allocates and synchronises; inside a capture the call must fail with a clear state error instead of
+    invalidating the capture, and the same forward works once the envelope is decided."""
+    from mapf_gpt_amd.model import build_model
+    rows = np.load(os.path.join(GOLDEN, "gptbig_6M_s1.npz"))["tokens"][:4]
+    tok = torch.from_numpy(rows).cuda()
+    net = build_model("tiny", seed=0, max_rows=4, precision="f16x3")
+    out = torch.empty((4, 67), dtype=torch.float32, device="cuda")
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with pytest.raises(RuntimeError, match="captur"):
+            with torch.cuda.graph(g, stream=s):
+                net.logits_tokens(tok, out=out)
+    torch.cuda.synchronize()
+    assert net.envelope()["state"] == "undecided"
+    net.logits_tokens(tok, out=out)
+    torch.cuda.synchronize()
+    assert net.envelope()["state"] == "inside"
 
 
 @pytest.mark.parametrize("offset", [0.5, 2.0])
