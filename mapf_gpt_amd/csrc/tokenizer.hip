@@ -473,7 +473,8 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
         for (int u = 0; u < U; u++) {
             uint8_t *rw = row + u * kRowBytes;
             const uint32_t my0 = my0s[q0 + u];
-            reinterpret_cast<uint2 *>(rw)[lane] = make_uint2(padv, padv);
+            // "!" (cpp:375-376, 386-387) over bytes 4 .. 259: tokens 3 .. 258; tokens 0 .. 2 are window cells, written below
+            *reinterpret_cast<uint32_t __attribute__((may_alias)) *>(rw + 4 + 4 * lane) = padv;
 
             // --- window tokens (cpp:288-311 + vocabulary cpp:321-357), both cells of the lane as one packed pair ---
             const uint32_t P = (w1[q0 + u] << 16) | w0[q0 + u];
