@@ -445,7 +445,9 @@ def build_workload(name, precision, rank, world, local_rank, instances=0, use_gr
     n_total = inst_per_gpu * world
     lo, hi = shard_range(n_total, rank, world)
     rows = (hi - lo) * n_agents
-    chunk = min(rows, chunk_rows or (16384 if model != "85M" else 1024))
+    # rows per forward launch.  85M: 4096 (round 6, tools/sweep_chunk85.sh: 1024 -> 1602, 2048 -> 1587, 4096 -> 1573 ms per cfg5 step; launches of
+    # <= 512 rows are SLOWER -- the q|k|v and hidden planes of a small launch do not come back from the memory-side cache)
+    chunk = min(rows, chunk_rows or (16384 if model != "85M" else 4096))
     net = build_model(model, seed=0, max_rows=chunk, precision=precision, device=f"cuda:{local_rank}")
     if name == "cfg4":                     # one map per instance, seeded by the global instance id
         grid, pos, goal = cfg4_instances(lo, hi, n_agents)
@@ -625,7 +627,7 @@ def main():
                     help="default: cfg3 at --gpus 1, cfg4 (its per-GPU shard) at --gpus N > 1")
     ap.add_argument("--precision", default=os.environ.get("MGPT_BENCH_PRECISION", "f16x3"), choices=["f32", "f16x3", "bf16"])
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default: the workload's)")
-    ap.add_argument("--chunk-rows", type=int, default=0, help="rows per forward launch (default 16384; 1024 for the 85M shape)")
+    ap.add_argument("--chunk-rows", type=int, default=0, help="rows per forward launch (default 16384; 4096 for the 85M shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tokenizer-leg", action="store_true", help="skip the >=1e5-row tokenizer roofline launch")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg2 run reported under 'secondary'")

@@ -26,15 +26,15 @@ KEYS = [  # (json key, kernel substring, grid, note)
      "go to the 56-MiB spill slab (written and read back by the same wave, L2 / memory-side cache) instead of a 3.22-GB y matrix + GEMM"),
     ("cfg3_f16x3_gpt_attention_last_layer", "attn_last1_kernel<256, 32>", 1572864,
      "last layer (attn_last1_kernel): all of x read once, only token 255's new row written (compact)"),
-    ("cfg3_tok_generate_observations", "tokens_kernel<4, 4>", 196608, "cfg3's own launch: 64 instances x 192 agents"),
+    ("cfg3_tok_generate_observations", "tokens_kernel<3, 4>", 196608, "cfg3's own launch: 64 instances x 192 agents"),
     ("cfg4_tok_generate_observations_65536_rows", "tokens_kernel<2, 4>", 1048576, "cfg4 per-GPU shard: 512 instances x 128 agents, per-instance maps"),
-    ("tok_generate_observations_524160_rows", "tokens_kernel<4, 16>", 2096640, "2730 instances x 192 agents on the warehouse map"),
+    ("tok_generate_observations_524160_rows", "tokens_kernel<3, 8>", 4193280, "2730 instances x 192 agents on the warehouse map (round 6: three candidate passes, 8 rows per wavefront)"),
 ]
 
-KEYS5 = [  # from the cfg5 passes (bench.py --workload cfg5 --precision bf16, launches of 1024 rows = 262 144 tokens)
-    ("cfg5_bf16_gpt_gemm_mlp_fc", "gemm_pk16_kernel<mgpt::fastk::BF16T, 3, 8, true>", 6291456,
-     "c_fc of the 85M bf16 chain (LayerNorm folded): raw operand planes of 262 144 tokens x 768 in, hidden planes x 3072 out, weight tiles from L2"),
-    ("cfg5_bf16_gpt_gemm_mlp_proj", "gemm_pk16_kernel<mgpt::fastk::BF16T, 2, 8, false>", 1572864,
+KEYS5 = [  # from the cfg5 passes (bench.py --workload cfg5 --precision bf16, launches of 4096 rows = 1 048 576 tokens since round 6)
+    ("cfg5_bf16_gpt_gemm_mlp_fc", "gemm_pk16_kernel<mgpt::fastk::BF16T, 3, 8, true>", 25165824,
+     "c_fc of the 85M bf16 chain (LayerNorm folded): raw operand planes of 1 048 576 tokens x 768 in, hidden planes x 3072 out, weight tiles from L2"),
+    ("cfg5_bf16_gpt_gemm_mlp_proj", "gemm_pk16_kernel<mgpt::fastk::BF16T, 2, 8, false>", 6291456,
      "residual GEMMs of the 85M bf16 chain (attention out-projection K = 768 and mlp.c_proj K = 3072 share this instantiation: the average mixes both)"),
 ]
 
@@ -63,6 +63,6 @@ if len(sys.argv) >= 6:
         fr = f5[fk[0]][1]
         wr = w5[wk[0]][1] if wk else 0.0
         out[key] = {"kernel": sub, "grid_threads": grid, "dispatches": f5[fk[0]][0], "fetch_raw": fr, "fetch_corrected_x2": 2 * fr, "write": wr, "note": note,
-                    "rows_per_launch": 1024}
+                    "rows_per_launch": 4096}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: (round(v["fetch_corrected_x2"] / 1e6, 1), round(v["write"] / 1e6, 1)) for k, v in out.items() if isinstance(v, dict)}, indent=1))
