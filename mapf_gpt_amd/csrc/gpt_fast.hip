@@ -739,7 +739,14 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         g->generation++;
     }
     // the first attention block forms x = wte[token] + wpe[position] itself (no embedding kernel, no first read of x)
-    const bool embed_fused = attn_block && g->L > 1 && !head_par;
+    // ... unless the persistent block kernel of the 2M shape serves the layer (round 6, profiles/r06_ab.txt visit B): embed_tiled_kernel (0.6 ms per 16 384 rows)
+    // + attn160o_kernel (4.5 ms) beat attn_block_kernel<EMBED> (5.8 ms), the round-1 kernel the first layer had stayed on because it gathers the embedding
+#if defined(MGPT_AB_EMBED_FUSED_160)
+    const bool persistent160 = false;
+#else
+    const bool persistent160 = attn_block && C == 160 && !head_par && m->attn160o_spill != nullptr && kAttn160o && m->x_tiled;
+#endif
+    const bool embed_fused = attn_block && g->L > 1 && !head_par && !persistent160;
     if (m->x_tiled && !embed_fused) {
         ProfScope ps(P_EMBED, s);
         hipLaunchKernelGGL(fastk::embed_tiled_kernel, dim3((unsigned)(M / 32)), dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, C);
