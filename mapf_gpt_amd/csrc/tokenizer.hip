@@ -143,10 +143,24 @@ __device__ __forceinline__ void window_origin(AgentRec &r, int gstep, int R)
     r.org[1] = (uint8_t)(max(r.pc - R, 0) / gstep);
 }
 
+// What tokens_kernel needs of a row before it can gather: {packed position, window origin | flags}.  Bits 0..28 of y: offset of the window's
+// first cell in the agent's field (H * W <= 2^22); bit 30: window not wholly inside the frame (cells read one by one, out-of-frame = wall);
+// bit 29: the window's last cell is the unseeded corner of the agent's cached partial window (cpp:178-198).  Kept per agent by create / update
+// (round 6: tokens_kernel formed it per wave -- ~25 vector instructions shared by only 4 or 8 rows).
+__device__ __forceinline__ uint2 row_header(const AgentRec &r, int H, int W, int gstep, int R)
+{
+    const int pr = r.pr, pc = r.pc;
+    const bool inside = pr >= R && pr + R < H && pc >= R && pc + R < W;
+    const int cr = gstep * ((int)r.org[0] + 2), cc = gstep * ((int)r.org[1] + 2);
+    const bool corner = cr <= H - 1 && cc <= W - 1 && pr + R == cr && pc + R == cc;
+    const uint32_t my0 = (uint32_t)(uint16_t)r.pr | ((uint32_t)(uint16_t)r.pc << 16);
+    return make_uint2(my0, inside ? ((uint32_t)((pr - R) * W + (pc - R)) | (corner ? 0x20000000u : 0u)) : 0x40000000u);
+}
+
 // create_agents, cpp:391-410 (history <- "n" x 5)
 __global__ __launch_bounds__(256) void tok_create_kernel(AgentRec *__restrict__ recs, const int16_t *__restrict__ pos,
                                                          const int16_t *__restrict__ goal, int total,
-                                                         int *__restrict__ u8_ok, int gstep, const TokCfg cfg)
+                                                         int *__restrict__ u8_ok, int gstep, const TokCfg cfg, uint2 *__restrict__ hdrs, int H, int W)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) *u8_ok = 1;          // every field is rebuilt next; bfs_kernel clears it if one does not fit a byte
@@ -159,6 +173,7 @@ __global__ __launch_bounds__(256) void tok_create_kernel(AgentRec *__restrict__ 
     r.next = (uint8_t)cfg.tok_bits0();
     window_origin(r, gstep, cfg.R);                                                                 // cpp:408
     recs[i] = r;
+    hdrs[i] = row_header(r, H, W, gstep, cfg.R);
 }
 
 // update_agents, cpp:432-485: position, action history (intended action of the previous step),
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(256) void tok_update_kernel(AgentRec *__restrict__ 
                                                          const int32_t *__restrict__ actions, uint8_t *__restrict__ dirty,
                                                          int total, int check_goals, const uint16_t *__restrict__ dist,
                                                          int H, int W, int gstep, const uint8_t *__restrict__ active, int n_agents,
-                                                         const TokCfg cfg)
+                                                         const TokCfg cfg, uint2 *__restrict__ hdrs)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -199,6 +214,7 @@ __global__ __launch_bounds__(256) void tok_update_kernel(AgentRec *__restrict__ 
         r.next = (uint8_t)next_action_token(dist + (size_t)i * H * W, H, W, r.pr, r.pc, cfg.tok_bits0());   // cpp:483-484
     }
     recs[i] = r;
+    hdrs[i] = row_header(r, H, W, gstep, cfg.R);
 }
 
 __global__ __launch_bounds__(256) void tok_next_kernel(AgentRec *__restrict__ recs, int total,
@@ -307,7 +323,8 @@ template <int KP, int RPW>
 __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict__ recs, const uint16_t *__restrict__ dist,
                                                      const uint8_t *__restrict__ dist8, const int *__restrict__ u8_ok,
                                                      int n_agents, int H, int W, int chunks_per_inst,
-                                                     uint8_t *__restrict__ tokens, int gstep, const TokCfg p)
+                                                     uint8_t *__restrict__ tokens, int gstep, const TokCfg p,
+                                                     const uint2 *__restrict__ hdrs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (read here, consumed at the window gathers: the flag's round trip overlaps the record loads below.  Rounds 1-5 branched on it
@@ -341,23 +358,13 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
     const uint4 *grec = reinterpret_cast<const uint4 *>(recs) + row0;
     const int a_begin = chunk * APB;
 
-    // This wave's rows first: lane q reads the record of row q (agent a_begin + wave + 4 q) straight from memory, so that the window
-    // gathers below start one round trip earlier than the records staged for the neighbour search (which every row of the chunk shares)
+    // This wave's rows first: lane q reads the header of row q (agent a_begin + wave + 4 q; kept by create / update: row_header), so that the
+    // window gathers below start one round trip earlier than the records staged for the neighbour search (which every row of the chunk shares)
     uint2 hv = make_uint2(0u, 0x80000000u);              // {packed position, window origin | flags}; bit 31: no such agent
     {
         const int a = a_begin + wave + 4 * (lane & (RPW - 1));
-        const uint4 me = grec[min(a, n_agents - 1)];     // (one unconditional 16-byte load: under the condition hipcc split it into two dependent ones)
-        {   // (branch-free, 24-bit multiplies: this block runs once per wave, but a wave owns only RPW rows)
-            const uint32_t my0 = me.x;
-            const int pr = (int16_t)(my0 & 0xffffu), pc = (int16_t)(my0 >> 16);
-            const bool inside = pr >= R && pr + R < H && pc >= R && pc + R < W;       // whole window inside the frame
-            // is the unseeded corner of the agent's cached partial window (cpp:178-198) the window's last cell?
-            const int cr = __mul24(gstep, (int)((me.w >> 16) & 0xffu) + 2), cc = __mul24(gstep, (int)(me.w >> 24) + 2);
-            const bool corner = cr <= H - 1 && cc <= W - 1 && pr + R == cr && pc + R == cc;
-            // bits 0..28: offset of the window's first cell in the field (H * W <= 2^22); bit 30: window not wholly inside; bit 29: corner
-            const uint32_t org = (uint32_t)(__mul24(pr - R, W) + (pc - R)) | (corner ? 0x20000000u : 0u);
-            hv = make_uint2(my0, a < n_agents ? (inside ? org : 0x40000000u) : 0x80000000u);
-        }
+        const uint2 h = hdrs[row0 + min(a, n_agents - 1)];     // (unconditional: one load, no exec juggling)
+        if (a < n_agents) hv = h;
     }
     uint4 stage[(KP * 64 + 255) / 256];                  // the instance's records, on their way to LDS
 #pragma unroll
@@ -373,7 +380,10 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
     uint16_t *list = slist + wave * (U * kListEntries);
     uint16_t *cand = scand + wave * (U * CW);
     const int cells = H * W;
-    // window cells of this lane: index lane and lane + 64 (lanes without one repeat cell 0 and store into the dump space)
+    // window cells of this lane: index lane and lane + 64 (lanes without one repeat cell 0 and store into the dump space).
+    // (Computed here with 24-bit multiplies and the host's reciprocal of the window side.  A 1-KiB table of these per-lane constants read by
+    //  every wave was built and measured: 15 vector instructions fewer per wave and 104 -> 122 us per 524 160 rows -- 65 520 waves fetching
+    //  the same eight cache lines serialise on their L2 channels.)
     const bool has0 = lane < ncell, has1 = lane + 64 < ncell;
     const int c0 = has0 ? lane : 0, c1 = has1 ? lane + 64 : 0;
     const int i0 = __mul24(c0, p.rwin) >> 16, j0 = c0 - __mul24(i0, win), i1 = __mul24(c1, p.rwin) >> 16, j1 = c1 - __mul24(i1, win);
@@ -815,6 +825,7 @@ struct mgpt_tokenizer {
     int *u8_ok = nullptr;
     AgentRec *recs = nullptr;
     uint8_t *dirty = nullptr;
+    uint2 *hdrs = nullptr;              // per agent: row_header (position, window origin, flags), kept by create / update for tokens_kernel
     bool have_grids = false, have_agents = false;
 };
 
@@ -855,7 +866,11 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
     t->cfg = TokCfg{cfg->cost2go_value_limit, cfg->num_agents, cfg->num_previous_actions, cfg->obs_radius, cfg->agents_radius,
                     65536 / (2 * cfg->obs_radius + 1) + 1};
     for (int c = 0; c < 128; c++)                       // the kernel's division of a cell index by the window side
-        MGPT_REQUIRE(((c * t->cfg.rwin) >> 16) == c / (2 * cfg->obs_radius + 1), MGPT_ERR_UNSUPPORTED, "reciprocal of the window side inexact at %d", c);
+        if (((c * t->cfg.rwin) >> 16) != c / (2 * cfg->obs_radius + 1)) {
+            set_error("reciprocal of the window side inexact at %d", c);
+            delete t;
+            return MGPT_ERR_UNSUPPORTED;
+        }
     const size_t cells = (size_t)H * W, total = (size_t)n_inst * n_agents;
     hipError_t e = hipMalloc(&t->grids, (size_t)n_grids * cells);
     if (e == hipSuccess) e = hipMalloc(&t->dist, total * cells * sizeof(uint16_t));
@@ -863,6 +878,7 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
     if (e == hipSuccess) e = hipMalloc(&t->u8_ok, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&t->recs, total * sizeof(AgentRec));
     if (e == hipSuccess) e = hipMalloc(&t->dirty, total);
+    if (e == hipSuccess) e = hipMalloc(&t->hdrs, total * sizeof(uint2));
     if (e != hipSuccess) {
         set_error("hipMalloc failed in mgpt_tokenizer_create: %s", hipGetErrorString(e));
         mgpt_tokenizer_destroy(t);
@@ -876,7 +892,7 @@ extern "C" int mgpt_tokenizer_destroy(mgpt_tokenizer *t)
 {
     if (!t) return MGPT_OK;
     (void)hipFree(t->grids); (void)hipFree(t->dist); (void)hipFree(t->dist8); (void)hipFree(t->u8_ok);
-    (void)hipFree(t->recs); (void)hipFree(t->dirty);
+    (void)hipFree(t->recs); (void)hipFree(t->dirty); (void)hipFree(t->hdrs);
     delete t;
     return MGPT_OK;
 }
@@ -915,7 +931,7 @@ extern "C" int mgpt_tokenizer_create_agents(mgpt_tokenizer *t, const int16_t *d_
     {
         ProfScope ps(P_TOK_UPDATE, s);
         hipLaunchKernelGGL(tok_create_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, d_pos, d_goal, total,
-                           t->u8_ok, t->step, t->cfg);
+                           t->u8_ok, t->step, t->cfg, t->hdrs, t->H, t->W);
         MGPT_LAUNCH_CHECK();
     }
     int rc = launch_bfs(t, nullptr, s);
@@ -946,7 +962,7 @@ extern "C" int mgpt_tokenizer_update_agents_masked(mgpt_tokenizer *t, const int1
     {
         ProfScope ps(P_TOK_UPDATE, s);
         hipLaunchKernelGGL(tok_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t->recs, d_pos, d_goal, d_actions,
-                           t->dirty, total, goals_may_change ? 1 : 0, t->dist, t->H, t->W, t->step, d_active, t->n_agents, t->cfg);
+                           t->dirty, total, goals_may_change ? 1 : 0, t->dist, t->H, t->W, t->step, d_active, t->n_agents, t->cfg, t->hdrs);
         MGPT_LAUNCH_CHECK();
     }
     if (goals_may_change) {
@@ -981,7 +997,7 @@ extern "C" int mgpt_tokenizer_generate_observations(mgpt_tokenizer *t, uint8_t *
     ProfScope ps(P_TOKENS, s);
 #define MGPT_TOKENS_R(KP_, RPW_)                                                                                       \
     hipLaunchKernelGGL((tokens_kernel<KP_, RPW_>), dim3(t->n_inst, chunks), dim3(256), smem, s, t->recs, t->dist,      \
-                       t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step, t->cfg)
+                       t->dist8, t->u8_ok, t->n_agents, t->H, t->W, chunks, d_tokens, t->step, t->cfg, t->hdrs)
 #define MGPT_TOKENS(KP_)                                                                                              \
     do {                                                                                                              \
         if (rpw == 16) MGPT_TOKENS_R(KP_, 16);                                                                        \
