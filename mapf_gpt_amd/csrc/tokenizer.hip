@@ -255,9 +255,10 @@ __global__ __launch_bounds__(256) void tok_next_kernel(AgentRec *__restrict__ re
 // arguments: they sit in scalar registers and cost the default configuration nothing.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowsInterleaved = 4; // rows a wave works on at once (U)
-constexpr int kRowBytes = 512;      // one row image: token t at byte t+1; bytes >= 264 are dump space
+constexpr int kRowBytes = 304;      // one row image: token t at byte t+1 (1 .. 256, read back as dwords up to byte 259); bytes 264 .. 295 are dump space.
+                                    // (512 until round 6: with 304 the 192-agent instance fits EIGHT workgroups on a CU instead of six)
 constexpr int kRowImage = kRowsInterleaved * kRowBytes;   // per wave
-constexpr int kDumpTok = 320;       // where lanes without a window cell put their byte (inside the 512-B image, never read)
+constexpr int kDumpTok = 264;       // where lanes without a window cell put their byte (inside the image, never read)
 constexpr int kBktBytes = 1024;     // per wave: 64 x 16 B {mask lo, mask hi, prefix, -}; entry 16 u + d = distance bucket d of row u
 constexpr int kListEntries = 16;    // per row: rank -> key (uint16; kNoKey = empty); num_agents <= 16
 constexpr unsigned kNoKey = 0xffffu;
@@ -388,8 +389,8 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
     const int c0 = has0 ? lane : 0, c1 = has1 ? lane + 64 : 0;
     const int i0 = __mul24(c0, p.rwin) >> 16, j0 = c0 - __mul24(i0, win), i1 = __mul24(c1, p.rwin) >> 16, j1 = c1 - __mul24(i1, win);
     const uint32_t off0 = (uint32_t)(__mul24(i0, W) + j0), off1 = (uint32_t)(__mul24(i1, W) + j1);
-    uint8_t *tok0_at = row + (has0 ? 1 + lane : kDumpTok + lane);
-    uint8_t *tok1_at = row + (has1 ? 65 + lane : kDumpTok + 64 + lane);
+    uint8_t *tok0_at = row + (has0 ? 1 + lane : kDumpTok + (lane & 15));
+    uint8_t *tok1_at = row + (has1 ? 65 + lane : kDumpTok + 16 + (lane & 15));
     const int centre_lane = R * win + R;                                 // < 64 for every R <= 5
     // emission: lane 16 u + s writes record s of row u
     const int eu = lane >> 4, es = lane & 15;
@@ -484,7 +485,9 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
             uint8_t *rw = row + u * kRowBytes;
             const uint32_t my0 = my0s[q0 + u];
             // "!" (cpp:375-376, 386-387) over bytes 4 .. 259: tokens 3 .. 258; tokens 0 .. 2 are window cells, written below
+#if !defined(MGPT_ABL_TOK) || (MGPT_ABL_TOK != 4)
             *reinterpret_cast<uint32_t __attribute__((may_alias)) *>(rw + 4 + 4 * lane) = padv;
+#endif
 
             // --- window tokens (cpp:288-311 + vocabulary cpp:321-357), both cells of the lane as one packed pair ---
             const uint32_t P = (w1[q0 + u] << 16) | w0[q0 + u];
@@ -500,8 +503,12 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
             t = t + e + e;
             const us2 isunr = (us2){0, 0} - __builtin_elementwise_sub_sat(as_us2(P), as_us2(unrm2));   // 0xffff iff v = UNR (cpp:308-309)
             const uint32_t tt = (as_u32(isunr) & unrtok2) | (~as_u32(isunr) & as_u32(t));               // -> one bit-select
-            tok0_at[u * kRowBytes] = (uint8_t)tt;
+#if !defined(MGPT_ABL_TOK) || (MGPT_ABL_TOK != 1)      // LDS ablations (results wrong; tools/tok_lds_ablation.sh): 1 window-token stores, 2 bucket atomics,
+            tok0_at[u * kRowBytes] = (uint8_t)tt;           // 3 emission (record gather + stores), 4 pad fill, 5 rank read-back + list
             tok1_at[u * kRowBytes] = (uint8_t)(tt >> 16);
+#else
+            asm volatile("" :: "v"(tt));
+#endif
 
             // --- neighbours: the (2A+1)^2 scan of cpp:492-495 on the LDS-resident positions ---
             const uint32_t myb = my0 ^ 0x80008000u;
@@ -554,7 +561,12 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
 #pragma unroll
         for (int u = 0; u < U; u++) {
             mine[u] = bkt + u * 16 + cmd[u];
+#if defined(MGPT_ABL_TOK) && (MGPT_ABL_TOK == 2)
+            asm volatile("" :: "v"(mine[u]));
+            if (false)
+#else
             if (have[u])                // divergent on purpose: same-address LDS atomics serialise, so only real neighbours issue one
+#endif
                 __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(mine[u]), 1ull << lane,
                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);        // ds_or_b64, order-independent
         }
@@ -572,7 +584,11 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
         // --- the first S leave their id at list[row][rank] (cpp:506) ---
 #pragma unroll
         for (int u = 0; u < U; u++) {
+#if defined(MGPT_ABL_TOK) && (MGPT_ABL_TOK == 5)
+            if (false) {
+#else
             if (have[u]) {
+#endif
                 const uint4 e = *mine[u];
                 // lower buckets + the bucket's candidates in lanes below this one (v_mbcnt: the lane mask is implicit)
                 const uint32_t r = __builtin_amdgcn_mbcnt_hi(e.y, __builtin_amdgcn_mbcnt_lo(e.x, e.z));
@@ -609,7 +625,11 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
         //     +-A), rel goal clamped to +-L, the last Hn history tokens oldest first, greedy-direction bits ---
         {
             const uint32_t k16 = list[lane];
+#if defined(MGPT_ABL_TOK) && (MGPT_ABL_TOK == 3)
+            if (false) {
+#else
             if (k16 != kNoKey) {
+#endif
                 const uint4 o = srec[k16];
                 const uint32_t my0 = hdr[wave * RPW + q0 + eu];
                 const ss2 base = as_ss2(my0) - as_ss2(rep16(L));                               // pos - L
