@@ -21,6 +21,7 @@ struct mgpt_gpt {
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *hbuf = nullptr, *logits_tmp = nullptr;
     // fast-path state (gpt_fast.hip)
     void *fast = nullptr;
+    float *embed_table = nullptr;     // C = 256: [256 positions][67 tokens][C] = wpe + wte, the rows layer 0's attention block starts from (gpt_fast.hip)
     uint64_t generation = 1;          // bumped when weight planes / workspaces are freed or rebuilt (common.h: gpt_generation)
     // precision envelope of the split-fp16 mode (gpt.hip: envelope_*; include/mapf_gpt_amd.h: mgpt_gpt_envelope)
     float env_max_w = 0.f, env_max_rms = 0.f;   // over the 2-D matrices of the blocks, computed by mgpt_gpt_finalize

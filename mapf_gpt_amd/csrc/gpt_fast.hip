@@ -292,6 +292,13 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                     MGPT_LAUNCH_CHECK();
                 }
                 MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256q_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
+                MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256q_kernel<T, NP, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
+                if (g->embed_table == nullptr) {       // (position, token) rows for layer 0 (attn256q_kernel<.., EMB>); one per checkpoint, shared by the modes
+                    MGPT_HIP(hipMalloc(&g->embed_table, (size_t)kT * kV * C * sizeof(float)));
+                    hipLaunchKernelGGL(fastk::embed_table_kernel, dim3((unsigned)cdiv64((int64_t)kT * kV * (C / 4), 256)), dim3(256), 0, nullptr,
+                                       g->params + g->off_wte, g->params + g->off_wpe, g->embed_table, C, kV);
+                    MGPT_LAUNCH_CHECK();
+                }
                 MGPT_HIP(hipMalloc(&m->attn256o_spill, (size_t)m->n_cu * 8 * 14 * NP * 1024));
                 MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn256o_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, kA256Lds<NP>));
             }
@@ -747,7 +754,15 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     const bool persistent160 = attn_block && C == 160 && !head_par && m->attn160o_spill != nullptr && kAttn160o && m->x_tiled;
 #endif
     const bool embed_fused = attn_block && g->L > 1 && !head_par && !persistent160;
-    if (m->x_tiled && !embed_fused) {
+    // ... and so does the 6M shape's persistent block kernel in a large call (attn256q_kernel<.., EMB>: from the (position, token) table, round 6)
+#if defined(MGPT_AB_EMBED_KERNEL_256)
+    const bool embed256 = false;
+#else
+    const bool embed256 = m->attn256 && kAttn256Fused && kAttn256Q && g->L > 1 && g->embed_table != nullptr && m->x_tiled &&
+                          !(call_rows <= kSmallRows && rows <= kSmallRows && kSmall256);
+#endif
+    if (embed256) {
+    } else if (m->x_tiled && !embed_fused) {
         ProfScope ps(P_EMBED, s);
         hipLaunchKernelGGL(fastk::embed_tiled_kernel, dim3((unsigned)(M / 32)), dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, C);
         MGPT_LAUNCH_CHECK();
@@ -865,7 +880,11 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
             // ---- the whole attention block (LN1, QKV, attention, out-projection, residual) in one persistent kernel: q, k, v, y stay on chip ----
             ProfScope ps(P_ATTN, s);
             // (gpt_kernels_c256b.h: the projection steps and the tail on v_mfma_f32_16x16x32, the attention phase as it was)
-            if (kAttn256Q)
+            if (kAttn256Q && embed256 && l == 0)
+                hipLaunchKernelGGL((fastk::attn256q_kernel<T, NP, 0, true>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
+                                   m->attn256q_pk[l], m->attn256_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn256o_spill, rows,
+                                   (unsigned long long *)nullptr, d_tokens, g->embed_table);
+            else if (kAttn256Q)
                 hipLaunchKernelGGL((fastk::attn256q_kernel<T, NP>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)kA256Lds<NP>, s, g->x,
                                    m->attn256q_pk[l], m->attn256_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn256o_spill, rows,
                                    (unsigned long long *)nullptr);
@@ -1087,6 +1106,8 @@ int gpt_fast_finalize(mgpt_gpt *g)
     FastState *f = static_cast<FastState *>(g->fast);
     if (f) {                                             // parameters changed: planes are rebuilt lazily
         for (auto &m : f->mode) free_mode(g, &m);
+        (void)hipFree(g->embed_table);                   // ... and so is the (position, token) table of layer 0
+        g->embed_table = nullptr;
     } else {
         g->fast = new FastState();
     }
@@ -1100,6 +1121,8 @@ void gpt_fast_destroy(mgpt_gpt *g)
     for (auto &m : f->mode) free_mode(g, &m);
     delete f;
     g->fast = nullptr;
+    (void)hipFree(g->embed_table);
+    g->embed_table = nullptr;
 }
 
 int gpt_fast_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, hipStream_t s, int call_rows)

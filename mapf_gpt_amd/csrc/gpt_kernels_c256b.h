@@ -76,10 +76,16 @@ __global__ __launch_bounds__(256) void pack_attn256q_kernel(const float *__restr
 // STAMPS (tools/bench_probes/check_attn256o.hip only): wave 0 of every workgroup leaves {entry cycles, entry 100-MHz ticks, cycles in
 // the prologues, in the q|k|v projection steps, in the attention phases (k / v barrier included), in the tail steps, in the
 // tail epilogues, exit ticks} summed over its rows.  STAMPS == 2: waves 0 and 4 leave the step-phase cycles (sphase below).
-template <class T, int NP, int STAMPS = 0>
+// EMB (layer 0 of a forward, round 6): the rows do not exist yet -- the prologue takes them from the (position, token) embedding table
+// etab[256 positions][67 tokens][C] = wpe[position] + wte[token] (model.py:171-175; built once per checkpoint, 17.5 MB: L2 / memory-side cache
+// resident) through the SAME 32 loads per lane with other addresses, and writes them to x from there (the tail's residual read finds them:
+// the same wave's stores, one attention phase earlier).  embed_tiled_kernel (0.75 ms per 12 288 rows: a 3.2-GB write) and the prologue's
+// 3.2-GB read of what it wrote are gone.
+template <class T, int NP, int STAMPS = 0, bool EMB = false>
 __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv_scale,
                                                           float scale_log2e, float inv_proj, unsigned char *__restrict__ spill,
-                                                          int n_rows, unsigned long long *stamps = nullptr)
+                                                          int n_rows, unsigned long long *stamps = nullptr,
+                                                          const unsigned char *__restrict__ tokens = nullptr, const float *__restrict__ etab = nullptr)
 {
     constexpr int C = 256, KS = 16, NH = 8, HS = 32, NW = 8;
     static_assert(NP == 2 || NP == 1, "planes");
@@ -137,6 +143,8 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
     for (int G = 0; G < NSLOT - 1; G++) issue(G);
     // top of stream step G, part 1: this wave's pieces of step G + 1 have landed (PENDING = vector-memory operations of this wave
     // issued after them), every LDS access of the step before is done, barrier
+    // (EMB: the first steps of a row's first head find the prologue's 32 row stores in flight and retire them with their counted waits.  Allowing
+    //  them to stay in flight -- + 32 on the first three steps' counts -- was built and measured: no difference, profiles/r06_ab.txt visit D)
     auto sync_wait = [&](auto pending_c) {
         vm_wait<decltype(pending_c)::value>();
         __builtin_amdgcn_s_barrier();
@@ -361,16 +369,46 @@ __global__ __launch_bounds__(512, 2) void attn256q_kernel(float *__restrict__ x,
             asm volatile("" : "+v"(l16p));
             const unsigned xoff_p = (l16p >> 8) * 1024 + ((l16p >> 4) & 15u) * 32;
             f32x4 xr[32];                                  // xr[2 (8 tg + kb) + hf] = features 32 kb + 8 q + 4 hf .. + 3 of token 16 tg + t
+            if constexpr (EMB) {
+                // ids of this lane's two tokens (tok0 + t, tok0 + 16 + t) -> byte offsets of their (position, token) table rows
+                const unsigned char *tk = tokens + b * kT + tok0;                                      // uniform
+                const unsigned tt_p = (l16p >> 4) & 15u;
+                unsigned id0, id1;
+                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(id0) : "v"(tt_p), "s"(tk) : "memory");
+                asm volatile("global_load_ubyte %0, %1, %2 offset:16" : "=v"(id1) : "v"(tt_p), "s"(tk) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(id0), "+v"(id1) : : "memory");
+                const unsigned q32 = (l16p >> 8) * 32u;
+                const unsigned ve0 = (((unsigned)tok0 + tt_p) * 67u + id0) * 1024u + q32;
+                const unsigned ve1 = (((unsigned)tok0 + 16u + tt_p) * 67u + id1) * 1024u + q32;
+                const unsigned char *eb = reinterpret_cast<const unsigned char *>(etab);
+#pragma unroll
+                for (int i = 0; i < 32; i++) {             // k-block i / 4: features 32 kb + 8 q + 4 hf of the row -> byte kb * 128 + q * 32 + hf * 16
+                    if (((i >> 1) & 1) == 0)
+                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr[2 * (i >> 2) + (i & 1)]) : "v"(ve0), "s"(eb), "n"((i >> 2) * 128 + (i & 1) * 16) : "memory");
+                    else
+                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr[2 * (8 + (i >> 2)) + (i & 1)]) : "v"(ve1), "s"(eb), "n"((i >> 2) * 128 + (i & 1) * 16) : "memory");
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 32; i++) {
                 const unsigned char *xq = xw + (i >> 2) * 4096;   // k-block i / 4 (13-bit immediate offsets: one base per k-block); i % 4 = (tg, hf)
                 asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr[2 * (8 * ((i >> 1) & 1) + (i >> 2)) + (i & 1)]) : "v"(xoff_p), "s"(xq), "n"(((i >> 1) & 1) * 512 + (i & 1) * 16) : "memory");
+            }
             }
             // everything older (ring pieces, the previous row's last stores) retires with them: vmcnt(0)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) : : "memory");
             asm volatile("" : "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]), "+v"(xr[15]));
             asm volatile("" : "+v"(xr[16]), "+v"(xr[17]), "+v"(xr[18]), "+v"(xr[19]), "+v"(xr[20]), "+v"(xr[21]), "+v"(xr[22]), "+v"(xr[23]));
             asm volatile("" : "+v"(xr[24]), "+v"(xr[25]), "+v"(xr[26]), "+v"(xr[27]), "+v"(xr[28]), "+v"(xr[29]), "+v"(xr[30]), "+v"(xr[31]));
+            if constexpr (EMB) {
+                // the rows' first appearance in x (chunk-major, the addresses the loads above would have had).  The 32 stores are younger than
+                // every ring piece in flight: the first steps' counted waits simply retire them too (vector-memory operations retire in order)
+#pragma unroll
+                for (int i = 0; i < 32; i++) {
+                    const unsigned char *xq = xw + (i >> 2) * 4096;
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(xoff_p), "v"(xr[2 * (8 * ((i >> 1) & 1) + (i >> 2)) + (i & 1)]), "s"(xq), "n"(((i >> 1) & 1) * 512 + (i & 1) * 16) : "memory");
+                }
+            }
             float rstd[2];
 #pragma unroll
             for (int tg = 0; tg < 2; tg++) {

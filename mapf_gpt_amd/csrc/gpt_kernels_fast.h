@@ -247,6 +247,17 @@ __global__ __launch_bounds__(256) void untile_rows_kernel(const float *__restric
     *reinterpret_cast<f32x4 *>(out + (int64_t)b * C + 4 * c4) = *reinterpret_cast<const f32x4 *>(xt + xt_off(b, 4 * c4, C));
 }
 
+// etab[position][token][C] = wpe[position] + wte[token] (model.py:171-175: the same fp32 addition, done once per checkpoint): the rows
+// attn256q_kernel<.., EMB> starts layer 0 from
+__global__ __launch_bounds__(256) void embed_table_kernel(const float *__restrict__ wte, const float *__restrict__ wpe, float *__restrict__ etab, int C, int n_tok)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // (position, token, 4 features)
+    const int c4n = C >> 2;
+    if (i >= (int64_t)kT * n_tok * c4n) return;
+    const int c4 = (int)(i % c4n), id = (int)((i / c4n) % n_tok), t = (int)(i / ((int64_t)c4n * n_tok));
+    *reinterpret_cast<f32x4 *>(etab + i * 4) = *reinterpret_cast<const f32x4 *>(wte + (size_t)id * C + 4 * c4) + *reinterpret_cast<const f32x4 *>(wpe + (size_t)t * C + 4 * c4);
+}
+
 // x = wte[token] + wpe[position] (model.py:171-175) written chunk-major: one workgroup per 32-token tile, a wave writes
 // whole 1-KiB chunks (lane (r, h): token r, columns 8 c + 4 h .. + 3); the embedding rows come from L2
 __global__ __launch_bounds__(256) void embed_tiled_kernel(const uint8_t *__restrict__ tokens, const float *__restrict__ wte,
