@@ -403,6 +403,14 @@ int build_mode(mgpt_gpt *g, ModeState *m, bool f16)
                 MGPT_HIP(hipMalloc(&m->attn160o_spill, (size_t)m->n_cu * fastk::kA160oSpillPerWg<NP>));
                 MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn160o_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              fastk::kA160oLds<NP>));
+                MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::attn160o_kernel<T, NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             fastk::kA160oLds<NP>));
+                if (g->embed_table == nullptr) {       // (position, token) rows for layer 0 (attn160o_kernel<.., EMB>); one per checkpoint, shared by the modes
+                    MGPT_HIP(hipMalloc(&g->embed_table, (size_t)kT * kV * C * sizeof(float)));
+                    hipLaunchKernelGGL(fastk::embed_table_kernel, dim3((unsigned)cdiv64((int64_t)kT * kV * (C / 4), 256)), dim3(256), 0, nullptr,
+                                       g->params + g->off_wte, g->params + g->off_wpe, g->embed_table, C, kV);
+                    MGPT_LAUNCH_CHECK();
+                }
                 MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp160p_kernel<T, NP, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              fastk::kM5Lds<NP>));
                 MGPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fastk::mlp160p_kernel<T, NP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -761,7 +769,12 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
     const bool embed256 = m->attn256 && kAttn256Fused && kAttn256Q && g->L > 1 && g->embed_table != nullptr && m->x_tiled &&
                           !(call_rows <= kSmallRows && rows <= kSmallRows && kSmall256);
 #endif
-    if (embed256) {
+#if defined(MGPT_AB_EMBED_KERNEL_160)
+    const bool embed160 = false;
+#else
+    const bool embed160 = persistent160 && g->L > 1 && g->embed_table != nullptr;      // ... and the 2M shape's (attn160o_kernel<.., EMB>)
+#endif
+    if (embed256 || embed160) {
     } else if (m->x_tiled && !embed_fused) {
         ProfScope ps(P_EMBED, s);
         hipLaunchKernelGGL(fastk::embed_tiled_kernel, dim3((unsigned)(M / 32)), dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, C);
@@ -851,8 +864,12 @@ int forward_chunk(mgpt_gpt *g, ModeState *m, const uint8_t *d_tokens, int rows, 
         } else if (attn_block && C == 160 && !head_par && !last_short && !(embed_fused && l == 0) && m->attn160o_spill != nullptr && kAttn160o) {
             // ---- the 2M shape's attention block as one persistent kernel (attn160o_kernel) ----
             ProfScope ps(P_ATTN, s);
-            hipLaunchKernelGGL((fastk::attn160o_kernel<T, NP>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)fastk::kA160oLds<NP>, s, g->x,
-                               m->attn160o_pk[l], m->attn160_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn160o_spill, rows);
+            if (embed160 && l == 0)
+                hipLaunchKernelGGL((fastk::attn160o_kernel<T, NP, true>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)fastk::kA160oLds<NP>, s, g->x,
+                                   m->attn160o_pk[l], m->attn160_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn160o_spill, rows, d_tokens, g->embed_table);
+            else
+                hipLaunchKernelGGL((fastk::attn160o_kernel<T, NP>), dim3((unsigned)std::min(rows, m->n_cu)), dim3(512), (size_t)fastk::kA160oLds<NP>, s, g->x,
+                                   m->attn160o_pk[l], m->attn160_inv[l], scale_log2e, m->proj[l].inv_scale, m->attn160o_spill, rows);
             MGPT_LAUNCH_CHECK();
         } else if (attn_block) {
             // ---- LN1 + QKV + attention + out-projection + residual in one kernel: q, k, v, y stay on chip ----

@@ -78,9 +78,12 @@ __global__ __launch_bounds__(256) void pack_attn160o_kernel(const float *__restr
     if (NP == 2) *reinterpret_cast<u32x4 *>(dst + 512) = lo;
 }
 
-template <class T, int NP>
+// EMB (layer 0, round 6; as attn256q_kernel<.., EMB>, gpt_kernels_c256b.h): the prologue takes the rows from the (position, token) embedding table
+// etab[256][67][C] = wpe + wte and writes them to x itself; no embedding kernel, no first read of x
+template <class T, int NP, bool EMB = false>
 __global__ __launch_bounds__(512, 2) void attn160o_kernel(float *__restrict__ x, const uint16_t *__restrict__ wstream, float inv_scale,
-                                                          float scale_log2e, float inv_proj, unsigned char *__restrict__ spill, int n_rows)
+                                                          float scale_log2e, float inv_proj, unsigned char *__restrict__ spill, int n_rows,
+                                                          const unsigned char *__restrict__ tokens = nullptr, const float *__restrict__ etab = nullptr)
 {
     constexpr int C = 160, KS = 10, NH = 5, HS = 32, NW = 8;
     static_assert(NP == 2 || NP == 1, "planes");
@@ -291,14 +294,36 @@ __global__ __launch_bounds__(512, 2) void attn160o_kernel(float *__restrict__ x,
         // ---- prologue: this lane's token, LayerNorm (two-pass, model.py:19-20), operand planes ----
         {
             f32x4 xr[2 * KS];                              // xr[i] = features 8 i + 4 h .. + 3 (chunk i)
+            if constexpr (EMB) {
+                unsigned xoff_e = xoff;
+                asm volatile("" : "+v"(xoff_e));
+                const unsigned rr_e = xoff_e >> 5, h16 = xoff_e & 16u;                                  // this lane's token r and half h
+                const unsigned char *tk = tokens + b * kT + tok0;                                        // uniform
+                unsigned id;
+                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(id) : "v"(rr_e), "s"(tk) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(id) : : "memory");
+                const unsigned ve = (((unsigned)tok0 + rr_e) * 67u + id) * (unsigned)(C * 4) + h16;     // the (position, token) row, this lane's half of a chunk
+                const unsigned char *eb = reinterpret_cast<const unsigned char *>(etab);
+#pragma unroll
+                for (int i = 0; i < 2 * KS; i++)
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr[i]) : "v"(ve), "s"(eb), "n"(i * 32) : "memory");
+            } else {
 #pragma unroll
             for (int i = 0; i < 2 * KS; i++) {
                 const unsigned char *xq = xw + (i >> 2) * 4096;   // (13-bit immediate offsets: four chunks per base)
                 asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr[i]) : "v"(xoff), "s"(xq), "n"((i & 3) * 1024) : "memory");
             }
+            }
             // everything older (ring pieces, the previous row's last stores) retires with them: vmcnt(0)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]), "+v"(xr[8]), "+v"(xr[9]) : : "memory");
             asm volatile("" : "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]), "+v"(xr[15]), "+v"(xr[16]), "+v"(xr[17]), "+v"(xr[18]), "+v"(xr[19]));
+            if constexpr (EMB) {                           // the rows' first appearance in x (they retire with the first steps' counted waits)
+#pragma unroll
+                for (int i = 0; i < 2 * KS; i++) {
+                    const unsigned char *xq = xw + (i >> 2) * 4096;
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(xoff), "v"(xr[i]), "s"(xq), "n"((i & 3) * 1024) : "memory");
+                }
+            }
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 2 * KS; i++) s += (xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3]);
