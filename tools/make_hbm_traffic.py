@@ -21,8 +21,8 @@ KEYS = [  # (json key, kernel substring, grid, note)
      "mlp256q_kernel (mlp256p_kernel on the 16 x 16 x 32 MFMA; persistent, 256 workgroups x 512 threads): x rows read by the producer for LayerNorm and again by the consumer for the "
      "residual add (2 x 3.22 GB; the second read comes ~90 us after the first, inside the 256-MiB memory-side cache's reach, and is still "
      "counted: FETCH_SIZE tallies L2 <-> fabric requests), the 2.2 MB cyclic weight stream per 128-token block served by L2, one write of x"),
-    ("cfg3_f16x3_gpt_attention", "attn256q_kernel<mgpt::fastk::F16T, 2, 0>", 131072,
-     "attn256q_kernel (attn256o_kernel with its projections and tail on the 16 x 16 x 32 MFMA; persistent, whole attention block): x read for LayerNorm (3.22 GB) and again for the residual add, x written; the y planes "
+    ("cfg3_f16x3_gpt_attention", "attn256q_kernel<mgpt::fastk::F16T, 2, 0, false>", 131072,
+     "attn256q_kernel (attn256o_kernel with its projections and tail on the 16 x 16 x 32 MFMA; persistent, whole attention block; layers 1..6 of a forward -- layer 0 is the <.., EMB> instance, which reads the embedding table instead of x for its LayerNorm): x read for LayerNorm (3.22 GB) and again for the residual add, x written; the y planes "
      "go to the 56-MiB spill slab (written and read back by the same wave, L2 / memory-side cache) instead of a 3.22-GB y matrix + GEMM"),
     ("cfg3_f16x3_gpt_attention_last_layer", "attn_last1_kernel<256, 32>", 1572864,
      "last layer (attn_last1_kernel): all of x read once, only token 255's new row written (compact)"),
