@@ -359,13 +359,19 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
     const uint4 *grec = reinterpret_cast<const uint4 *>(recs) + row0;
     const int a_begin = chunk * APB;
 
-    // This wave's rows first: lane q reads the header of row q (agent a_begin + wave + 4 q; kept by create / update: row_header), so that the
-    // window gathers below start one round trip earlier than the records staged for the neighbour search (which every row of the chunk shares)
-    uint2 hv = make_uint2(0u, 0x80000000u);              // {packed position, window origin | flags}; bit 31: no such agent
+    // This wave's rows first: agents a_w0 .. a_w0 + RPW - 1, whose headers (kept by create / update: row_header) are RPW x 8 contiguous bytes at a
+    // wave-uniform address -- SCALAR loads: the values arrive in scalar registers (no per-row v_readlane) after one short round trip, and the
+    // window gathers below are in flight before the instance's records are staged for the neighbour search.  (hdrs is padded by 64 entries.)
+    const int a_w0 = a_begin + wave * RPW;
+    uint32_t my0s[RPW], infos[RPW];
     {
-        const int a = a_begin + wave + 4 * (lane & (RPW - 1));
-        const uint2 h = hdrs[row0 + min(a, n_agents - 1)];     // (unconditional: one load, no exec juggling)
-        if (a < n_agents) hv = h;
+        const uint2 *hw = hdrs + (row0 + a_w0);          // uniform
+#pragma unroll
+        for (int q = 0; q < RPW; q++) {
+            const uint2 h = hw[q];
+            my0s[q] = h.x;
+            infos[q] = a_w0 + q < n_agents ? h.y : 0x80000000u;      // bit 31: no such agent
+        }
     }
     uint4 stage[(KP * 64 + 255) / 256];                  // the instance's records, on their way to LDS
 #pragma unroll
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
         stage[j] = make_uint4(0x7fff7fffu, 0u, 0u, 0u);  // sentinel position: never inside a window (H, W <= 16384)
         if (i < n_agents) stage[j] = grec[i];            // {pr|pc<<16, gr|gc<<16, hist0..3, hist4|next<<8|org<<16}
     }
-    if (lane < RPW) hdr[wave * RPW + lane] = hv.x;       // (read back by this wave's emission lanes only)
+    if (lane < RPW) hdr[wave * RPW + lane] = hdrs[row0 + min(a_w0 + lane, n_agents - 1)].x;     // (read back by this wave's emission lanes only)
 
     uint8_t *row = srow + wave * kRowImage;
     uint4 *bkt = reinterpret_cast<uint4 *>(sbkt + wave * kBktBytes);
@@ -410,12 +416,6 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
     //  all resident at once spend memory + arithmetic instead of their maximum, 46 against 35 us per 131 072 rows of 128 agents; one
     //  group ahead only costs the large launches 3 %; 8 rows per wave with both groups up front is the fastest large-launch form.)
     uint32_t w0[RPW], w1[RPW];
-    uint32_t my0s[RPW], infos[RPW];
-#pragma unroll
-    for (int q = 0; q < RPW; q++) {
-        my0s[q] = __builtin_amdgcn_readlane(hv.x, q);
-        infos[q] = __builtin_amdgcn_readlane(hv.y, q);
-    }
     auto gather = [&](auto u8_c, const __amdgpu_buffer_rsrc_t rd, auto g_c) {
         constexpr bool U8 = decltype(u8_c)::value;
         constexpr unsigned UNRC = U8 ? 255u : (unsigned)kUnreach;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
         for (int q = QB; q < QB + U; q++) {
             const uint32_t my0 = my0s[q], info = infos[q];
             w0[q] = UNRC; w1[q] = UNRC;
-            const uint32_t fld = (uint32_t)(wave + 4 * q) * (uint32_t)cells;   // this row's field inside the chunk (uniform)
+            const uint32_t fld = (uint32_t)(wave * RPW + q) * (uint32_t)cells; // this row's field inside the chunk (uniform)
             if ((info >> 30) == 0) {                                        // wave-uniform; always taken for env states
                 const uint32_t org = fld + (info & 0x1fffffffu);            // the window's first cell (uniform)
                 w0[q] = field_load<U8>(rd, off0, org);
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void tokens_kernel(const AgentRec *__restrict_
             if ((infos[q0 + u] >> 31) != 0) break;
             const uint32_t *row32 = reinterpret_cast<const uint32_t *>(row + u * kRowBytes);
             const uint32_t packed = __builtin_amdgcn_alignbyte(row32[lane + 1], row32[lane], 1);   // tokens 4*lane .. 4*lane+3
-            __builtin_amdgcn_raw_buffer_store_b32(packed, rtok, lane4, (uint32_t)(wave + 4 * (q0 + u)) * 256u, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(packed, rtok, lane4, (uint32_t)(wave * RPW + q0 + u) * 256u, 0);
         }
         __builtin_amdgcn_wave_barrier();
         return true;
@@ -898,7 +898,8 @@ extern "C" int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_para
     if (e == hipSuccess) e = hipMalloc(&t->u8_ok, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&t->recs, total * sizeof(AgentRec));
     if (e == hipSuccess) e = hipMalloc(&t->dirty, total);
-    if (e == hipSuccess) e = hipMalloc(&t->hdrs, total * sizeof(uint2));
+    if (e == hipSuccess) e = hipMalloc(&t->hdrs, (total + 64) * sizeof(uint2));     // (+ 64: a wave's scalar loads of its rows' headers may run past the last agent)
+    if (e == hipSuccess) e = hipMemset(t->hdrs, 0, (total + 64) * sizeof(uint2));
     if (e != hipSuccess) {
         set_error("hipMalloc failed in mgpt_tokenizer_create: %s", hipGetErrorString(e));
         mgpt_tokenizer_destroy(t);
