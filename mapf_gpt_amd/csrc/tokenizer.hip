@@ -227,30 +227,34 @@ __global__ __launch_bounds__(256) void tok_next_kernel(AgentRec *__restrict__ re
 }
 
 // ---------------------------------------------------------------------------------------------
-// generate_observations, cpp:516-528.  Workgroup = 4 wavefronts = one chunk of 4*RPW agents of ONE
-// instance; a wavefront owns one agent (one 256-token row) at a time, RPW rows in flight, U = 4 of them
-// interleaved phase by phase (a row's chain is ~8 dependent LDS round trips).
-//   LDS: per-row headers, the instance's agent records (16 B each) + their biased packed positions, per wave
-//        U row images (token t at byte t+1 so that 10-token neighbour records are 2-byte aligned), a distance-bucket
-//        table, a (rank -> agent) list per row and (KP > 1) the compacted neighbour keys.
-//   HBM reads per row: the window of the agent's own distance field (one byte per cell from `dist8` when every
-//        field fits a byte, else two from `dist`); writes: one coalesced 256-B store.
-// The kernel is instruction-issue bound (rounds 1-5: DESIGN.md section 11.4), so round 6 rewrote the row body around the
-// DYNAMIC instruction count (profiles/r06_pmc_insts.txt; round 5: 111 VALU + 65 SALU per row at 192 agents):
+// generate_observations, cpp:516-528.  Grid (instance, chunk); workgroup = 4 wavefronts = one chunk of 4*RPW agents of ONE
+// instance; a wavefront owns RPW consecutive agents (one 256-token row each), U = 4 of them interleaved phase by phase
+// (a row's chain is ~10 dependent LDS round trips).
+//   LDS: the instance's agent records (16 B each) + their biased packed positions, per wave U row images (token t at byte
+//        t+1 so that 10-token neighbour records are 2-byte aligned), a distance-bucket table, a (rank -> agent) list per
+//        row and (KP > 1) the compacted neighbour ids.
+//   HBM reads per row: its 8-byte header (scalar load), the window of the agent's own distance field (one byte per cell from
+//        `dist8` when every field fits a byte, else two from `dist`); writes: one coalesced 256-B store.
+// Rounds 1-5 found the kernel instruction-issue bound (111 VALU + 65 SALU per row at 192 agents), so round 6 rewrote the row body
+// around the DYNAMIC instruction count (profiles/r06_pmc_insts_tokenizer.txt: 54.6 + 55.8):
 //   * the two window cells of a lane are ONE packed 16-bit pair: saturating v_pk_add/sub_u16, v_pk_min_u16 -- the whole
 //     clamp / sentinel / vocabulary chain is branch-free and runs once per pair; the high half is stored with
 //     ds_write_b8_d16_hi (round 5's per-cell ternaries compiled to four exec-mask branches per cell);
-//   * window addresses are (wave-uniform 64-bit base incl. the window origin) + (per-lane constant): no vector address arithmetic;
-//   * neighbour test on packed 16-bit positions (v_pk_sub_u16 / v_pk_max_u16), candidates of the KP passes compacted in id
-//     order by ballot + mbcnt into 16-bit keys (distance << 11 | id) -- the compaction area holds every candidate of the
-//     KP <= 4 instances, so no per-lane overflow test;
+//   * window addresses are (buffer resource of the chunk's fields) + (wave-uniform scalar offset incl. the window origin) +
+//     (per-lane constant): no vector address arithmetic; the row headers (position, window origin, flags) are kept per agent
+//     by create / update and reach a wave as ONE scalar load;
+//   * neighbour test on packed 16-bit positions (v_pk_sub_u16 / v_pk_max_u16), the ids of the neighbours of the KP passes
+//     compacted in id order by ballot + mbcnt -- the compaction area holds every candidate of the KP <= 4 instances, so no
+//     per-lane overflow test; the Manhattan distance is formed once per row after the compaction (v_sad_u16);
 //   * order = (Manhattan distance, agent id) ascending, first S (cpp:496-506): rank = #candidates in lower distance buckets
 //     + #lower ids in the own bucket: every candidate ORs its lane bit into bucket[d] in LDS (ds_or_b64), 16 lanes prefix-sum the
-//     bucket populations (DPP row scan), each candidate reads its bucket once;
-//   * a ranked candidate only leaves its key in list[row][rank]; the records of FOUR rows are then emitted at once by lanes
+//     bucket populations (DPP row scan), each candidate reads its bucket once (rank = v_mbcnt of the mask + prefix);
+//   * a ranked candidate only leaves its id in list[row][rank]; the records of FOUR rows are then emitted at once by lanes
 //     16 u + rank (round 5 emitted per row with <= 13 of 64 lanes active);
 //   * more than 64 neighbours in one window (> 64 agents in an open room): exact slow path that walks the distance
 //     buckets over all passes and fills the same list.
+// What bounds it after that is no single resource (profiles/r06_tokenizer_ablation.txt): vector issue ~55 %, the CU's scalar unit
+// ~50 %, LDS pipe ~70 % busy, and removing any one LDS phase, the window traffic or raising the occupancy moves the time by <= 10 %.
 // KP = ceil(n_agents / 64) candidate passes per row.  All of InputParameters (limit, slots, history, radii) are kernel
 // arguments: they sit in scalar registers and cost the default configuration nothing.
 // ---------------------------------------------------------------------------------------------
