@@ -35,8 +35,12 @@ class GPT:
     def __init__(self, config, max_rows=2048, precision="f32", device="cuda", envelope="fallback"):
         if config.vocab_size != 67:
             raise ValueError("vocab_size must be 67 (observation_generator.cpp:321-344)")
-        if config.bias or config.dropout != 0.0:
-            raise ValueError("the released models use bias=False, dropout=0.0 (model.py:114-115); nothing else is implemented")
+        if config.bias:
+            raise ValueError("the released models use bias=False (model.py:115); Linear / LayerNorm biases are not implemented")
+        if not (0.0 <= config.dropout < 1.0):
+            raise ValueError("dropout must be in [0, 1)")
+        # dropout: accepted and ignored -- this is the inference path, and the reference serves every model in eval mode
+        # (inference.py:85 net.eval(): nn.Dropout and scaled_dot_product_attention's dropout_p are the identity there, model.py:33-34,59,82,129)
         self.config = config
         self.max_rows = int(max_rows)
         self.precision = precision

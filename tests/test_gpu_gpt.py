@@ -81,6 +81,24 @@ def test_forward_chunking_and_row_independence():
     assert np.abs(full - ref).max() < TOL
 
 
+def test_dropout_in_the_config_changes_nothing_at_inference():
+    """The reference serves its models in eval mode (inference.py:85), where nn.Dropout is the identity: a checkpoint whose model_args carry
+    dropout = 0.1 must give the logits of the same weights with dropout = 0, bit for bit, and stay within 1e-5 of the reference's eval-mode forward."""
+    from mapf_gpt_amd.model import GPT, GPTConfig
+    rows = load_tok("random000")["tokens"][5, :6]
+    tokens = torch.from_numpy(rows).cuda()
+    sd = weights.synthetic_state_dict("tiny", seed=0)
+    out = {}
+    for dp in (0.0, 0.1):
+        args = dict(weights.model_args("tiny"), dropout=dp)
+        net = GPT(GPTConfig(**args), max_rows=8, precision="f32")
+        net.load_state_dict(sd)
+        out[dp] = net.logits_tokens(tokens).cpu().numpy()
+    assert np.array_equal(out[0.0], out[0.1])
+    ref = gpt_oracle.forward_logits(sd, weights.model_args("tiny"), rows).numpy()
+    assert np.abs(out[0.1] - ref).max() < TOL
+
+
 def test_device_sampler_matches_host_restatement():
     net = _net("tiny", max_rows=64)
     rows = np.concatenate([load_tok("mazes000")["tokens"][t] for t in range(4)])[:200]

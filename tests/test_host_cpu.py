@@ -120,3 +120,15 @@ def test_gpt_envelope_policy_names():
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mapf_gpt_amd.h")).read()
     for name, value in (("FALLBACK", 0), ("REFUSE", 1), ("IGNORE", 2)):
         assert f"#define MGPT_ENVELOPE_{name} {value}" in header
+
+
+def test_gpt_config_dropout_is_an_eval_mode_no_op_and_bias_is_refused():
+    """model.py:33-34,59,82,129: every Dropout of the reference is the identity once inference.py:85 has called net.eval(); this inference-only
+    implementation therefore accepts any dropout in [0, 1) and ignores it.  bias=True (Linear / LayerNorm biases, model.py:17,29-31,79-81) is not
+    implemented and is refused at construction -- no device needed for either."""
+    from mapf_gpt_amd.model import GPT, GPTConfig
+    assert GPT(GPTConfig(block_size=256, dropout=0.1)).config.dropout == 0.1
+    with pytest.raises(ValueError, match="bias"):
+        GPT(GPTConfig(block_size=256, bias=True))
+    with pytest.raises(ValueError, match="dropout"):
+        GPT(GPTConfig(block_size=256, dropout=1.5))
