@@ -174,15 +174,21 @@ typedef struct mgpt_gpt mgpt_gpt;
 #define MGPT_PREC_F16X3 1   /* split-fp16 (hi/lo, 3 MFMA passes, fp32 accumulate): ~fp32 accuracy     */
 #define MGPT_PREC_BF16 2    /* single-pass bf16 MFMA, fp32 accumulate: the reference's autocast mode  */
 
-/* = GPTConfig + GPT.__init__ (model.py:107-145): bias=False, dropout=0, vocab 67.
- * max_rows = largest batch one forward call will see (activation workspace is sized for it). */
+/* = GPTConfig + GPT.__init__ (model.py:107-145): vocab 67; dropout is the identity at inference (inference.py:85 net.eval()).
+ * bias (model.py:115; False in every released config): a checkpoint has bias vectors iff mgpt_gpt_set_param is handed any
+ * "*.bias" tensor -- see there.  max_rows = largest batch one forward call will see (activation workspace is sized for it). */
 int mgpt_gpt_create(mgpt_gpt **out, int n_layer, int n_head, int n_embd, int block_size, int max_rows);
 int mgpt_gpt_destroy(mgpt_gpt *gpt);
 
 /* = load_state_dict (inference.py:83).  `name` is the reference state_dict key
  * ("transformer.h.3.attn.c_attn.weight", ...; lm_head.weight is tied to transformer.wte.weight,
  * model.py:138, either name sets both).  data: float32, HOST or DEVICE pointer (is_device),
- * n_elem must match the parameter's size.  Synchronous. */
+ * n_elem must match the parameter's size.  Synchronous.
+ * GPTConfig.bias = True checkpoints (model.py:14-17 LayerNorm bias; model.py:29,31,79,81 nn.Linear bias): their seven kinds of
+ * "*.bias" tensors ("transformer.ln_f.bias", "transformer.h.N.{ln_1,ln_2}.bias", "...attn.c_attn.bias", "...attn.c_proj.bias",
+ * "...mlp.c_fc.bias", "...mlp.c_proj.bias") are accepted; once one is set, mgpt_gpt_finalize wants all of them.  Only the
+ * MGPT_PREC_F32 kernels carry bias terms: MGPT_PREC_F16X3 requests follow the envelope policy (the checkpoint counts as outside:
+ * fallback = served in fp32, refuse / ignore = MGPT_ERR_UNSUPPORTED), MGPT_PREC_BF16 requests return MGPT_ERR_UNSUPPORTED. */
 int mgpt_gpt_set_param(mgpt_gpt *gpt, const char *name, const float *data, int64_t n_elem, int is_device);
 /* call once after all parameters are set (builds the packed operand planes of the chosen precisions) */
 int mgpt_gpt_finalize(mgpt_gpt *gpt);

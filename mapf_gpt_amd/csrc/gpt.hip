@@ -91,6 +91,21 @@ extern "C" int mgpt_gpt_create(mgpt_gpt **out, int n_layer, int n_head, int n_em
     }
     g->n_params = off;
     g->is_set.assign(n_tensors(g), 0);
+    {   // bias vectors of a bias = True checkpoint (allocated when the first one arrives)
+        size_t bo = 0;
+        g->off_lnf_b = bo; bo += C;
+        for (int l = 0; l < n_layer; l++) {
+            BiasOff b;
+            b.ln1 = bo; bo += C;
+            b.attn = bo; bo += 3 * C;
+            b.proj = bo; bo += C;
+            b.ln2 = bo; bo += C;
+            b.fc = bo; bo += 4 * C;
+            b.proj2 = bo; bo += C;
+            g->bias_layers.push_back(b);
+        }
+        g->bias_set.assign(1 + (size_t)n_layer * 6, 0);
+    }
     const size_t M = (size_t)max_rows * kT;
     hipError_t e = hipMalloc(&g->params, off * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&g->x, M * C * sizeof(float));
@@ -112,9 +127,37 @@ extern "C" int mgpt_gpt_destroy(mgpt_gpt *g)
     if (!g) return MGPT_OK;
     gpt_fast_destroy(g);
     (void)hipFree(g->params); (void)hipFree(g->x); (void)hipFree(g->xn); (void)hipFree(g->qkv);
-    (void)hipFree(g->hbuf); (void)hipFree(g->logits_tmp);
+    (void)hipFree(g->hbuf); (void)hipFree(g->logits_tmp); (void)hipFree(g->bias);
     delete g;
     return MGPT_OK;
+}
+
+static size_t n_bias_elems(const mgpt_gpt *g) { return (size_t)g->C * (1 + 11 * (size_t)g->L); }
+
+// reference state_dict key of a bias vector (GPTConfig.bias = True) -> (bias tensor index, offset into g->bias, element count)
+static bool locate_bias(const mgpt_gpt *g, const char *name_in, size_t *idx, size_t *off, size_t *count)
+{
+    std::string name(name_in);
+    const std::string pre = "_orig_mod.";
+    if (name.compare(0, pre.size(), pre) == 0) name = name.substr(pre.size());
+    const size_t C = g->C;
+    if (name == "transformer.ln_f.bias") { *idx = 0; *off = g->off_lnf_b; *count = C; return true; }
+    const std::string hp = "transformer.h.";
+    if (name.compare(0, hp.size(), hp) != 0) return false;
+    size_t p = hp.size(), l = 0;
+    if (p >= name.size() || name[p] < '0' || name[p] > '9') return false;
+    while (p < name.size() && name[p] >= '0' && name[p] <= '9') { l = l * 10 + (size_t)(name[p] - '0'); p++; }
+    if (l >= (size_t)g->L || p >= name.size() || name[p] != '.') return false;
+    const std::string rest = name.substr(p + 1);
+    const BiasOff &b = g->bias_layers[l];
+    const size_t base = 1 + l * 6;
+    if (rest == "ln_1.bias") { *idx = base + 0; *off = b.ln1; *count = C; return true; }
+    if (rest == "attn.c_attn.bias") { *idx = base + 1; *off = b.attn; *count = 3 * C; return true; }
+    if (rest == "attn.c_proj.bias") { *idx = base + 2; *off = b.proj; *count = C; return true; }
+    if (rest == "ln_2.bias") { *idx = base + 3; *off = b.ln2; *count = C; return true; }
+    if (rest == "mlp.c_fc.bias") { *idx = base + 4; *off = b.fc; *count = 4 * C; return true; }
+    if (rest == "mlp.c_proj.bias") { *idx = base + 5; *off = b.proj2; *count = C; return true; }
+    return false;
 }
 
 // reference state_dict key -> (tensor index, offset, element count)
@@ -149,6 +192,18 @@ extern "C" int mgpt_gpt_set_param(mgpt_gpt *g, const char *name, const float *da
 {
     MGPT_REQUIRE(g && name && data, MGPT_ERR_ARG, "NULL argument");
     size_t idx, off, count;
+    if (locate_bias(g, name, &idx, &off, &count)) {        // a bias = True checkpoint (model.py:115): see mgpt_gpt_forward for which kernels carry it
+        MGPT_REQUIRE((size_t)n_elem == count, MGPT_ERR_ARG, "parameter '%s': got %lld elements, expected %zu", name, (long long)n_elem, count);
+        if (!g->bias) {
+            MGPT_HIP(hipMalloc(&g->bias, n_bias_elems(g) * sizeof(float)));
+            MGPT_HIP(hipMemset(g->bias, 0, n_bias_elems(g) * sizeof(float)));
+        }
+        MGPT_HIP(hipMemcpy(g->bias + off, data, count * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        g->bias_set[idx] = 1;
+        g->has_bias = true;
+        g->finalized = false;
+        return MGPT_OK;
+    }
     MGPT_REQUIRE(locate_param(g, name, &idx, &off, &count), MGPT_ERR_ARG, "unknown parameter '%s'", name);
     MGPT_REQUIRE((size_t)n_elem == count, MGPT_ERR_ARG, "parameter '%s': got %lld elements, expected %zu", name,
                  (long long)n_elem, count);
@@ -207,10 +262,14 @@ extern "C" int mgpt_gpt_finalize(mgpt_gpt *g)
     MGPT_REQUIRE(g, MGPT_ERR_ARG, "NULL argument");
     for (size_t i = 0; i < g->is_set.size(); i++)
         MGPT_REQUIRE(g->is_set[i], MGPT_ERR_STATE, "parameter tensor #%zu was never set (see mgpt_gpt_set_param)", i);
+    if (g->has_bias)                                       // nn.Linear(bias=True) / LayerNorm(bias=True) come together (model.py:126-131)
+        for (size_t i = 0; i < g->bias_set.size(); i++)
+            MGPT_REQUIRE(g->bias_set[i], MGPT_ERR_STATE, "the checkpoint has bias vectors, but bias tensor #%zu (0 = ln_f, then six per layer) was never set", i);
     int rc = gpt_fast_finalize(g);
     if (rc != MGPT_OK) return rc;
     if ((rc = envelope_stats(g)) != MGPT_OK) return rc;
-    g->env_state = 0; g->env_probe_err = g->env_probe_err_small = g->env_probe_err_large = -1.f; g->env_logged = false;
+    // (bias vectors: outside by construction -- the 16-bit kernels have no bias terms, MGPT_PREC_F16X3 requests follow the envelope policy)
+    g->env_state = g->has_bias ? 2 : 0; g->env_probe_err = g->env_probe_err_small = g->env_probe_err_large = -1.f; g->env_logged = false;
     g->env_probe_tol = 0.f; g->env_probe_max_logit = 0.f;
     g->finalized = true;
     return MGPT_OK;
@@ -243,7 +302,8 @@ int gpt_launch_head_at(mgpt_gpt *g, const float *xsrc, int64_t row_stride, int64
 {
     ProfScope ps(P_HEAD, s);
     hipLaunchKernelGGL(f32k::head_kernel, dim3(rows), dim3(64), (size_t)g->C * sizeof(float), s, xsrc, g->params + g->off_lnf,
-                       g->params + g->off_wte, d_logits, g->C, kV, row_stride, row_offset);
+                       g->params + g->off_wte, d_logits, g->C, kV, row_stride, row_offset,
+                       g->has_bias ? (const float *)(g->bias + g->off_lnf_b) : (const float *)nullptr);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
@@ -277,14 +337,14 @@ static int launch_gemm(const float *A, const float *W, float *out, int64_t M, in
     return MGPT_OK;
 }
 
-static int launch_layernorm(const float *x, const float *w, float *y, int64_t n_tok, int C, hipStream_t s)
+static int launch_layernorm(const float *x, const float *w, const float *b, float *y, int64_t n_tok, int C, hipStream_t s)
 {
     ProfScope ps(P_LAYERNORM, s);
     const dim3 grid((unsigned)cdiv64(n_tok, 4));
-    if (C <= 256) hipLaunchKernelGGL((f32k::layernorm_kernel<1>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C);
-    else if (C <= 512) hipLaunchKernelGGL((f32k::layernorm_kernel<2>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C);
-    else if (C <= 768) hipLaunchKernelGGL((f32k::layernorm_kernel<3>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C);
-    else hipLaunchKernelGGL((f32k::layernorm_kernel<4>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C);
+    if (C <= 256) hipLaunchKernelGGL((f32k::layernorm_kernel<1>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C, b);
+    else if (C <= 512) hipLaunchKernelGGL((f32k::layernorm_kernel<2>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C, b);
+    else if (C <= 768) hipLaunchKernelGGL((f32k::layernorm_kernel<3>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C, b);
+    else hipLaunchKernelGGL((f32k::layernorm_kernel<4>), grid, dim3(256), 0, s, x, w, y, n_tok, C, (int64_t)C, (int64_t)C, b);
     MGPT_LAUNCH_CHECK();
     return MGPT_OK;
 }
@@ -306,11 +366,15 @@ static int forward_f32_chunk(mgpt_gpt *g, const uint8_t *d_tokens, int rows, flo
     ep.C = C; ep.n_head = g->nh; ep.hs = g->hs; ep.plane = M * C;
     const float scale = 1.0f / sqrtf((float)g->hs);
     float *q = g->qkv, *k = g->qkv + M * C, *v = g->qkv + 2 * M * C;
+    const float *Bv = g->has_bias ? g->bias : nullptr;       // bias = True checkpoints (model.py:14-17,29,31,79,81)
+    auto bias_at = [&](size_t off) -> const float * { return Bv ? Bv + off : nullptr; };
     for (int l = 0; l < g->L; l++) {
         const LayerOff &lo = g->layers[l];
-        if ((rc = launch_layernorm(g->x, P + lo.ln1, g->xn, M, C, s)) != MGPT_OK) return rc;
+        const BiasOff &bo = g->bias_layers[l];
+        if ((rc = launch_layernorm(g->x, P + lo.ln1, bias_at(bo.ln1), g->xn, M, C, s)) != MGPT_OK) return rc;
         {
             ProfScope ps(P_GEMM_QKV, s);
+            ep.bias = bias_at(bo.attn);
             if ((rc = launch_gemm<f32k::EPI_QKV>(g->xn, P + lo.attn_w, g->qkv, M, 3 * C, C, ep, C, s)) != MGPT_OK) return rc;
         }
         {
@@ -321,15 +385,18 @@ static int forward_f32_chunk(mgpt_gpt *g, const uint8_t *d_tokens, int rows, flo
         }
         {
             ProfScope ps(P_GEMM_PROJ, s);
+            ep.bias = bias_at(bo.proj);
             if ((rc = launch_gemm<f32k::EPI_RESID>(g->xn, P + lo.proj_w, g->x, M, C, C, ep, C, s)) != MGPT_OK) return rc;
         }
-        if ((rc = launch_layernorm(g->x, P + lo.ln2, g->xn, M, C, s)) != MGPT_OK) return rc;
+        if ((rc = launch_layernorm(g->x, P + lo.ln2, bias_at(bo.ln2), g->xn, M, C, s)) != MGPT_OK) return rc;
         {
             ProfScope ps(P_GEMM_FC, s);
+            ep.bias = bias_at(bo.fc);
             if ((rc = launch_gemm<f32k::EPI_GELU>(g->xn, P + lo.fc_w, g->hbuf, M, 4 * C, C, ep, C, s)) != MGPT_OK) return rc;
         }
         {
             ProfScope ps(P_GEMM_PROJ2, s);
+            ep.bias = bias_at(bo.proj2);
             if ((rc = launch_gemm<f32k::EPI_RESID>(g->hbuf, P + lo.proj2_w, g->x, M, C, 4 * C, ep, C, s)) != MGPT_OK) return rc;
         }
     }
@@ -420,6 +487,10 @@ static int gpt_forward_impl(mgpt_gpt *g, const uint8_t *d_tokens, int rows, floa
     MGPT_REQUIRE(rows > 0, MGPT_ERR_ARG, "rows=%d", rows);
     MGPT_REQUIRE(g->finalized, MGPT_ERR_STATE, "mgpt_gpt_finalize must precede forward");
     hipStream_t s = (hipStream_t)stream;
+    // bias = True checkpoints: only the exact-fp32 kernels carry the bias terms.  MGPT_PREC_F16X3 under the fallback policy is served by them
+    // (the checkpoint counts as outside the envelope, mgpt_gpt_finalize); every other 16-bit request is refused -- it would be wrong, not imprecise
+    MGPT_REQUIRE(!g->has_bias || precision == MGPT_PREC_F32 || (precision == MGPT_PREC_F16X3 && g->env_policy == MGPT_ENVELOPE_FALLBACK),
+                 MGPT_ERR_UNSUPPORTED, "the checkpoint has Linear / LayerNorm bias vectors (GPTConfig.bias = True): they are carried by the MGPT_PREC_F32 kernels only");
     if (precision == MGPT_PREC_F16X3 && g->env_policy != MGPT_ENVELOPE_IGNORE) {
         if (g->env_state == 0) {
             const int rc = envelope_decide(g, s);
@@ -427,7 +498,8 @@ static int gpt_forward_impl(mgpt_gpt *g, const uint8_t *d_tokens, int rows, floa
         }
         if (g->env_state == 2) {
             char probe[160];
-            if (g->env_probe_err < 0.f) snprintf(probe, sizeof(probe), "not probed: the weight statistics decide");
+            if (g->has_bias) snprintf(probe, sizeof(probe), "not probed: the checkpoint has bias vectors, which the 16-bit kernels do not carry");
+            else if (g->env_probe_err < 0.f) snprintf(probe, sizeof(probe), "not probed: the weight statistics decide");
             else snprintf(probe, sizeof(probe), "probe |f16x3 - f32| %.3g (small calls) / %.3g (large calls) of %.3g at max |logit| %.3g",
                           g->env_probe_err_small, g->env_probe_err_large, g->env_probe_tol, g->env_probe_max_logit);
             MGPT_REQUIRE(g->env_policy != MGPT_ENVELOPE_REFUSE, MGPT_ERR_UNSUPPORTED,

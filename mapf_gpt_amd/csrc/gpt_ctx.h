@@ -8,6 +8,11 @@ struct LayerOff {
     size_t ln1, attn_w, proj_w, ln2, fc_w, proj2_w;
 };
 
+// GPTConfig.bias = True (model.py:14-17,29,31,79,81,115): LayerNorm and Linear bias vectors, offsets into mgpt_gpt::bias
+struct BiasOff {
+    size_t ln1, attn, proj, ln2, fc, proj2;
+};
+
 
 struct mgpt_gpt {
     int L, nh, C, hs, block, max_rows;
@@ -16,6 +21,12 @@ struct mgpt_gpt {
     std::vector<LayerOff> layers;
     float *params = nullptr;          // fp32 master copy, device
     std::vector<uint8_t> is_set;      // per parameter tensor
+    // bias = True checkpoints: allocated (zeroed) by the first *.bias tensor mgpt_gpt_set_param sees; carried by the exact-fp32 kernels only
+    float *bias = nullptr;            // [ln_f C | per layer: ln_1 C, c_attn 3C, attn c_proj C, ln_2 C, c_fc 4C, mlp c_proj C], device
+    size_t off_lnf_b = 0;
+    std::vector<BiasOff> bias_layers;
+    std::vector<uint8_t> bias_set;    // per bias tensor: [ln_f | 6 per layer]
+    bool has_bias = false;
     bool finalized = false;
     // fp32-path workspace
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *hbuf = nullptr, *logits_tmp = nullptr;

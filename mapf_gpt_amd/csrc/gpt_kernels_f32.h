@@ -40,11 +40,11 @@ __global__ __launch_bounds__(256) void embed_kernel(const uint8_t *__restrict__ 
     }
 }
 
-// ----- LayerNorm over C, eps 1e-5, gain only (model.py:19-20): one wavefront per token -----
+// ----- LayerNorm over C, eps 1e-5, gain (+ bias when the checkpoint has one: `b` may be NULL; model.py:14-20): one wavefront per token -----
 template <int kMaxV4>   // float4 slots per lane: C <= 256 * kMaxV4
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         float *__restrict__ y, int64_t n_tok, int C, int64_t in_stride,
-                                                        int64_t out_stride)
+                                                        int64_t out_stride, const float *__restrict__ b = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -81,8 +81,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
         const int i = lane + 64 * k;
         if (i < c4n) {
             const float4 g = pw[i];
-            py[i] = make_float4((v[k].x - mean) * rstd * g.x, (v[k].y - mean) * rstd * g.y,
-                                (v[k].z - mean) * rstd * g.z, (v[k].w - mean) * rstd * g.w);
+            float4 o = make_float4((v[k].x - mean) * rstd * g.x, (v[k].y - mean) * rstd * g.y,
+                                   (v[k].z - mean) * rstd * g.z, (v[k].w - mean) * rstd * g.w);
+            if (b != nullptr) {                                  // (uniform) F.layer_norm(..., weight, bias, 1e-5)
+                const float4 bb = reinterpret_cast<const float4 *>(b)[i];
+                o = make_float4(o.x + bb.x, o.y + bb.y, o.z + bb.z, o.w + bb.w);
+            }
+            py[i] = o;
         }
     }
 }
@@ -93,6 +98,7 @@ enum { EPI_STORE = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_QKV = 3 };
 struct EpiArgs {
     int C, n_head, hs;      // EPI_QKV: scatter into [3][rows][n_head][256][hs]
     int64_t plane;          // EPI_QKV: elements per q/k/v plane = M * C
+    const float *bias = nullptr;   // nn.Linear bias [N] of a bias = True checkpoint (model.py:29,31,79,81), else NULL
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int n = n0 + (wn * TN + j) * 32 + r;
+            const float bn = ep.bias != nullptr ? ep.bias[n] : 0.f;
             int64_t qkv_col = 0;                                // EPI_QKV: column-only part of the scatter offset
             if (EPI == EPI_QKV) {                               // model.py:50-53
                 const int which = n / ep.C, cc = n - which * ep.C;
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 #pragma unroll
             for (int g = 0; g < 16; g++) {
                 const int64_t m = m0 + (wm * TM + i) * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                const float v = acc[i][j][g];
+                float v = acc[i][j][g];
+                if (ep.bias != nullptr) v += bn;                 // (uniform)
                 if (EPI == EPI_STORE) {
                     out[m * N + n] = v;
                 } else if (EPI == EPI_RESID) {
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float *__restrict__
 // compact last-token buffer: stride C, offset 0)
 __global__ __launch_bounds__(64) void head_kernel(const float *__restrict__ x, const float *__restrict__ lnf,
                                                   const float *__restrict__ wte, float *__restrict__ logits, int C,
-                                                  int V, int64_t row_stride, int64_t row_offset)
+                                                  int V, int64_t row_stride, int64_t row_offset, const float *__restrict__ lnf_b = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xn = reinterpret_cast<float *>(smem);
@@ -315,7 +323,11 @@ __global__ __launch_bounds__(64) void head_kernel(const float *__restrict__ x, c
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qv += __shfl_xor(qv, o);
     const float rstd = rsqrtf(qv / (float)C + 1e-5f);
-    for (int c = lane; c < C; c += 64) xn[c] = (px[c] - mean) * rstd * lnf[c];
+    for (int c = lane; c < C; c += 64) {
+        float o = (px[c] - mean) * rstd * lnf[c];
+        if (lnf_b != nullptr) o += lnf_b[c];                    // ln_f.bias of a bias = True checkpoint (lm_head itself never has one, model.py:131)
+        xn[c] = o;
+    }
     __syncthreads();
     for (int vtok = lane; vtok < V; vtok += 64) {
         const float *wr = wte + (size_t)vtok * C;

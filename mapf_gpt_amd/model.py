@@ -35,8 +35,8 @@ class GPT:
     def __init__(self, config, max_rows=2048, precision="f32", device="cuda", envelope="fallback"):
         if config.vocab_size != 67:
             raise ValueError("vocab_size must be 67 (observation_generator.cpp:321-344)")
-        if config.bias:
-            raise ValueError("the released models use bias=False (model.py:115); Linear / LayerNorm biases are not implemented")
+        # bias=True (model.py:115; no released config uses it): the checkpoint's *.bias tensors are loaded like any other and carried by the
+        # exact-fp32 kernels -- precision="f16x3" then follows the envelope policy (fallback: fp32), "bf16" raises (include/mapf_gpt_amd.h)
         if not (0.0 <= config.dropout < 1.0):
             raise ValueError("dropout must be in [0, 1)")
         # dropout: accepted and ignored -- this is the inference path, and the reference serves every model in eval mode
@@ -96,6 +96,9 @@ class GPT:
         sd = weights.strip_prefix(state_dict)
         unknown = []
         for k, v in sd.items():
+            if k.endswith(".bias") and not self.config.bias:      # a bias=False module has no such parameter: an unexpected key (model.py:14-17,29)
+                unknown.append(k)
+                continue
             a = v.detach().to(torch.float32).cpu().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
             a = np.ascontiguousarray(a)
             rc = _lib.lib().mgpt_gpt_set_param(self._h, k.encode(), ctypes.c_void_p(a.ctypes.data), a.size, 0)

@@ -10,6 +10,7 @@ shapes (model.py:126-138; VERIFIED key list in SURVEY.md section 8a-M0):
     transformer.h.{l}.attn.c_proj.weight (C,C)  transformer.h.{l}.ln_2.weight (C)
     transformer.h.{l}.mlp.c_fc.weight (4C,C) transformer.h.{l}.mlp.c_proj.weight (C,4C)
     transformer.ln_f.weight (C)      lm_head.weight (67,C)
+    bias=True (model.py:115; no released config): + ln_1 / ln_2 / ln_f .bias (C), c_attn.bias (3C), c_proj.bias (C), c_fc.bias (4C)
 
 `load_checkpoint` accepts the reference's on-disk dict {"model": state_dict, "model_args": {...}}
 including the `_orig_mod.` prefixes torch.compile leaves behind (inference.py:33-44,72-78).
@@ -39,7 +40,9 @@ def model_args(name_or_args):
 
 def synthetic_state_dict(name_or_args, seed=0, scale=1.0, ln_jitter=0.1):
     """numpy PCG64 -> dict[str, float32 ndarray].  N(0, 0.02*scale) for 2-D weights, c_proj scaled by
-    1/sqrt(2L) (model.py:141-145); LayerNorm gains 1 + ln_jitter*N(0,1) so that gains are exercised."""
+    1/sqrt(2L) (model.py:141-145); LayerNorm gains 1 + ln_jitter*N(0,1) so that gains are exercised.  bias=True: every bias vector
+    N(0, 0.02*scale) (the reference initialises them to zero, model.py:152-153; zeros would exercise nothing), drawn AFTER all the weights so
+    that the weights of a seed do not depend on the flag."""
     a = model_args(name_or_args)
     L, C, V, T = a["n_layer"], a["n_embd"], a["vocab_size"], a["block_size"]
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -60,6 +63,16 @@ def synthetic_state_dict(name_or_args, seed=0, scale=1.0, ln_jitter=0.1):
         sd[p + "mlp.c_proj.weight"] = normal((C, 4 * C), 0.02 * scale / math.sqrt(2 * L))
     sd["transformer.ln_f.weight"] = (1.0 + ln_jitter * rng.standard_normal(C)).astype(np.float32)
     sd["lm_head.weight"] = sd["transformer.wte.weight"]  # tied
+    if a["bias"]:
+        for l in range(L):
+            p = f"transformer.h.{l}."
+            sd[p + "ln_1.bias"] = normal((C,), 0.02 * scale)
+            sd[p + "attn.c_attn.bias"] = normal((3 * C,), 0.02 * scale)
+            sd[p + "attn.c_proj.bias"] = normal((C,), 0.02 * scale)
+            sd[p + "ln_2.bias"] = normal((C,), 0.02 * scale)
+            sd[p + "mlp.c_fc.bias"] = normal((4 * C,), 0.02 * scale)
+            sd[p + "mlp.c_proj.bias"] = normal((C,), 0.02 * scale)
+        sd["transformer.ln_f.bias"] = normal((C,), 0.02 * scale)
     return sd
 
 

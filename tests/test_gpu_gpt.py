@@ -99,6 +99,75 @@ def test_dropout_in_the_config_changes_nothing_at_inference():
     assert np.abs(out[0.1] - ref).max() < TOL
 
 
+@pytest.mark.envelope_fallback_ok
+@pytest.mark.parametrize("name", ["tiny", "2M", "6M"])
+def test_bias_true_checkpoint_vs_reference_golden(name):
+    """GPTConfig.bias = True (model.py:14-17,29,31,79,81,115; VERDICT r05 "missing" item 4): logits of the real model.py with N(0, 0.02) bias
+    vectors on every Linear and LayerNorm (tests/golden/make_golden_bias.py).  The fp32 kernels carry the bias terms; a precision="f16x3"
+    request is served by them under the default envelope policy (bit-identical to "f32"), refused under "refuse" / "ignore", and "bf16" is refused."""
+    from mapf_gpt_amd.model import GPT, GPTConfig
+    g = np.load(os.path.join(GOLDEN, f"gptbias_{name}_s1.npz"))
+    plain = np.load(os.path.join(GOLDEN, f"gpt_{name}_s1.npz"))
+    assert np.abs(g["logits"] - plain["logits"]).max() > 0.1          # the bias vectors matter: this is not the bias-free golden again
+    args = dict(weights.model_args(name), bias=True)
+    sd = weights.synthetic_state_dict(args, seed=0, scale=1.0)
+    net = GPT(GPTConfig(**args), max_rows=16, precision="f32")
+    assert net.load_state_dict(sd) == []
+    tokens = torch.from_numpy(g["tokens"]).cuda()
+    logits = net.logits_tokens(tokens).cpu().numpy()
+    err = np.abs(logits - g["logits"]).max()
+    assert err <= TOL, f"{name}: max |dlogit| = {err:.3e}"
+    top2 = np.sort(g["logits"][:, :5], axis=1)[:, -2:]
+    safe = (top2[:, 1] - top2[:, 0]) > 4 * TOL
+    assert np.array_equal(net.act_tokens(tokens, do_sample=False).cpu().numpy()[safe], g["greedy"][safe])
+    # the 16-bit kernels have no bias terms: f16x3 falls back (default policy) ...
+    assert np.array_equal(net.logits_tokens(tokens, precision="f16x3").cpu().numpy(), logits)
+    env = net.envelope()
+    assert env["state"] == "outside" and env["effective_precision"] == "f32" and env["probe_err"] is None
+    # ... or is refused; bf16 always is
+    with pytest.raises(RuntimeError, match="bias"):
+        net.logits_tokens(tokens, precision="bf16")
+    for policy in ("refuse", "ignore"):
+        n2 = GPT(GPTConfig(**args), max_rows=16, precision="f16x3", envelope=policy)
+        n2.load_state_dict(sd)
+        with pytest.raises(RuntimeError, match="bias"):
+            n2.logits_tokens(tokens)
+        assert np.array_equal(n2.logits_tokens(tokens, precision="f32").cpu().numpy(), logits)
+
+
+def test_bias_keys_and_the_config_flag():
+    """load_state_dict(strict=False) semantics of the reference (inference.py:83): a bias=False model ignores *.bias keys (unexpected), a bias=True model
+    without them keeps its zero-initialised vectors (model.py:152-153) = the bias-free logits; at the C ABI, once one bias tensor is set all are wanted."""
+    from mapf_gpt_amd.model import GPT, GPTConfig
+    g = np.load(os.path.join(GOLDEN, "gpt_tiny_s1.npz"))
+    tokens = torch.from_numpy(g["tokens"]).cuda()
+    sd_b = weights.synthetic_state_dict(dict(weights.model_args("tiny"), bias=True), seed=0)
+    sd = weights.synthetic_state_dict("tiny", seed=0)
+    assert all(np.array_equal(sd[k], sd_b[k]) for k in sd)              # the same weights with and without the flag
+    net = GPT(GPTConfig(**weights.model_args("tiny")), max_rows=16)
+    unknown = net.load_state_dict(sd_b)
+    assert sorted(unknown) == sorted(k for k in sd_b if k.endswith(".bias")) and len(unknown) == 13
+    base = net.logits_tokens(tokens).cpu().numpy()
+    assert np.abs(base - g["logits"]).max() <= TOL
+    assert net.envelope()["state"] in ("undecided", "inside")
+    net_b = GPT(GPTConfig(**dict(weights.model_args("tiny"), bias=True)), max_rows=16)
+    net_b.load_state_dict(sd)
+    assert np.array_equal(net_b.logits_tokens(tokens).cpu().numpy(), base)
+    # C ABI: one bias tensor alone -> finalize names what is missing
+    h = ctypes.c_void_p()
+    L = _lib.lib()
+    _lib.check(L.mgpt_gpt_create(ctypes.byref(h), 2, 2, 64, 256, 4))
+    for k, v in sd.items():
+        a = np.ascontiguousarray(v, dtype=np.float32)
+        _lib.check(L.mgpt_gpt_set_param(h, k.encode(), ctypes.c_void_p(a.ctypes.data), a.size, 0))
+    a = np.ascontiguousarray(sd_b["transformer.h.1.mlp.c_fc.bias"])
+    assert L.mgpt_gpt_set_param(h, b"transformer.h.1.mlp.c_fc.bias", ctypes.c_void_p(a.ctypes.data), a.size - 1, 0) == _lib.ERR_ARG
+    _lib.check(L.mgpt_gpt_set_param(h, b"_orig_mod.transformer.h.1.mlp.c_fc.bias", ctypes.c_void_p(a.ctypes.data), a.size, 0))
+    assert L.mgpt_gpt_finalize(h) == _lib.ERR_STATE and b"bias tensor #0" in L.mgpt_last_error()
+    assert L.mgpt_gpt_set_param(h, b"lm_head.bias", ctypes.c_void_p(a.ctypes.data), 67, 0) == _lib.ERR_ARG     # never exists (model.py:131)
+    L.mgpt_gpt_destroy(h)
+
+
 def test_device_sampler_matches_host_restatement():
     net = _net("tiny", max_rows=64)
     rows = np.concatenate([load_tok("mazes000")["tokens"][t] for t in range(4)])[:200]

@@ -57,6 +57,18 @@ def test_gpt_oracle_matches_reference_logits(tag, tol):
     assert np.array_equal(gpt_oracle.act_greedy(gpt_oracle.forward_logits(sd, args, g["tokens"])).numpy(), g["greedy"])
 
 
+@pytest.mark.parametrize("name", ["tiny", "2M", "6M"])
+def test_gpt_oracle_with_bias_vectors_vs_reference(name):
+    """GPTConfig.bias = True: the port's bias terms against the real model.py (tests/golden/make_golden_bias.py)."""
+    g = np.load(os.path.join(GOLDEN, f"gptbias_{name}_s1.npz"))
+    args = dict(weights.model_args(name), bias=True)
+    sd = weights.synthetic_state_dict(args, seed=int(g["seed"]), scale=float(g["scale"]))
+    logits = gpt_oracle.forward_logits(sd, args, g["tokens"]).numpy()
+    assert np.abs(logits - g["logits"]).max() <= 1e-5
+    no_bias = {k: v for k, v in sd.items() if not k.endswith(".bias")}
+    assert np.abs(gpt_oracle.forward_logits(no_bias, args, g["tokens"]).numpy() - g["logits"]).max() > 0.1
+
+
 def test_gpt_oracle_layers_tiny():
     g = np.load(os.path.join(GOLDEN, "gpt_tiny_s1.npz"))
     args = weights.model_args("tiny")
