@@ -199,6 +199,12 @@ int mgpt_gpt_finalize(mgpt_gpt *gpt);
 int mgpt_gpt_forward(mgpt_gpt *gpt, const uint8_t *d_tokens, int rows, float *d_logits,
                      int precision, void *stream);
 
+/* = GPT.forward(idx) for idx of T <= block_size tokens per row (model.py:167-175, "Cannot forward sequence of length t, block size is only
+ * block_size" :170): d_tokens uint8 [rows, T] -> d_logits float32 [rows, 67], the logits of position T - 1.  mgpt_gpt_create accepts
+ * block_size 1 .. 256 (transformer.wpe.weight is [block_size, C]); models with block_size < 256 are served by this entry point only.  Exact-fp32
+ * kernels whatever the model's usual precision: the hot path (tokenizer rows, inference.py:145) is 256 tokens and never comes here. */
+int mgpt_gpt_forward_t(mgpt_gpt *gpt, const uint8_t *d_tokens, int rows, int T, float *d_logits, void *stream);
+
 /* = GPT.act (model.py:244-260): softmax over logits[:5]; do_sample != 0 draws from it with the
  * library's counter-based RNG keyed by (seed, step, row0 + row) -- torch.multinomial's stream is
  * device-specific and not reproduced -- else arg-max.  row0 = GLOBAL id of this call's first row, so

@@ -69,6 +69,7 @@ SYMBOLS = {
     "mgpt_gpt_set_param": (_i, [_vp, ctypes.c_char_p, _vp, _i64, _i]),
     "mgpt_gpt_finalize": (_i, [_vp]),
     "mgpt_gpt_forward": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "mgpt_gpt_forward_t": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mgpt_gpt_act": (_i, [_vp, _vp, _i, _vp, _vp, _i, _u64, _u64, _u64, _i, _vp]),
     "mgpt_gpt_act_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _u64, _vp, _u64, _i, _vp]),
     "mgpt_step_create": (_i, [_pp, _vp, _vp, _vp, _i, _i, _i, _u64, _u64]),

@@ -67,7 +67,8 @@ extern "C" int mgpt_gpt_create(mgpt_gpt **out, int n_layer, int n_head, int n_em
 {
     MGPT_REQUIRE(out, MGPT_ERR_ARG, "NULL argument");
     MGPT_REQUIRE(n_layer > 0 && n_head > 0 && n_embd > 0 && max_rows > 0, MGPT_ERR_ARG, "bad sizes");
-    MGPT_REQUIRE(block_size == kT, MGPT_ERR_UNSUPPORTED, "block_size must be 256 (config-*.py:13), got %d", block_size);
+    // block_size 256 in every released config (config-*.py:13); a shorter one is a model whose rows are T <= block_size tokens: mgpt_gpt_forward_t
+    MGPT_REQUIRE(block_size >= 1 && block_size <= kT, MGPT_ERR_UNSUPPORTED, "block_size must be in 1 .. 256, got %d", block_size);
     MGPT_REQUIRE(n_embd % n_head == 0, MGPT_ERR_ARG, "n_embd %% n_head != 0 (model.py:27)");
     const int hs = n_embd / n_head;
     MGPT_REQUIRE(hs == 32 || hs == 64, MGPT_ERR_UNSUPPORTED, "head size %d: kernels exist for 32 and 64", hs);
@@ -77,7 +78,7 @@ extern "C" int mgpt_gpt_create(mgpt_gpt **out, int n_layer, int n_head, int n_em
     const size_t C = n_embd;
     size_t off = 0;
     g->off_wte = off; off += (size_t)kV * C;
-    g->off_wpe = off; off += (size_t)kT * C;
+    g->off_wpe = off; off += (size_t)block_size * C;
     g->off_lnf = off; off += C;
     for (int l = 0; l < n_layer; l++) {
         LayerOff lo;
@@ -168,7 +169,7 @@ static bool locate_param(const mgpt_gpt *g, const char *name_in, size_t *idx, si
     if (name.compare(0, pre.size(), pre) == 0) name = name.substr(pre.size());
     const size_t C = g->C;
     if (name == "transformer.wte.weight" || name == "lm_head.weight") { *idx = 0; *off = g->off_wte; *count = kV * C; return true; }
-    if (name == "transformer.wpe.weight") { *idx = 1; *off = g->off_wpe; *count = (size_t)kT * C; return true; }
+    if (name == "transformer.wpe.weight") { *idx = 1; *off = g->off_wpe; *count = (size_t)g->block * C; return true; }
     if (name == "transformer.ln_f.weight") { *idx = 2; *off = g->off_lnf; *count = C; return true; }
     const std::string hp = "transformer.h.";
     if (name.compare(0, hp.size(), hp) != 0) return false;
@@ -265,8 +266,8 @@ extern "C" int mgpt_gpt_finalize(mgpt_gpt *g)
     if (g->has_bias)                                       // nn.Linear(bias=True) / LayerNorm(bias=True) come together (model.py:126-131)
         for (size_t i = 0; i < g->bias_set.size(); i++)
             MGPT_REQUIRE(g->bias_set[i], MGPT_ERR_STATE, "the checkpoint has bias vectors, but bias tensor #%zu (0 = ln_f, then six per layer) was never set", i);
-    int rc = gpt_fast_finalize(g);
-    if (rc != MGPT_OK) return rc;
+    int rc = MGPT_OK;
+    if (g->block == kT && (rc = gpt_fast_finalize(g)) != MGPT_OK) return rc;      // (the 16-bit kernels and their operand planes exist for 256-token rows only)
     if ((rc = envelope_stats(g)) != MGPT_OK) return rc;
     // (bias vectors: outside by construction -- the 16-bit kernels have no bias terms, MGPT_PREC_F16X3 requests follow the envelope policy)
     g->env_state = g->has_bias ? 2 : 0; g->env_probe_err = g->env_probe_err_small = g->env_probe_err_large = -1.f; g->env_logged = false;
@@ -349,21 +350,24 @@ static int launch_layernorm(const float *x, const float *w, const float *b, floa
     return MGPT_OK;
 }
 
-static int forward_f32_chunk(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, hipStream_t s)
+// T = tokens per row (kT on the hot path; mgpt_gpt_forward_t: any T <= block_size).  M = rows * T tokens; the GEMMs run on Mp = M rounded up to
+// their 128-token tile -- the padding rows of the workspaces hold whatever an earlier call left there, every token's arithmetic is its own, and
+// the one kernel that mixes tokens (attention) and the q|k|v scatter look at the first M only
+static int forward_f32_chunk(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, hipStream_t s, int T = kT)
 {
     const int C = g->C;
-    const int64_t M = (int64_t)rows * kT;
+    const int64_t M = (int64_t)rows * T, Mp = (M + 127) / 128 * 128;
     const float *P = g->params;
     int rc;
     {
         ProfScope ps(P_EMBED, s);
         const int64_t total = M * (C / 4);
         const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 64);
-        hipLaunchKernelGGL(f32k::embed_kernel, dim3(blocks), dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, M, C);
+        hipLaunchKernelGGL(f32k::embed_kernel, dim3(blocks), dim3(256), 0, s, d_tokens, P + g->off_wte, P + g->off_wpe, g->x, M, C, T);
         MGPT_LAUNCH_CHECK();
     }
     f32k::EpiArgs ep;
-    ep.C = C; ep.n_head = g->nh; ep.hs = g->hs; ep.plane = M * C;
+    ep.C = C; ep.n_head = g->nh; ep.hs = g->hs; ep.plane = M * C; ep.T = T; ep.m_valid = M;
     const float scale = 1.0f / sqrtf((float)g->hs);
     float *q = g->qkv, *k = g->qkv + M * C, *v = g->qkv + 2 * M * C;
     const float *Bv = g->has_bias ? g->bias : nullptr;       // bias = True checkpoints (model.py:14-17,29,31,79,81)
@@ -375,32 +379,33 @@ static int forward_f32_chunk(mgpt_gpt *g, const uint8_t *d_tokens, int rows, flo
         {
             ProfScope ps(P_GEMM_QKV, s);
             ep.bias = bias_at(bo.attn);
-            if ((rc = launch_gemm<f32k::EPI_QKV>(g->xn, P + lo.attn_w, g->qkv, M, 3 * C, C, ep, C, s)) != MGPT_OK) return rc;
+            if ((rc = launch_gemm<f32k::EPI_QKV>(g->xn, P + lo.attn_w, g->qkv, Mp, 3 * C, C, ep, C, s)) != MGPT_OK) return rc;
         }
         {
             ProfScope ps(P_ATTN, s);
-            if (g->hs == 32) hipLaunchKernelGGL((f32k::attn_f32_kernel<32>), dim3(rows * g->nh), dim3(256), 0, s, q, k, v, g->xn, g->nh, scale);
-            else hipLaunchKernelGGL((f32k::attn_f32_kernel<64>), dim3(rows * g->nh), dim3(256), 0, s, q, k, v, g->xn, g->nh, scale);
+            if (g->hs == 32) hipLaunchKernelGGL((f32k::attn_f32_kernel<32>), dim3(rows * g->nh), dim3(256), 0, s, q, k, v, g->xn, g->nh, scale, T);
+            else hipLaunchKernelGGL((f32k::attn_f32_kernel<64>), dim3(rows * g->nh), dim3(256), 0, s, q, k, v, g->xn, g->nh, scale, T);
             MGPT_LAUNCH_CHECK();
         }
         {
             ProfScope ps(P_GEMM_PROJ, s);
             ep.bias = bias_at(bo.proj);
-            if ((rc = launch_gemm<f32k::EPI_RESID>(g->xn, P + lo.proj_w, g->x, M, C, C, ep, C, s)) != MGPT_OK) return rc;
+            if ((rc = launch_gemm<f32k::EPI_RESID>(g->xn, P + lo.proj_w, g->x, Mp, C, C, ep, C, s)) != MGPT_OK) return rc;
         }
         if ((rc = launch_layernorm(g->x, P + lo.ln2, bias_at(bo.ln2), g->xn, M, C, s)) != MGPT_OK) return rc;
         {
             ProfScope ps(P_GEMM_FC, s);
             ep.bias = bias_at(bo.fc);
-            if ((rc = launch_gemm<f32k::EPI_GELU>(g->xn, P + lo.fc_w, g->hbuf, M, 4 * C, C, ep, C, s)) != MGPT_OK) return rc;
+            if ((rc = launch_gemm<f32k::EPI_GELU>(g->xn, P + lo.fc_w, g->hbuf, Mp, 4 * C, C, ep, C, s)) != MGPT_OK) return rc;
         }
         {
             ProfScope ps(P_GEMM_PROJ2, s);
             ep.bias = bias_at(bo.proj2);
-            if ((rc = launch_gemm<f32k::EPI_RESID>(g->hbuf, P + lo.proj2_w, g->x, M, C, 4 * C, ep, C, s)) != MGPT_OK) return rc;
+            if ((rc = launch_gemm<f32k::EPI_RESID>(g->hbuf, P + lo.proj2_w, g->x, Mp, C, 4 * C, ep, C, s)) != MGPT_OK) return rc;
         }
     }
-    return gpt_launch_head(g, rows, d_logits, s);
+    if (T == kT) return gpt_launch_head(g, rows, d_logits, s);
+    return gpt_launch_head_at(g, g->x, (int64_t)T * C, (int64_t)(T - 1) * C, rows, d_logits, s);      // the last position of a T-token row (model.py:186)
 }
 
 // debugging aid for the GPU parity tests: copy an fp32-path workspace buffer out after a forward
@@ -486,6 +491,7 @@ static int gpt_forward_impl(mgpt_gpt *g, const uint8_t *d_tokens, int rows, floa
     MGPT_REQUIRE(g && d_tokens && d_logits, MGPT_ERR_ARG, "NULL argument");
     MGPT_REQUIRE(rows > 0, MGPT_ERR_ARG, "rows=%d", rows);
     MGPT_REQUIRE(g->finalized, MGPT_ERR_STATE, "mgpt_gpt_finalize must precede forward");
+    MGPT_REQUIRE(g->block == kT, MGPT_ERR_UNSUPPORTED, "this entry point takes 256-token rows and the model's block_size is %d: mgpt_gpt_forward_t", g->block);
     hipStream_t s = (hipStream_t)stream;
     // bias = True checkpoints: only the exact-fp32 kernels carry the bias terms.  MGPT_PREC_F16X3 under the fallback policy is served by them
     // (the checkpoint counts as outside the envelope, mgpt_gpt_finalize); every other 16-bit request is refused -- it would be wrong, not imprecise
@@ -526,6 +532,23 @@ static int gpt_forward_impl(mgpt_gpt *g, const uint8_t *d_tokens, int rows, floa
 extern "C" int mgpt_gpt_forward(mgpt_gpt *g, const uint8_t *d_tokens, int rows, float *d_logits, int precision, void *stream)
 {
     return gpt_forward_impl(g, d_tokens, rows, d_logits, precision, stream, rows);
+}
+
+// = GPT.forward(idx) for idx of T <= block_size tokens per row (model.py:167-175: positions 0 .. T - 1, attention over the T tokens, logits of position
+// T - 1).  The hot path never does this -- the tokenizer emits 256-token rows, inference.py:145 -- so it is served by the exact-fp32 kernels alone.
+extern "C" int mgpt_gpt_forward_t(mgpt_gpt *g, const uint8_t *d_tokens, int rows, int T, float *d_logits, void *stream)
+{
+    MGPT_REQUIRE(g && d_tokens && d_logits, MGPT_ERR_ARG, "NULL argument");
+    MGPT_REQUIRE(rows > 0, MGPT_ERR_ARG, "rows=%d", rows);
+    MGPT_REQUIRE(g->finalized, MGPT_ERR_STATE, "mgpt_gpt_finalize must precede forward");
+    MGPT_REQUIRE(T >= 1 && T <= g->block, MGPT_ERR_ARG, "cannot forward sequence of length %d, block size is only %d (model.py:170)", T, g->block);
+    hipStream_t s = (hipStream_t)stream;
+    for (int r0 = 0; r0 < rows; r0 += g->max_rows) {
+        const int n = std::min(g->max_rows, rows - r0);
+        const int rc = forward_f32_chunk(g, d_tokens + (size_t)r0 * T, n, d_logits + (size_t)r0 * kV, s, T);
+        if (rc != MGPT_OK) return rc;
+    }
+    return MGPT_OK;
 }
 
 extern "C" int mgpt_sample_actions(const float *d_logits, int rows, int32_t *d_actions, int do_sample, uint64_t seed,

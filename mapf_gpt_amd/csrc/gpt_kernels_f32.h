@@ -21,18 +21,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kT = 256;   // tokens per row (block_size, experiment_setup/config-*.py:13)
+// T (kernel argument below): tokens per row of THIS call -- 256 on the hot path; GPT.forward accepts any T <= block_size (model.py:167-175), which
+// mgpt_gpt_forward_t serves with these kernels.  For T = 256 every kernel executes the instructions it executed before T was an argument.
 
 // ----- embedding: x = wte[idx] + wpe[pos]  (model.py:171-175) -----
 __global__ __launch_bounds__(256) void embed_kernel(const uint8_t *__restrict__ tokens, const float *__restrict__ wte,
                                                     const float *__restrict__ wpe, float *__restrict__ x, int64_t n_tok,
-                                                    int C)
+                                                    int C, int T = kT)
 {
     const int c4n = C >> 2;
     const int64_t total = n_tok * c4n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t tok = i / c4n;
         const int c4 = (int)(i - tok * c4n);
-        const int t = (int)(tok & (kT - 1));
+        const int t = (int)(tok % T);
         const int id = tokens[tok];
         const float4 a = reinterpret_cast<const float4 *>(wte + (size_t)id * C)[c4];
         const float4 b = reinterpret_cast<const float4 *>(wpe + (size_t)t * C)[c4];
@@ -99,6 +101,8 @@ struct EpiArgs {
     int C, n_head, hs;      // EPI_QKV: scatter into [3][rows][n_head][256][hs]
     int64_t plane;          // EPI_QKV: elements per q/k/v plane = M * C
     const float *bias = nullptr;   // nn.Linear bias [N] of a bias = True checkpoint (model.py:29,31,79,81), else NULL
+    int T = kT;                    // EPI_QKV: tokens per row
+    int64_t m_valid = INT64_MAX;   // EPI_QKV: tokens of the call (M is padded to the 128-token tile when rows * T is not a multiple of it: no scatter from the padding)
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             if (EPI == EPI_QKV) {                               // model.py:50-53
                 const int which = n / ep.C, cc = n - which * ep.C;
                 const int head = cc / ep.hs, d = cc - head * ep.hs;
-                qkv_col = (int64_t)which * ep.plane + (int64_t)head * kT * ep.hs + d;
+                qkv_col = (int64_t)which * ep.plane + (int64_t)head * ep.T * ep.hs + d;
             }
 #pragma unroll
             for (int g = 0; g < 16; g++) {
@@ -204,9 +208,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                 } else if (EPI == EPI_GELU) {
                     out[m * N + n] = gelu_erf(v);               // nn.GELU() exact erf, model.py:80,86
                 } else {
-                    const int64_t b = m >> 8;                   // kT == 256
-                    const int t = (int)(m & (kT - 1));
-                    out[qkv_col + (b * ep.n_head * kT + t) * ep.hs] = v;
+                    const int64_t b = m / ep.T;
+                    const int t = (int)(m - b * ep.T);
+                    if (m < ep.m_valid) out[qkv_col + (b * ep.n_head * ep.T + t) * ep.hs] = v;
                 }
             }
         }
@@ -218,24 +222,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 // position for O^T = V^T P^T -- nothing moves across lanes and S never leaves registers.
 // Keys are walked in tiles of 32 with a running (max, sum) pair (exact softmax, flash-style
 // rescaling), which keeps the kernel at ~100 VGPRs instead of holding all 256x32 scores.
+// T tokens per row (256 on the hot path).  T % 32 != 0: the last tile's missing keys and queries are read from row T - 1 (in bounds, finite), the missing
+// keys' scores are -inf before the running maximum (probability exactly 0, as if they were not there), the missing queries are not stored.
 template <int HS>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                        const float *__restrict__ v, float *__restrict__ y, int n_head,
-                                                       float scale)
+                                                       float scale, int T = kT)
 {
-    constexpr int HH = HS / 2, DT = HS / 32, KT = kT / 32;
+    constexpr int HH = HS / 2, DT = HS / 32;
+    const int KT = (T + 31) >> 5;
+    const bool ragged = (T & 31) != 0;                          // (uniform)
     const int bh = blockIdx.x;
     const int b = bh / n_head, head = bh - b * n_head;
     const int C = n_head * HS;
-    const float *Q = q + (size_t)bh * kT * HS, *Kp = k + (size_t)bh * kT * HS, *V = v + (size_t)bh * kT * HS;
+    const float *Q = q + (size_t)bh * T * HS, *Kp = k + (size_t)bh * T * HS, *V = v + (size_t)bh * T * HS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
 
     for (int qt = wave; qt < KT; qt += 4) {
         float4 qf[HH / 4];                                      // Q[query r][h*HH .. h*HH+HH)
+        const int qi = min(qt * 32 + r, T - 1);
 #pragma unroll
         for (int i = 0; i < HH / 4; i++)
-            qf[i] = *reinterpret_cast<const float4 *>(Q + (size_t)(qt * 32 + r) * HS + h * HH + 4 * i);
+            qf[i] = *reinterpret_cast<const float4 *>(Q + (size_t)qi * HS + h * HH + 4 * i);
         f32x16 o[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; dt++)
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float *__restrict__
             f32x16 s;
 #pragma unroll
             for (int g = 0; g < 16; g++) s[g] = 0.f;
-            const float *krow = Kp + (size_t)(kt * 32 + r) * HS + h * HH;
+            const float *krow = Kp + (size_t)min(kt * 32 + r, T - 1) * HS + h * HH;
 #pragma unroll
             for (int i = 0; i < HH / 4; i++) {
                 const float4 kf = *reinterpret_cast<const float4 *>(krow + 4 * i);
@@ -258,6 +267,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float *__restrict__
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[i].w, s, 0, 0, 0);
             }
             // s[g] = S[query r][key = kt*32 + (g&3) + 8*(g>>2) + 4*h]
+            const bool last_ragged = ragged && kt == KT - 1;     // (uniform)
+            if (last_ragged) {
+#pragma unroll
+                for (int g = 0; g < 16; g++)
+                    if (kt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h >= T) s[g] = -INFINITY;
+            }
             float mx = s[0];
 #pragma unroll
             for (int g = 1; g < 16; g++) mx = fmaxf(mx, s[g]);
@@ -283,14 +298,17 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float *__restrict__
                 const int key = (g & 3) + 8 * (g >> 2);         // + kt*32 + 4*h folded into vbase
 #pragma unroll
                 for (int dt = 0; dt < DT; dt++) {
-                    const float vv = vbase[(size_t)key * HS + dt * 32];
+                    float vv;
+                    if (last_ragged) vv = V[(size_t)min(kt * 32 + 4 * h + key, T - 1) * HS + r + dt * 32];   // (its probability is 0)
+                    else vv = vbase[(size_t)key * HS + dt * 32];
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[g], o[dt], 0, 0, 0);
                 }
             }
         }
         const float inv = 1.0f / l_run;
         // o[dt][g] = O[query r][d = dt*32 + (g&3) + 8*(g>>2) + 4*h]  -> y[b, t, head*HS + d]  (model.py:68)
-        float *yrow = y + ((size_t)b * kT + qt * 32 + r) * C + head * HS;
+        if (qt * 32 + r >= T) continue;                         // (a query the row does not have: nothing to store; no barrier below)
+        float *yrow = y + ((size_t)b * T + qt * 32 + r) * C + head * HS;
 #pragma unroll
         for (int dt = 0; dt < DT; dt++)
 #pragma unroll

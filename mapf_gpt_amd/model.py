@@ -133,9 +133,26 @@ class GPT:
         return _lib.PRECISIONS[precision or self.precision]
 
     def _tokens_u8(self, idx):
-        if idx.dim() != 2 or idx.shape[1] != self.config.block_size or self.config.block_size != 256:
-            raise ValueError(f"idx must be [B, 256] token rows, got {tuple(idx.shape)}")
+        # model.py:168-170: any t <= block_size.  256-token rows (what the tokenizer emits, inference.py:145) take the model's kernels of its
+        # precision; shorter rows are served by the exact-fp32 kernels (mgpt_gpt_forward_t)
+        if idx.dim() != 2 or idx.shape[1] < 1:
+            raise ValueError(f"idx must be [B, T] token rows, got {tuple(idx.shape)}")
+        if idx.shape[1] > self.config.block_size:
+            raise ValueError(f"Cannot forward sequence of length {idx.shape[1]}, block size is only {self.config.block_size}")
         return idx.to(device=self.device, dtype=torch.uint8).contiguous()
+
+    def logits_tokens_t(self, tokens_u8, out=None):
+        """tokens uint8 [rows, T <= block_size] on the device -> float32 [rows, 67]: the logits of position T - 1 (model.py:186), exact-fp32 kernels."""
+        assert self._loaded, "load_state_dict first"
+        rows, T = tokens_u8.shape
+        if out is None:
+            out = torch.empty((rows, 67), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgpt_gpt_forward_t(self._h, _lib.ptr(tokens_u8), rows, T, _lib.ptr(out), _lib.stream_ptr()))
+        return out
+
+    def _logits(self, tokens_u8):
+        return self.logits_tokens(tokens_u8) if tokens_u8.shape[1] == 256 else self.logits_tokens_t(tokens_u8)
 
     def logits_tokens(self, tokens_u8, precision=None, out=None):
         """tokens uint8 [rows, 256] on the device -> float32 [rows, 67] (last-position logits)."""
@@ -164,7 +181,7 @@ class GPT:
     def forward(self, idx, targets=None):
         if targets is not None:
             raise NotImplementedError("training loss is out of scope (inference path only)")
-        logits = self.logits_tokens(self._tokens_u8(idx))
+        logits = self._logits(self._tokens_u8(idx))
         return logits[:, None, :], None
 
     __call__ = forward
@@ -177,6 +194,11 @@ class GPT:
         successive calls draw fresh uniforms like the reference's advancing global RNG does.
         Returns an int64 tensor [B] (0-d for B == 1, like the reference's .squeeze())."""
         tokens = self._tokens_u8(idx)
+        if tokens.shape[1] != 256:                 # short rows (never the hot path): logits from the fp32 kernels, then the reference's own call shape
+            logits = self.logits_tokens_t(tokens)
+            if do_sample:
+                return torch.multinomial(torch.softmax(logits[:, :5], dim=-1), num_samples=1, generator=generator).squeeze()   # model.py:250-257
+            return torch.argmax(logits[:, :5], dim=-1).squeeze()                                                               # model.py:258-259
         if do_sample and generator is not None:
             logits = self.logits_tokens(tokens)
             probs = torch.softmax(logits[:, :5], dim=-1)                       # model.py:250-254

@@ -42,7 +42,8 @@ def test_version_and_error_string(L):
 
 def test_argument_validation_without_gpu(L):
     h = ctypes.c_void_p()
-    assert L.mgpt_gpt_create(ctypes.byref(h), 2, 2, 64, 161, 4) == _lib.ERR_UNSUPPORTED      # block_size must be 256
+    assert L.mgpt_gpt_create(ctypes.byref(h), 2, 2, 64, 257, 4) == _lib.ERR_UNSUPPORTED      # block_size 1 .. 256
+    assert L.mgpt_gpt_create(ctypes.byref(h), 2, 2, 64, 0, 4) == _lib.ERR_UNSUPPORTED
     assert L.mgpt_gpt_create(ctypes.byref(h), 2, 3, 64, 256, 4) == _lib.ERR_ARG              # n_embd % n_head
     # InputParameters (observation_generator.h:22-40): non-default values are honoured inside the kernels' layout bounds
     # (tests/test_gpu_tokenizer.py::test_non_default_input_parameters_vs_reference_goldens); outside them the call refuses

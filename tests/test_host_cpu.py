@@ -122,13 +122,18 @@ def test_gpt_envelope_policy_names():
         assert f"#define MGPT_ENVELOPE_{name} {value}" in header
 
 
-def test_gpt_config_dropout_is_an_eval_mode_no_op_and_bias_is_refused():
+def test_gpt_config_flags_accepted_at_construction():
     """model.py:33-34,59,82,129: every Dropout of the reference is the identity once inference.py:85 has called net.eval(); this inference-only
-    implementation therefore accepts any dropout in [0, 1) and ignores it.  bias=True (Linear / LayerNorm biases, model.py:17,29-31,79-81) is not
-    implemented and is refused at construction -- no device needed for either."""
+    implementation therefore accepts any dropout in [0, 1) and ignores it.  bias=True (Linear / LayerNorm biases, model.py:17,29-31,79-81) and the
+    reference's default block_size (161, model.py:109) are accepted too (tests/test_gpu_gpt.py has the parity side) -- no device needed here; rows longer
+    than block_size are refused in the reference's words (model.py:170)."""
+    import torch
     from mapf_gpt_amd.model import GPT, GPTConfig
     assert GPT(GPTConfig(block_size=256, dropout=0.1)).config.dropout == 0.1
-    with pytest.raises(ValueError, match="bias"):
-        GPT(GPTConfig(block_size=256, bias=True))
+    assert GPT(GPTConfig(block_size=256, bias=True)).config.bias is True
+    net = GPT(GPTConfig())
+    assert net.config.block_size == 161
+    with pytest.raises(ValueError, match="Cannot forward sequence of length 162, block size is only 161"):
+        net._tokens_u8(torch.zeros((1, 162), dtype=torch.int64))
     with pytest.raises(ValueError, match="dropout"):
         GPT(GPTConfig(block_size=256, dropout=1.5))

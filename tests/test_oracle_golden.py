@@ -69,6 +69,24 @@ def test_gpt_oracle_with_bias_vectors_vs_reference(name):
     assert np.abs(gpt_oracle.forward_logits(no_bias, args, g["tokens"]).numpy() - g["logits"]).max() > 0.1
 
 
+def test_gpt_oracle_on_rows_shorter_than_256_tokens_vs_reference():
+    """GPT.forward for T <= block_size (model.py:167-175) and a block_size = 100 model: the port against the real model.py
+    (tests/golden/make_golden_short.py)."""
+    g = np.load(os.path.join(GOLDEN, "gptshort.npz"))
+    keys = sorted({k.rsplit("_", 1)[0] for k in g.files})
+    assert len(keys) == 14
+    for k in keys:
+        name, rest = k.split("_b")
+        block, T = (int(x) for x in rest.split("_t"))
+        if name == "85M":
+            continue                                                   # (seconds of CPU per row; the GPU test covers it)
+        args = dict(weights.model_args(name), block_size=block)
+        sd = weights.synthetic_state_dict(args, seed=0, scale=1.0)
+        assert g[k + "_tokens"].shape[1] == T
+        logits = gpt_oracle.forward_logits(sd, args, g[k + "_tokens"]).numpy()
+        assert np.abs(logits - g[k + "_logits"]).max() <= 1e-5, k
+
+
 def test_gpt_oracle_layers_tiny():
     g = np.load(os.path.join(GOLDEN, "gpt_tiny_s1.npz"))
     args = weights.model_args("tiny")
