@@ -4,8 +4,8 @@ env (GridEnv, POGEMA's list API) -> MAPFGPTInference.act -> env.step until the e
 
     python example.py --map_name validation-random-seed-000 --num_agents 32 --model 2M [--weights weights/MAPF-GPT-2M.pt]
 
-Without released weights (unreachable offline) `--weights synthetic:2M` (the default) runs a randomly initialised policy;
-animation export (POGEMA's SVG writer) is not part of this package.
+Without released weights (unreachable offline) `--weights synthetic:2M` (the default) runs a randomly initialised policy.
+`--animation` writes the episode as svg/<map>-<model>-seed-<seed>.svg (example.py:59,66-70; own writer, mapf_gpt_amd/animation.py).
 """
 import argparse
 
@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--model", type=str, choices=["2M", "6M", "85M", "DDG-2M"], default="2M")
     ap.add_argument("--weights", type=str, default=None, help="checkpoint path (default: synthetic:<model>)")
     ap.add_argument("--precision", type=str, default="f16x3", choices=["f32", "f16x3", "bf16"])
+    ap.add_argument("--animation", action="store_true", help="save the episode as an animated SVG (example.py:30,66-70)")
     a = ap.parse_args()
 
     from mapf_gpt_amd import maps
@@ -45,7 +46,11 @@ def main():
     shape = "2M" if a.model == "DDG-2M" else a.model
     algo = MAPFGPTInference(MAPFGPTInferenceConfig(path_to_weights=a.weights or f"synthetic:{shape}", device=a.device,
                                                    precision=a.precision))
+    if a.animation:
+        env.enable_animation()                                                     # example.py:59
     print(run_episode(env, algo))
+    if a.animation:
+        print("Saved animation to:", env.save_animation(f"svg/{a.map_name}-{a.model}-seed-{a.seed}.svg"))   # example.py:66-70
 
 
 if __name__ == "__main__":

@@ -140,7 +140,22 @@ class GridEnv:
             _lib.check(_lib.lib().mgpt_env_step_host(e._h, ctypes.c_void_p(act.ctypes.data) if act is not None else None,
                                                      ctypes.c_void_p(self._host.ctypes.data), _lib.stream_ptr()))
         host = self._host
-        return host[:4 * n].view(np.int16).reshape(n, 2), host[4 * n:8 * n].view(np.int16).reshape(n, 2), int(host[8 * n])
+        pos, goal = host[:4 * n].view(np.int16).reshape(n, 2), host[4 * n:8 * n].view(np.int16).reshape(n, 2)
+        if getattr(self, "_frames", None) is not None:         # enable_animation(): keep what is handed out anyway
+            self._frames.append(pos.copy())
+            self._goal_frames.append(goal.copy())
+        return pos, goal, int(host[8 * n])
+
+    def enable_animation(self):
+        """= env.enable_animation() of the reference's example (example.py:59): record the episode for save_animation."""
+        self._frames, self._goal_frames = [], []
+
+    def save_animation(self, path, seconds_per_step=0.25):
+        """= env.save_animation(svg_path) (example.py:67-69): the episode since the last reset as one animated SVG (mapf_gpt_amd/animation.py)."""
+        from . import animation
+        if getattr(self, "_frames", None) is None:
+            raise RuntimeError("enable_animation() first")
+        return animation.write_svg(path, self.grid, self._frames, self._goal_frames, seconds_per_step)
 
     def _obs(self, pos, goal):
         p, g = pos.tolist(), goal.tolist()
@@ -152,6 +167,8 @@ class GridEnv:
             self.seed = seed
         pos, goal = maps.place_agents(self.grid, self.num_agents, self.seed, self.start_ok, self.goal_ok)
         self._env.reset(torch.from_numpy(pos[None]), torch.from_numpy(goal[None]))
+        if getattr(self, "_frames", None) is not None:
+            self._frames, self._goal_frames = [], []           # a recording covers one episode
         pos, goal, _ = self._pull()
         return self._obs(pos, goal), {}
 

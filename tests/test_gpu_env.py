@@ -128,3 +128,27 @@ def test_rule_switches_match_the_oracle(rules):
     assert differs, "the mask must change at least one outcome on this scenario"
     with pytest.raises(RuntimeError):
         env.set_rules(8)
+
+
+def test_grid_env_records_and_saves_an_episode_animation(tmp_path):
+    """enable_animation() / save_animation() of the list-API env (example.py:59,66-70): frames = reset + every step, positions as handed out."""
+    import xml.etree.ElementTree as ET
+    from mapf_gpt_amd.env import GridEnv
+    env = GridEnv(map_name="validation-random-seed-000", num_agents=8, seed=1, max_episode_steps=16)
+    with pytest.raises(RuntimeError):
+        env.save_animation(str(tmp_path / "x.svg"))
+    env.enable_animation()
+    obs, _ = env.reset()
+    rng = np.random.default_rng(0)
+    seen = [[o["global_xy"] for o in obs]]
+    for _ in range(5):
+        obs, *_ = env.step(rng.integers(0, 5, size=8).tolist())
+        seen.append([o["global_xy"] for o in obs])
+    assert len(env._frames) == 6 and all(np.array_equal(np.asarray(s), f) for s, f in zip(seen, env._frames))
+    root = ET.parse(env.save_animation(str(tmp_path / "ep.svg"))).getroot()
+    ns = "{http://www.w3.org/2000/svg}"
+    assert len(root.findall(ns + "circle")) == 16
+    moved = [c for c in root.findall(ns + "circle") if c.findall(ns + "animate")]
+    assert moved and all(len(a.attrib["values"].split(";")) == 6 for c in moved for a in c.findall(ns + "animate"))
+    env.reset()
+    assert len(env._frames) == 1                                                # a recording covers one episode

@@ -137,3 +137,32 @@ def test_gpt_config_flags_accepted_at_construction():
         net._tokens_u8(torch.zeros((1, 162), dtype=torch.int64))
     with pytest.raises(ValueError, match="dropout"):
         GPT(GPTConfig(block_size=256, dropout=1.5))
+
+
+def test_animation_writer_svg(tmp_path):
+    """mapf_gpt_amd/animation.py (the role of env.save_animation, example.py:66-70): well-formed SVG, one disc + one ring per agent, key frames = recorded
+    frames, the padded border cropped, a standing agent not animated, a goal change moves the ring."""
+    import xml.etree.ElementTree as ET
+    from mapf_gpt_amd import animation
+    grid = maps.pad(np.array([[0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 0, 0]], np.uint8))
+    frames = [np.array([[5, 5], [7, 8]]), np.array([[6, 5], [7, 8]]), np.array([[6, 6], [7, 8]])]
+    goals = [np.array([[7, 7], [5, 7]]), np.array([[7, 7], [5, 7]]), np.array([[7, 7], [6, 5]])]
+    path = animation.write_svg(str(tmp_path / "sub" / "ep.svg"), grid, frames, goals, seconds_per_step=0.5)
+    root = ET.parse(path).getroot()
+    ns = "{http://www.w3.org/2000/svg}"
+    assert root.attrib["viewBox"] == "0 0 80 60"                                # 4 x 3 cells of 20 px: border cropped
+    rects = root.findall(ns + "rect")
+    assert len(rects) == 1 + 2                                                   # background + two obstacles
+    assert {(r.attrib["x"], r.attrib["y"]) for r in rects[1:]} == {("20", "0"), ("60", "20")}
+    circles = root.findall(ns + "circle")
+    assert len(circles) == 4
+    rings, discs = circles[:2], circles[2:]
+    assert all(c.attrib["fill"] == "none" for c in rings) and rings[0].attrib["stroke"] == discs[0].attrib["fill"] != discs[1].attrib["fill"]
+    a0 = discs[0].findall(ns + "animate")
+    assert len(a0) == 2 and a0[0].attrib["values"] == "10;10;30" and a0[1].attrib["values"] == "10;30;30" and a0[0].attrib["dur"] == "1s"
+    assert a0[0].attrib["keyTimes"] == "0.00000;0.50000;1.00000"
+    assert discs[1].findall(ns + "animate") == []                               # agent 1 never moved
+    assert rings[0].findall(ns + "animate") == [] and len(rings[1].findall(ns + "animate")) == 2    # only agent 1's goal changed
+    assert rings[1].findall(ns + "animate")[0].attrib["calcMode"] == "discrete"
+    with pytest.raises(ValueError):
+        animation.write_svg(str(tmp_path / "none.svg"), grid, [], goals)
