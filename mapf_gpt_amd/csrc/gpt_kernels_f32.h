@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const uint8_t *__restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t tok = i / c4n;
         const int c4 = (int)(i - tok * c4n);
-        const int t = (int)(tok % T);
+        const int t = T == kT ? (int)(tok & (kT - 1)) : (int)((unsigned)tok % (unsigned)T);
         const int id = tokens[tok];
         const float4 a = reinterpret_cast<const float4 *>(wte + (size_t)id * C)[c4];
         const float4 b = reinterpret_cast<const float4 *>(wpe + (size_t)t * C)[c4];
@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                 } else if (EPI == EPI_GELU) {
                     out[m * N + n] = gelu_erf(v);               // nn.GELU() exact erf, model.py:80,86
                 } else {
-                    const int64_t b = m / ep.T;
-                    const int t = (int)(m - b * ep.T);
+                    int64_t b;
+                    int t;
+                    if (ep.T == kT) { b = m >> 8; t = (int)(m & (kT - 1)); }                     // (uniform) the hot shape: no division
+                    else { const unsigned bu = (unsigned)m / (unsigned)ep.T; b = bu; t = (int)((unsigned)m - bu * (unsigned)ep.T); }   // (token counts fit 32 bits: the workspaces do)
                     if (m < ep.m_valid) out[qkv_col + (b * ep.n_head * ep.T + t) * ep.hs] = v;
                 }
             }
