@@ -80,6 +80,11 @@ typedef struct mgpt_tokenizer mgpt_tokenizer;
 int mgpt_tokenizer_create(mgpt_tokenizer **out, const mgpt_input_parameters *cfg,
                           int n_inst, int n_agents, int H, int W, int n_grids);
 int mgpt_tokenizer_destroy(mgpt_tokenizer *tok);
+/* = the size of Encoder's vocabulary (cpp:321-350): 2 cost2go_value_limit + 27 -- the integers -limit .. limit, the three sentinels,
+ * six actions, sixteen direction strings and "!".  67 for the reference's limit of 20 = the vocab_size of every released model (model.py:110).
+ * A policy whose embedding has fewer rows cannot take this tokenizer's rows: the reference's nn.Embedding raises IndexError there,
+ * mgpt_step_create returns MGPT_ERR_UNSUPPORTED, and mgpt_gpt_forward does not look at the ids it is given. */
+int mgpt_tokenizer_vocab_size(const mgpt_tokenizer *tok, int *out);
 
 /* the `grid` ctor argument (h:112): d_grids = uint8 [n_grids, H, W], non-zero = blocked */
 int mgpt_tokenizer_set_grids(mgpt_tokenizer *tok, const uint8_t *d_grids, void *stream);

@@ -41,6 +41,7 @@ SYMBOLS = {
     "mgpt_device_count": (_i, [ctypes.POINTER(_i)]),
     "mgpt_tokenizer_create": (_i, [_pp, ctypes.POINTER(InputParametersStruct), _i, _i, _i, _i, _i]),
     "mgpt_tokenizer_destroy": (_i, [_vp]),
+    "mgpt_tokenizer_vocab_size": (_i, [_vp, _vp]),
     "mgpt_tokenizer_set_grids": (_i, [_vp, _vp, _vp]),
     "mgpt_tokenizer_create_agents": (_i, [_vp, _vp, _vp, _vp]),
     "mgpt_tokenizer_update_agents": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),

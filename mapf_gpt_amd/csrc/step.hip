@@ -69,6 +69,14 @@ extern "C" int mgpt_step_create(mgpt_step **out, mgpt_tokenizer *tok, mgpt_gpt *
                                 int do_sample, uint64_t seed, uint64_t row0)
 {
     MGPT_REQUIRE(out && tok && gpt && env && rows > 0, MGPT_ERR_ARG, "bad argument");
+    {   // a tokenizer with a larger value limit than the policy's vocabulary was built for emits ids the embedding does not have (the reference:
+        // IndexError in nn.Embedding, model.py:126,172)
+        int vocab = 0;
+        const int rc = mgpt_tokenizer_vocab_size(tok, &vocab);
+        if (rc != MGPT_OK) return rc;
+        MGPT_REQUIRE(vocab <= MGPT_VOCAB, MGPT_ERR_UNSUPPORTED, "the tokenizer's vocabulary has %d tokens (cost2go_value_limit %d), the policy's embedding %d",
+                     vocab, (vocab - 27) / 2, MGPT_VOCAB);
+    }
     mgpt_step *st = new mgpt_step();
     st->tok = tok; st->gpt = gpt; st->env = env; st->rows = rows; st->precision = precision; st->do_sample = do_sample;
     st->seed = seed; st->row0 = row0;

@@ -922,6 +922,13 @@ extern "C" int mgpt_tokenizer_destroy(mgpt_tokenizer *t)
     return MGPT_OK;
 }
 
+extern "C" int mgpt_tokenizer_vocab_size(const mgpt_tokenizer *t, int *out)
+{
+    MGPT_REQUIRE(t && out, MGPT_ERR_ARG, "NULL argument");
+    *out = 2 * t->cfg.L + 27;                            // cpp:321-350: 2 L + 1 integers, -80 / -40 / +40, 6 actions, 16 direction strings, "!"
+    return MGPT_OK;
+}
+
 extern "C" int mgpt_tokenizer_set_grids(mgpt_tokenizer *t, const uint8_t *d_grids, void *stream)
 {
     MGPT_REQUIRE(t && d_grids, MGPT_ERR_ARG, "NULL argument");

@@ -98,6 +98,12 @@ class MAPFGPTInference:
                            device=self.cfg.device, envelope=self.cfg.envelope)
             self.net.load_state_dict(sd, strict=False)                       # inference.py:83
             self.net.eval()
+        # (the reference builds Encoder's vocabulary from cost2go_value_limit, cpp:321-350, and its nn.Embedding raises IndexError on ids the
+        #  model was not built for; here the ids would index past the embedding table on the device, so the pairing is checked up front)
+        vocab = getattr(getattr(self.net, "config", None), "vocab_size", 67)      # (an injected net may be any callable with .act, inference.py:79-80)
+        if 2 * self.cfg.cost2go_value_limit + 27 > vocab:
+            raise ValueError(f"cost2go_value_limit={self.cfg.cost2go_value_limit} gives a vocabulary of {2 * self.cfg.cost2go_value_limit + 27} tokens; "
+                             f"the policy's embedding has {vocab} (model.py:110,126)")
         self.input_parameters = InputParameters(                              # inference.py:109-118
             self.cfg.cost2go_value_limit, self.cfg.num_agents, self.cfg.num_previous_actions, self.cfg.context_size,
             self.cfg.cost2go_radius, self.cfg.agents_radius, self.cfg.grid_step, self.cfg.save_cost2go)

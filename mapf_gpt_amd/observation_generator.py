@@ -62,6 +62,13 @@ class BatchedTokenizer:
             _lib.check(_lib.lib().mgpt_tokenizer_set_grids(self._h, _lib.ptr(self.grids), _lib.stream_ptr()))
         self.rows = self.n_inst * self.n_agents
 
+    @property
+    def vocab_size(self):
+        """Tokens of the Encoder's vocabulary for this configuration (cpp:321-350): 2 * cost2go_value_limit + 27; 67 with the reference's limit."""
+        v = ctypes.c_int(0)
+        _lib.check(_lib.lib().mgpt_tokenizer_vocab_size(self._h, ctypes.byref(v)))
+        return v.value
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
