@@ -634,6 +634,12 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event hooks")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed without a launcher: become the launch line the contract names (one rank per GPU, rendezvous on
+        # 127.0.0.1 -- the container hostname may not resolve); the ranks then run this file from the top with RANK / WORLD_SIZE set
+        port = os.environ.get("MASTER_PORT", "29577")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -56,6 +56,20 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     assert all("sclk_mhz_mean" in r and "socket_power_w_mean" in r for r in pr)
 
 
+def test_bench_gpus_n_without_a_launcher_launches_itself():
+    """`python bench.py --gpus 2` with no torchrun around it re-executes as the contract's launch line (two ranks; here sharing the one
+    GPU over gloo) instead of failing on the world-size assertion."""
+    env = dict(os.environ, MGPT_BENCH_BACKEND="gloo", MGPT_BENCH_SHARE_GPU="1", MASTER_PORT="29549")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg4",
+           "--instances", "3", "--no-prof"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and "6 total" in j["config"]["workload"] and len(j["per_rank"]) == 2
+
+
 def test_bench_single_rank_line():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--instances", "4",
            "--no-cpu-baseline", "--no-tokenizer-leg", "--no-secondary"]
