@@ -448,7 +448,9 @@ def build_workload(name, precision, rank, world, local_rank, instances=0, use_gr
     # rows per forward launch.  85M: 4096 (round 6, tools/sweep_chunk85.sh: 1024 -> 1602, 2048 -> 1587, 4096 -> 1573 ms per cfg5 step; launches of
     # <= 512 rows are SLOWER -- the q|k|v and hidden planes of a small launch do not come back from the memory-side cache)
     chunk = min(rows, chunk_rows or (16384 if model != "85M" else 4096))
-    net = build_model(model, seed=0, max_rows=chunk, precision=precision, device=f"cuda:{local_rank}")
+    # (MGPT_BENCH_ENVELOPE=ignore: timing-only ablation builds whose wrong logits the precision-envelope probe would answer with the fp32 kernels)
+    net = build_model(model, seed=0, max_rows=chunk, precision=precision, device=f"cuda:{local_rank}",
+                      envelope=os.environ.get("MGPT_BENCH_ENVELOPE", "fallback"))
     if name == "cfg4":                     # one map per instance, seeded by the global instance id
         grid, pos, goal = cfg4_instances(lo, hi, n_agents)
         s_ok = g_ok = None

@@ -29,6 +29,15 @@ constexpr int kLast1R = 4;                      // rows per workgroup
 // feature split: a token's normalised row is held by S threads (C / S registers each), the workgroup has 256 S threads
 constexpr int last1_split(int C) { return C >= 128 ? 2 : 1; }   // (4 for C = 256 spills under the 128-register cap of 16 waves and is 0.6 ms slower)
 
+// workgroup barrier for LDS traffic only: __syncthreads() also waits for every global load in flight (vmcnt(0)) -- here that would be the next
+// row's tokens, requested ahead on purpose
+__device__ __forceinline__ void last1_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int C, int R = kLast1R, bool TAIL = false>
 constexpr int kLast1Lds = (64 * (C + 4) + R * (C / 32) * C + last1_split(C) * (C / 32) * 256 + 3 * R * C + 2 * last1_split(C) * 256 + (TAIL ? 7 * C : 0)) * 4;
 
@@ -182,6 +191,22 @@ void attn_last1_kernel(const float *__restrict__ x, const float *__restrict__ ga
         return;
     }
     const int nr = (n_rows - b0 < R) ? (int)(n_rows - b0) : R;
+    // The token phases keep a row in registers (thread = (token, feature slice): CS floats), and a row's 256 x C floats are the kernel's whole
+    // memory traffic -- so the loads of row r + 1 are issued AHEAD of their use, by every wave
+    // as soon as the z phase of row r has put the wave's tokens into LDS (round 6: issued at the top of a row's token phases they were a
+    // serial 0.8 ms of the 1.7-ms launch at 12 288 rows -- profiles/r06_ab.txt, visit F).
+    float xn[CS];
+    auto load_row = [&](int r) {
+        const int64_t m = (b0 + r) * T + tok;
+        const float *xp = x + (((m >> 5) * (C >> 3) + sp * (CS / 8)) << 8) + ((m & 31) << 3);
+#pragma unroll
+        for (int c8 = 0; c8 < CS / 8; c8++) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(xp + c8 * 256), a1 = *reinterpret_cast<const f32x4 *>(xp + c8 * 256 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { xn[8 * c8 + i] = a0[i]; xn[8 * c8 + 4 + i] = a1[i]; }
+        }
+    };
+    const float gain_tid = tid < C ? gain[tid] : 0.0f;                 // (read here: a load at the end of a row would wait for the row requested ahead)
     // ---- phase 0: xn_255 of the R rows, one wave per row (two-pass LayerNorm, eps 1e-5, gain, no bias: model.py:20) ----
     if (wave < R) {
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -250,20 +275,12 @@ void attn_last1_kernel(const float *__restrict__ x, const float *__restrict__ ga
     }
     __syncthreads();
     // ---- the token phases, row by row: thread = (token tok, feature slice sp); xn below is the normalised row WITHOUT the gain ----
+    load_row(0);            // (before the matrix-vector products above it costs them their registers: 424 bytes of scratch per lane at C = 256)
 #pragma unroll 1
     for (int r = 0; r < nr; r++) {
         float *ur = uS + r * NH * C;
-        // x_t -> xn_t (this thread's CS features of it)
-        float xn[CS];
+        // x_t -> xn_t (this thread's CS features of it; the raw row was requested ahead: load_row above)
         {
-            const int64_t m = (b0 + r) * T + tok;
-            const float *xp = x + (((m >> 5) * (C >> 3) + sp * (CS / 8)) << 8) + ((m & 31) << 3);
-#pragma unroll
-            for (int c8 = 0; c8 < CS / 8; c8++) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(xp + c8 * 256), a1 = *reinterpret_cast<const f32x4 *>(xp + c8 * 256 + 4);
-#pragma unroll
-                for (int i = 0; i < 4; i++) { xn[8 * c8 + i] = a0[i]; xn[8 * c8 + 4 + i] = a1[i]; }
-            }
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < CS; c++) s += xn[c];
@@ -330,11 +347,19 @@ void attn_last1_kernel(const float *__restrict__ x, const float *__restrict__ ga
             for (int k = 0; k < 4; k++) pS[h * T + lane + 64 * k] = v[k] * inv;
         }
         __syncthreads();
-        // z_h[c] = sum_t p_h[t] xn_t[c]: tokens -> features through LDS, 64 tokens per pass; in a pass thread (c = tok, sp)
-        // takes the sp-th TQ / S tokens
-        float z[NH];
+        // z_h[c] = sum_t p_h[t] xn_t[c]: tokens -> features through LDS, TQ tokens per pass.  In a pass thread (pair, slice zs, head half hh)
+        // takes the features 2 pair, 2 pair + 1, the zs-th TQ / S tokens and the heads of half hh: one 8-byte read per token, one 16-byte read
+        // of p_h per four tokens and head, packed FMAs on the feature pair (round 6; until then one feature and all heads per thread: twice
+        // the probability reads -- which bound the phase -- and twice the vector instructions per product).  Every (feature, head) keeps its
+        // chain of products in the order it always had (tokens ascending inside a slice of TQ / S per pass, the S slices added in index
+        // order): the logits do not change by a bit.
+        constexpr int TG = TQ / S, NPAIR = C / 2, NHH = (NH + 1) / 2;
+        static_assert(2 * S * NPAIR <= 256 * S && TG % 4 == 0 && S * NH * C <= TQ * XS, "thread map of the z phase; the partial z alias xT");
+        const int zp = tid % NPAIR, zg = tid / NPAIR, zs = zg % S, h0 = (zg / S) * NHH;
+        const bool zon = zg < 2 * S;
+        f32x2 z2[NHH];
 #pragma unroll
-        for (int h = 0; h < NH; h++) z[h] = 0.0f;
+        for (int h = 0; h < NHH; h++) z2[h] = (f32x2){0.0f, 0.0f};
 #pragma unroll 1
         for (int pass = 0; pass < T / TQ; pass++) {
             if ((wave & 3) == pass) {
@@ -346,43 +371,48 @@ void attn_last1_kernel(const float *__restrict__ x, const float *__restrict__ ga
                     for (int i = 0; i < 4; i++) v[i] = xn[4 * c4 + i];
                     *reinterpret_cast<f32x4 *>(row + 4 * c4) = v;
                 }
+                if (r + 1 < nr) load_row(r + 1);                    // this wave's registers are free: the next row's tokens, ahead of their use
             }
-            __syncthreads();
-            if (tok < C) {
-                const float *pp = pS + pass * TQ + sp * (TQ / S);
-                const float *xr = xT + (sp * (TQ / S)) * XS + tok;
+            last1_lds_barrier();
+            if (zon) {
+                const float *pp = pS + pass * TQ + zs * TG + h0 * T;
+                const float *xr = xT + (zs * TG) * XS + 2 * zp;
 #pragma unroll
-                for (int t4 = 0; t4 < TQ / S / 4; t4++) {
-                    const float x0 = xr[(4 * t4) * XS], x1 = xr[(4 * t4 + 1) * XS], x2 = xr[(4 * t4 + 2) * XS], x3 = xr[(4 * t4 + 3) * XS];
+                for (int t4 = 0; t4 < TG / 4; t4++) {
+                    f32x2 xv[4];
 #pragma unroll
-                    for (int h = 0; h < NH; h++) {
-                        const f32x4 p = *reinterpret_cast<const f32x4 *>(pp + h * T + 4 * t4);
-                        z[h] = fmaf(p[0], x0, z[h]); z[h] = fmaf(p[1], x1, z[h]); z[h] = fmaf(p[2], x2, z[h]); z[h] = fmaf(p[3], x3, z[h]);
+                    for (int i = 0; i < 4; i++) xv[i] = *reinterpret_cast<const f32x2 *>(xr + (4 * t4 + i) * XS);
+#pragma unroll
+                    for (int h = 0; h < NHH; h++) {
+                        if (h0 + h < NH) {                          // (uniform per wave half at most: NH odd)
+                            const f32x4 p = *reinterpret_cast<const f32x4 *>(pp + h * T + 4 * t4);
+#pragma unroll
+                            for (int i = 0; i < 4; i++) z2[h] = __builtin_elementwise_fma(xv[i], (f32x2){p[i], p[i]}, z2[h]);
+                        }
                     }
                 }
             }
-            __syncthreads();
+            last1_lds_barrier();
         }
-        // the S partial z meet in LDS (the probabilities are spent); u of this row is spent too: its slice now holds z
-        if (S > 1) {
-            if (tok < C) {
+        // the S partial z of every head meet in LDS (xT is spent); u of this row is spent too: its slice now holds z
+        {
+            float *zpart = xT;                                      // [S][NH][C]
+            if (zon) {
 #pragma unroll
-                for (int h = 0; h < NH; h++) pS[(sp * NH + h) * T + tok] = z[h];
+                for (int h = 0; h < NHH; h++)
+                    if (h0 + h < NH) *reinterpret_cast<f32x2 *>(zpart + (zs * NH + h0 + h) * C + 2 * zp) = z2[h];
             }
-            __syncthreads();
+            last1_lds_barrier();
             if (tid < C) {
 #pragma unroll
                 for (int h = 0; h < NH; h++) {
                     float a = 0.0f;
 #pragma unroll
-                    for (int q = 0; q < S; q++) a += pS[(q * NH + h) * T + tid];
-                    ur[h * C + tid] = a * gain[tid];                // z of xhat -> z of xn
+                    for (int q = 0; q < S; q++) a += zpart[(q * NH + h) * C + tid];
+                    ur[h * C + tid] = a * gain_tid;                 // z of xhat -> z of xn
                 }
             }
-            __syncthreads();
-        } else if (tid < C) {
-#pragma unroll
-            for (int h = 0; h < NH; h++) ur[h * C + tid] = z[h] * gain[tid];
+            last1_lds_barrier();
         }
     }
     __syncthreads();

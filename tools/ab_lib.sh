@@ -15,7 +15,7 @@ while [ $# -ge 3 ]; do
     python - <<PY
 import json
 d = json.loads(open("$OUT/$v.json").read().strip().splitlines()[-1])
-print("%-10s $W $P" % "$v", round(d["ms_per_step"], 2), {k: round(x, 2) for k, x in d["kernel_ms_per_step"].items() if x > 0.5})
+print("%-10s $W $P" % "$v", round(d["ms_per_step"], 2), {k: round(x, 2) for k, x in d["kernel_ms_per_step"].items() if x > 0.5}, {k: round(x, 3) for k, x in d.get("kernel_ms_per_step_last_layer_launches", {}).items()})
 PY
   done
 done | tee $OUT/ab.txt
